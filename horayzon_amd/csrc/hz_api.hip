@@ -1,0 +1,601 @@
+// hz_api.hip -- C-ABI entry points of libhorayzon_hip.so (see include/horayzon_hip.h).
+//
+// Host-side driver logic restating horizon_gridded_comp (horizon_comp.cpp:629-822)
+// and CppTerrain (shadow_comp.cpp:304-605): unit conversions, trig tables with the
+// reference's float/double promotion pattern, uploads, kernel launches, reports.
+#include "hz_internal.h"
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <limits>
+
+namespace hz {
+
+static thread_local std::string g_error;
+
+int set_error(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+bool is_device_ptr(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t attr;
+    const hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+    return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+// device view of an input array that may live on the host
+template <typename T>
+struct DevIn {
+    const T *dev = nullptr;
+    void *owned = nullptr;
+    ~DevIn() { if (owned) (void)hipFree(owned); }
+    int bind(const T *src, size_t count, hipStream_t st) {
+        if (!src || count == 0) { dev = nullptr; return HZ_OK; }
+        if (is_device_ptr(src)) { dev = src; return HZ_OK; }
+        HZ_HIP(hipMalloc(&owned, count * sizeof(T)));
+        HZ_HIP(hipMemcpyAsync(owned, src, count * sizeof(T), hipMemcpyHostToDevice, st));
+        dev = static_cast<const T *>(owned);
+        return HZ_OK;
+    }
+};
+
+// device buffer for an output array that may live on the host
+template <typename T>
+struct DevOut {
+    T *dev = nullptr;
+    T *host = nullptr;
+    void *owned = nullptr;
+    size_t count = 0;
+    ~DevOut() { if (owned) (void)hipFree(owned); }
+    int bind(T *dst, size_t n) {
+        count = n;
+        if (!dst || n == 0) { dev = nullptr; return HZ_OK; }
+        if (is_device_ptr(dst)) { dev = dst; return HZ_OK; }
+        HZ_HIP(hipMalloc(&owned, n * sizeof(T)));
+        dev = static_cast<T *>(owned); host = dst;
+        return HZ_OK;
+    }
+    int finish(hipStream_t st) {
+        if (host && count) HZ_HIP(hipMemcpyAsync(host, dev, count * sizeof(T), hipMemcpyDeviceToHost, st));
+        return HZ_OK;
+    }
+};
+
+static int select_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return set_error(HZ_ERR_NODEV, "no HIP device available (libhorayzon_hip needs an MI355X / gfx950 GPU)");
+    }
+    if (device < 0 || device >= n) return set_error(HZ_ERR_ARG, "device %d out of range (%d devices)", device, n);
+    HZ_HIP(hipSetDevice(device));
+    return HZ_OK;
+}
+
+// ---- helpers restating horizon_comp.cpp:37-39 ------------------------------------------
+static inline float deg2rad_f(float ang) { return (float)(((double)ang / 180.0) * M_PI); }
+
+struct HostTables {
+    std::vector<float> azim_sin, azim_cos, elev_ang, elev_sin, elev_cos;
+    int elev_num = 0;
+    float hori_acc = 0, low = 0, up = 0;
+};
+
+// horizon_comp.cpp:648, :667-669, :711-731
+static void build_tables(int azim_num, float hori_acc_deg, float low_deg, HostTables &t) {
+    float elev_ang_up_lim = 89.98;
+    t.hori_acc = deg2rad_f(hori_acc_deg);
+    t.low = deg2rad_f(low_deg);
+    t.up = deg2rad_f(elev_ang_up_lim);
+    t.azim_sin.resize((size_t)azim_num); t.azim_cos.resize((size_t)azim_num);
+    float ang;
+    for (int i = 0; i < azim_num; i++) {
+        ang = (float)(((2 * M_PI) / azim_num) * i);
+        t.azim_sin[(size_t)i] = sinf(ang);
+        t.azim_cos[(size_t)i] = cosf(ang);
+    }
+    const double step = (double)t.hori_acc / 5.0;
+    t.elev_num = (int)ceil((double)(t.up - t.low) / step) + 1;
+    const size_t n = (size_t)std::max(t.elev_num, 0);
+    t.elev_ang.resize(n); t.elev_sin.resize(n); t.elev_cos.resize(n);
+    for (int i = 0; i < t.elev_num; i++) {
+        ang = (float)((double)t.up - step * (double)i);
+        t.elev_ang[(size_t)(t.elev_num - i - 1)] = ang;
+        t.elev_sin[(size_t)(t.elev_num - i - 1)] = sinf(ang);
+        t.elev_cos[(size_t)(t.elev_num - i - 1)] = cosf(ang);
+    }
+}
+
+static int parse_alg(const char *s, int *alg) {
+    if (s && strcmp(s, "discrete_sampling") == 0) { *alg = 0; return HZ_OK; }
+    if (s && strcmp(s, "binary_search") == 0) { *alg = 1; return HZ_OK; }
+    if (s && strcmp(s, "guess_constant") == 0) { *alg = 2; return HZ_OK; }
+    return set_error(HZ_ERR_ARG, "invalid input argument for ray_algorithm");
+}
+
+static int check_geom(const char *s) {
+    // all three describe the same surface (horizon_comp.cpp:139-183); the explicit
+    // "triangle" split is what the LBVH leaves hold
+    if (s && (strcmp(s, "triangle") == 0 || strcmp(s, "quad") == 0 || strcmp(s, "grid") == 0)) return HZ_OK;
+    return set_error(HZ_ERR_ARG, "invalid input argument for geom_type");
+}
+
+static int scene_new(int device, Scene **out) {
+    int rc = select_device(device);
+    if (rc) return rc;
+    Scene *sc = new Scene();
+    sc->device = device;
+    const hipError_t e = hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete sc; return set_error(HZ_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    *out = sc;
+    return HZ_OK;
+}
+
+static void scene_free(Scene *sc) {
+    if (!sc) return;
+    (void)hipSetDevice(sc->device);
+    if (sc->stream) { (void)hipStreamSynchronize(sc->stream); (void)hipStreamDestroy(sc->stream); }
+    if (sc->owns_blob && sc->blob) (void)hipFree(sc->blob);
+    delete sc;
+}
+
+struct Terrain {
+    int device = 0;
+    Scene *scene = nullptr;
+    bool owns_scene = false;
+    int offset_0 = 0, offset_1 = 0, dim_in_0 = 0, dim_in_1 = 0;
+    void *tilt = nullptr, *norm = nullptr, *enl = nullptr, *elev = nullptr, *mask = nullptr;
+    bool own_tilt = false, own_norm = false, own_enl = false, own_elev = false, own_mask = false;
+    float fill = 0, ang_max = 89.0f;
+    int refrac = 0;
+    unsigned long long *counters = nullptr;
+    hipStream_t stream = nullptr;
+    bool initialised = false;
+};
+
+static void terrain_release_arrays(Terrain *t) {
+    if (t->own_tilt && t->tilt) (void)hipFree(t->tilt);
+    if (t->own_norm && t->norm) (void)hipFree(t->norm);
+    if (t->own_enl && t->enl) (void)hipFree(t->enl);
+    if (t->own_elev && t->elev) (void)hipFree(t->elev);
+    if (t->own_mask && t->mask) (void)hipFree(t->mask);
+    t->tilt = t->norm = t->enl = t->elev = t->mask = nullptr;
+    t->own_tilt = t->own_norm = t->own_enl = t->own_elev = t->own_mask = false;
+    if (t->owns_scene && t->scene) scene_free(t->scene);
+    t->scene = nullptr; t->owns_scene = false; t->initialised = false;
+}
+
+// persistent device copy (Terrain keeps its inputs in HBM instead of raw host pointers,
+// shadow_comp.cpp:332-346)
+static int persist(const void *src, size_t bytes, hipStream_t st, void **dst, bool *own) {
+    if (is_device_ptr(src)) { *dst = const_cast<void *>(src); *own = false; return HZ_OK; }
+    HZ_HIP(hipMalloc(dst, bytes ? bytes : 16));
+    *own = true;
+    HZ_HIP(hipMemcpyAsync(*dst, src, bytes, hipMemcpyHostToDevice, st));
+    return HZ_OK;
+}
+
+static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_north, int offset_0,
+                       int offset_1, float *hori_buffer, int dim_in_0, int dim_in_1, int azim_num,
+                       float dist_search, float hori_acc, const char *ray_algorithm,
+                       float elev_ang_low_lim, const uint8_t *mask, float hori_fill, float ray_org_elev,
+                       const hz_opts *opts, hz_stats *stats) {
+    int alg = 2;
+    int rc = parse_alg(ray_algorithm, &alg);
+    if (rc) return rc;
+    if (!vec_norm || !vec_north || !mask) return set_error(HZ_ERR_ARG, "vec_norm, vec_north and mask must not be NULL");
+    if (dim_in_0 <= 0 || dim_in_1 <= 0 || azim_num <= 0) return set_error(HZ_ERR_ARG, "dim_in_0, dim_in_1 and azim_num must be positive");
+    if (offset_0 < 0 || offset_1 < 0 || offset_0 + dim_in_0 > sc->hdr.d0 || offset_1 + dim_in_1 > sc->hdr.d1)
+        return set_error(HZ_ERR_ARG, "inconsistency between input arguments dem_dim_0, dem_dim_1, offset_0, offset_1 and vec_norm");
+    if (!(hori_acc > 0.0f) || hori_acc > 10.0f) return set_error(HZ_ERR_ARG, "limit of hori_acc (10 degree) is exceeded");
+    const bool skip_hori = opts && opts->skip_hori;
+    if (!hori_buffer && !skip_hori) return set_error(HZ_ERR_ARG, "hori_buffer is NULL");
+    if (opts && opts->svf && !opts->vec_tilt) return set_error(HZ_ERR_ARG, "opts.svf needs opts.vec_tilt");
+    int row_begin = 0, row_end = dim_in_0;
+    if (opts) {
+        if (opts->row_begin > 0) row_begin = opts->row_begin;
+        if (opts->row_end > 0) row_end = std::min(opts->row_end, dim_in_0);
+    }
+    if (row_begin >= row_end) return set_error(HZ_ERR_ARG, "empty row slab [%d, %d)", row_begin, row_end);
+    HZ_HIP(hipSetDevice(sc->device));
+    hipStream_t st = sc->stream;
+    Timer t_total; t_total.start();
+
+    // unit conversions: horizon_comp.cpp:667-670
+    HostTables tb;
+    build_tables(azim_num, hori_acc, elev_ang_low_lim, tb);
+    if (tb.elev_num < 2) return set_error(HZ_ERR_ARG, "elevation table is empty (elev_ang_low_lim too high)");
+    const float dist_m = (float)((double)dist_search * 1000.0);
+
+    const size_t ncell = (size_t)dim_in_0 * dim_in_1;
+    const size_t slab_cells = (size_t)(row_end - row_begin) * dim_in_1;
+    Timer t_h2d; t_h2d.start();
+    DevIn<float> d_norm, d_north, d_tilt, d_as, d_ac, d_ea, d_es, d_ec;
+    DevIn<uint8_t> d_mask;
+    if ((rc = d_norm.bind(vec_norm, ncell * 3, st))) return rc;
+    if ((rc = d_north.bind(vec_north, ncell * 3, st))) return rc;
+    if ((rc = d_mask.bind(mask, ncell, st))) return rc;
+    if (opts && opts->svf) if ((rc = d_tilt.bind(opts->vec_tilt, ncell * 3, st))) return rc;
+    if ((rc = d_as.bind(tb.azim_sin.data(), (size_t)azim_num, st))) return rc;
+    if ((rc = d_ac.bind(tb.azim_cos.data(), (size_t)azim_num, st))) return rc;
+    if ((rc = d_ea.bind(tb.elev_ang.data(), (size_t)tb.elev_num, st))) return rc;
+    if ((rc = d_es.bind(tb.elev_sin.data(), (size_t)tb.elev_num, st))) return rc;
+    if ((rc = d_ec.bind(tb.elev_cos.data(), (size_t)tb.elev_num, st))) return rc;
+    DevOut<float> d_hori, d_svf;
+    float *hori_slab_host = hori_buffer ? hori_buffer + (size_t)row_begin * dim_in_1 * azim_num : nullptr;
+    if (!skip_hori) if ((rc = d_hori.bind(hori_slab_host, slab_cells * (size_t)azim_num))) return rc;
+    float *svf_slab = (opts && opts->svf) ? opts->svf + (size_t)row_begin * dim_in_1 : nullptr;
+    if ((rc = d_svf.bind(svf_slab, svf_slab ? slab_cells : 0))) return rc;
+    DevIn<unsigned long long> d_cnt;
+    unsigned long long zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void *cnt_dev = nullptr;
+    HZ_HIP(hipMalloc(&cnt_dev, sizeof(zeros)));
+    d_cnt.owned = cnt_dev;
+    HZ_HIP(hipMemcpyAsync(cnt_dev, zeros, sizeof(zeros), hipMemcpyHostToDevice, st));
+    HZ_HIP(hipStreamSynchronize(st));
+    const double h2d_s = t_h2d.stop();
+
+    HorizonArgs a;
+    a.vec_norm = d_norm.dev; a.vec_north = d_north.dev; a.mask = d_mask.dev;
+    // kernels index by global cell: shift slab-local buffers back by row_begin rows
+    a.hori = d_hori.dev ? d_hori.dev - (size_t)row_begin * dim_in_1 * azim_num : nullptr;
+    a.svf = d_svf.dev ? d_svf.dev - (size_t)row_begin * dim_in_1 : nullptr;
+    a.vec_tilt = d_tilt.dev;
+    a.offset_0 = offset_0; a.offset_1 = offset_1; a.dim_in_0 = dim_in_0; a.dim_in_1 = dim_in_1;
+    a.row_begin = row_begin; a.row_end = row_end;
+    a.azim_num = azim_num; a.elev_num = tb.elev_num; a.alg = alg;
+    a.hori_acc = tb.hori_acc; a.low = tb.low; a.up = tb.up; a.dist = dist_m;
+    a.hori_fill = hori_fill; a.ray_org_elev = ray_org_elev;
+    a.azim_sin = d_as.dev; a.azim_cos = d_ac.dev; a.elev_ang = d_ea.dev; a.elev_sin = d_es.dev; a.elev_cos = d_ec.dev;
+    a.top_nodes = opts ? opts->top_nodes : -1;
+    a.regroup = opts ? opts->regroup : -1;
+    a.count_work = opts ? opts->count_work : 0;
+    a.counters = (unsigned long long *)cnt_dev;
+
+    hipEvent_t e0, e1;
+    HZ_HIP(hipEventCreate(&e0)); HZ_HIP(hipEventCreate(&e1));
+    HZ_HIP(hipEventRecord(e0, st));
+    rc = horizon_launch(sc, a, st);
+    if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+    HZ_HIP(hipEventRecord(e1, st));
+    HZ_HIP(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    HZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    HZ_HIP(hipGetLastError());
+
+    Timer t_d2h; t_d2h.start();
+    unsigned long long cnt[8];
+    HZ_HIP(hipMemcpyAsync(cnt, cnt_dev, sizeof(cnt), hipMemcpyDeviceToHost, st));
+    if ((rc = d_hori.finish(st))) return rc;
+    if ((rc = d_svf.finish(st))) return rc;
+    HZ_HIP(hipStreamSynchronize(st));
+    const double d2h_s = t_d2h.stop();
+
+    if (stats) {
+        stats->num_rays += cnt[0]; stats->guard_events += cnt[1];
+        stats->nodes_visited += cnt[2]; stats->tris_tested += cnt[3]; stats->num_cells += cnt[4];
+        stats->t_h2d_s += h2d_s; stats->t_kernel_s += (double)ms * 1e-3; stats->t_d2h_s += d2h_s;
+        stats->t_total_s += t_total.stop();
+        stats->elev_num = tb.elev_num; stats->bvh_height = sc->hdr.height; stats->scene_bytes = sc->hdr.total_bytes;
+    }
+    if (opts && opts->verbose) {   // the reference's report, horizon_comp.cpp:692-700, 805-810
+        printf("Number of grid cells for which horizon is computed: %llu \n", cnt[4]);
+        printf("Ray tracing time: %g s\n", (double)ms * 1e-3);
+        printf("Number of rays shot: %llu\n", cnt[0]);
+        if (cnt[4]) printf("Average number of rays per location and azimuth: %.2f \n",
+                           (double)cnt[0] / ((double)cnt[4] * azim_num));
+    }
+    return HZ_OK;
+}
+
+}  // namespace hz
+
+using namespace hz;
+
+extern "C" {
+
+const char *hz_last_error(void) { return g_error.c_str(); }
+
+int hz_device_count(int *count) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    if (count) *count = n;
+    return HZ_OK;
+}
+
+int hz_device_info(int device, char *name, int cap, int *cu, uint64_t *hbm_bytes) {
+    int rc = select_device(device);
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    HZ_HIP(hipGetDeviceProperties(&prop, device));
+    if (name && cap > 0) { strncpy(name, prop.gcnArchName, (size_t)cap - 1); name[cap - 1] = 0; }
+    if (cu) *cu = prop.multiProcessorCount;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)prop.totalGlobalMem;
+    return HZ_OK;
+}
+
+int hz_scene_create(const float *vert_grid, int dem_dim_0, int dem_dim_1, const char *geom_type,
+                    const float *vert_simp, int num_vert_simp, const int32_t *tri_ind_simp,
+                    int num_tri_simp, int device, hz_scene **scene, hz_stats *stats) {
+    if (!scene || !vert_grid) return set_error(HZ_ERR_ARG, "scene / vert_grid is NULL");
+    int rc = check_geom(geom_type);
+    if (rc) return rc;
+    Scene *sc = nullptr;
+    if ((rc = scene_new(device, &sc))) return rc;
+    rc = scene_build(sc, vert_grid, dem_dim_0, dem_dim_1, vert_simp, num_vert_simp, tri_ind_simp,
+                     num_tri_simp, stats);
+    if (rc) { scene_free(sc); return rc; }
+    *scene = reinterpret_cast<hz_scene *>(sc);
+    return HZ_OK;
+}
+
+int hz_scene_blob(const hz_scene *scene, void **device_ptr, size_t *nbytes) {
+    if (!scene) return set_error(HZ_ERR_ARG, "scene is NULL");
+    const Scene *sc = reinterpret_cast<const Scene *>(scene);
+    if (device_ptr) *device_ptr = sc->blob;
+    if (nbytes) *nbytes = sc->blob_bytes;
+    return HZ_OK;
+}
+
+int hz_scene_adopt(void *device_ptr, size_t nbytes, int device, hz_scene **scene) {
+    if (!device_ptr || !scene || nbytes < sizeof(BlobHeader)) return set_error(HZ_ERR_ARG, "invalid blob");
+    Scene *sc = nullptr;
+    int rc = scene_new(device, &sc);
+    if (rc) return rc;
+    BlobHeader h;
+    const hipError_t e = hipMemcpy(&h, device_ptr, sizeof(h), hipMemcpyDeviceToHost);
+    if (e != hipSuccess) { scene_free(sc); return set_error(HZ_ERR_HIP, "reading blob header failed: %s", hipGetErrorString(e)); }
+    if (h.magic != HZ_BLOB_MAGIC || h.version != HZ_BLOB_VERSION || h.total_bytes > nbytes) {
+        scene_free(sc);
+        return set_error(HZ_ERR_ARG, "not a horayzon scene blob (magic/version/size mismatch)");
+    }
+    sc->blob = device_ptr; sc->blob_bytes = nbytes; sc->owns_blob = false; sc->hdr = h;
+    *scene = reinterpret_cast<hz_scene *>(sc);
+    return HZ_OK;
+}
+
+int hz_scene_destroy(hz_scene *scene) {
+    scene_free(reinterpret_cast<Scene *>(scene));
+    return HZ_OK;
+}
+
+int hz_horizon_gridded_scene(const hz_scene *scene, const float *vec_norm, const float *vec_north,
+                             int offset_0, int offset_1, float *hori_buffer, int dim_in_0, int dim_in_1,
+                             int azim_num, float dist_search, float hori_acc, const char *ray_algorithm,
+                             float elev_ang_low_lim, const uint8_t *mask, float hori_fill,
+                             float ray_org_elev, const hz_opts *opts, hz_stats *stats) {
+    if (!scene) return set_error(HZ_ERR_ARG, "scene is NULL");
+    return horizon_run(reinterpret_cast<const Scene *>(scene), vec_norm, vec_north, offset_0, offset_1,
+                       hori_buffer, dim_in_0, dim_in_1, azim_num, dist_search, hori_acc, ray_algorithm,
+                       elev_ang_low_lim, mask, hori_fill, ray_org_elev, opts, stats);
+}
+
+int hz_horizon_gridded(const float *vert_grid, int dem_dim_0, int dem_dim_1, const float *vec_norm,
+                       const float *vec_north, int offset_0, int offset_1, float *hori_buffer,
+                       int dim_in_0, int dim_in_1, int azim_num, float dist_search, float hori_acc,
+                       const char *ray_algorithm, const char *geom_type, const float *vert_simp,
+                       int num_vert_simp, const int32_t *tri_ind_simp, int num_tri_simp,
+                       float elev_ang_low_lim, const uint8_t *mask, float hori_fill, float ray_org_elev,
+                       const hz_opts *opts, hz_stats *stats) {
+    Timer t; t.start();
+    hz_scene *scene = nullptr;
+    hz_stats local;
+    memset(&local, 0, sizeof(local));
+    int rc = hz_scene_create(vert_grid, dem_dim_0, dem_dim_1, geom_type, vert_simp, num_vert_simp,
+                             tri_ind_simp, num_tri_simp, opts ? opts->device : 0, &scene, &local);
+    if (rc) return rc;
+    if (opts && opts->verbose) printf("BVH build time: %g s\n", local.t_bvh_s);
+    rc = hz_horizon_gridded_scene(scene, vec_norm, vec_north, offset_0, offset_1, hori_buffer, dim_in_0,
+                                  dim_in_1, azim_num, dist_search, hori_acc, ray_algorithm,
+                                  elev_ang_low_lim, mask, hori_fill, ray_org_elev, opts, &local);
+    hz_scene_destroy(scene);   // the reference also releases the scene per call, horizon_comp.cpp:813-814
+    local.t_total_s = t.stop();
+    if (opts && opts->verbose) printf("Total run time: %g s\n", local.t_total_s);
+    if (stats) *stats = local;
+    return rc;
+}
+
+int hz_horizon_tables(int azim_num, float hori_acc, float elev_ang_low_lim, float *azim_sin,
+                      float *azim_cos, int elev_cap, float *elev_ang, float *elev_sin, float *elev_cos,
+                      int *elev_num) {
+    if (azim_num <= 0 || !(hori_acc > 0.0f)) return set_error(HZ_ERR_ARG, "azim_num and hori_acc must be positive");
+    HostTables t;
+    build_tables(azim_num, hori_acc, elev_ang_low_lim, t);
+    if (elev_num) *elev_num = t.elev_num;
+    if (azim_sin) memcpy(azim_sin, t.azim_sin.data(), sizeof(float) * (size_t)azim_num);
+    if (azim_cos) memcpy(azim_cos, t.azim_cos.data(), sizeof(float) * (size_t)azim_num);
+    if (elev_ang && elev_sin && elev_cos && t.elev_num > 0 && t.elev_num <= elev_cap) {
+        memcpy(elev_ang, t.elev_ang.data(), sizeof(float) * (size_t)t.elev_num);
+        memcpy(elev_sin, t.elev_sin.data(), sizeof(float) * (size_t)t.elev_num);
+        memcpy(elev_cos, t.elev_cos.data(), sizeof(float) * (size_t)t.elev_num);
+    }
+    return HZ_OK;
+}
+
+int hz_sky_view_factor(const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
+                       int len_2, float *svf, int device) {
+    if (!azim || !hori || !vec_tilt || !svf) return set_error(HZ_ERR_ARG, "NULL argument");
+    if (len_0 <= 0 || len_1 <= 0 || len_2 < 2) return set_error(HZ_ERR_ARG, "Inconsistent/incorrect shapes of input arrays");
+    int rc = select_device(device);
+    if (rc) return rc;
+    hipStream_t st = nullptr;
+    const size_t ncell = (size_t)len_0 * len_1;
+    DevIn<float> d_azim, d_hori, d_tilt;
+    DevOut<float> d_svf;
+    if ((rc = d_azim.bind(azim, (size_t)len_2, st))) return rc;
+    if ((rc = d_hori.bind(hori, ncell * (size_t)len_2, st))) return rc;
+    if ((rc = d_tilt.bind(vec_tilt, ncell * 3, st))) return rc;
+    if ((rc = d_svf.bind(svf, ncell))) return rc;
+    if ((rc = svf_launch(d_azim.dev, d_hori.dev, d_tilt.dev, len_0, len_1, len_2, d_svf.dev, st))) return rc;
+    if ((rc = d_svf.finish(st))) return rc;
+    HZ_HIP(hipStreamSynchronize(st));
+    return HZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// Terrain (shadow_comp.h:4-39)
+// ---------------------------------------------------------------------------------------
+
+int hz_terrain_create(int device, hz_terrain **terrain) {
+    if (!terrain) return set_error(HZ_ERR_ARG, "terrain is NULL");
+    int rc = select_device(device);
+    if (rc) return rc;
+    Terrain *t = new Terrain();
+    t->device = device;
+    *terrain = reinterpret_cast<hz_terrain *>(t);
+    return HZ_OK;
+}
+
+static int terrain_init_common(Terrain *t, int offset_0, int offset_1, const float *vec_tilt,
+                               const float *vec_norm, int dim_in_0, int dim_in_1, const float *surf_enl_fac,
+                               const float *elevation, const uint8_t *mask, float sw_dir_cor_fill,
+                               float ang_max, int refrac_cor) {
+    const Scene *sc = t->scene;
+    if (!vec_tilt || !vec_norm || !surf_enl_fac || !elevation || !mask) return set_error(HZ_ERR_ARG, "NULL input array");
+    if (dim_in_0 <= 0 || dim_in_1 <= 0 || offset_0 < 0 || offset_1 < 0 ||
+        offset_0 + dim_in_0 > sc->hdr.d0 || offset_1 + dim_in_1 > sc->hdr.d1)
+        return set_error(HZ_ERR_ARG, "inconsistency between input arguments 'dem_dim_0', 'dem_dim_1', 'offset_0', 'offset_1' and 'vec_norm'");
+    if (ang_max < 85.0f || ang_max > 89.99f) return set_error(HZ_ERR_ARG, "'ang_max' must be in the range [85.0, 89.99]");
+    hipStream_t st = sc->stream;
+    const size_t nc = (size_t)dim_in_0 * dim_in_1;
+    int rc;
+    if ((rc = persist(vec_tilt, nc * 12, st, &t->tilt, &t->own_tilt))) return rc;
+    if ((rc = persist(vec_norm, nc * 12, st, &t->norm, &t->own_norm))) return rc;
+    if ((rc = persist(surf_enl_fac, nc * 4, st, &t->enl, &t->own_enl))) return rc;
+    if ((rc = persist(elevation, nc * 4, st, &t->elev, &t->own_elev))) return rc;
+    if ((rc = persist(mask, nc, st, &t->mask, &t->own_mask))) return rc;
+    if (!t->counters) HZ_HIP(hipMalloc((void **)&t->counters, 8 * sizeof(unsigned long long)));
+    HZ_HIP(hipStreamSynchronize(st));
+    t->offset_0 = offset_0; t->offset_1 = offset_1; t->dim_in_0 = dim_in_0; t->dim_in_1 = dim_in_1;
+    t->fill = sw_dir_cor_fill; t->ang_max = ang_max; t->refrac = refrac_cor ? 1 : 0;
+    t->stream = st;
+    t->initialised = true;
+    return HZ_OK;
+}
+
+int hz_terrain_initialise(hz_terrain *terrain, const float *vert_grid, int dem_dim_0, int dem_dim_1,
+                          int offset_0, int offset_1, const float *vec_tilt, const float *vec_norm,
+                          int dim_in_0, int dim_in_1, const float *surf_enl_fac, const float *elevation,
+                          const uint8_t *mask, const char *geom_type, float sw_dir_cor_fill, float ang_max,
+                          int refrac_cor, hz_stats *stats) {
+    if (!terrain) return set_error(HZ_ERR_ARG, "terrain is NULL");
+    Terrain *t = reinterpret_cast<Terrain *>(terrain);
+    terrain_release_arrays(t);
+    hz_scene *scene = nullptr;
+    // no simplified outer TIN in the shadow scene: shadow_comp.cpp:198-298
+    int rc = hz_scene_create(vert_grid, dem_dim_0, dem_dim_1, geom_type, nullptr, 0, nullptr, 0, t->device,
+                             &scene, stats);
+    if (rc) return rc;
+    t->scene = reinterpret_cast<Scene *>(scene);
+    t->owns_scene = true;
+    rc = terrain_init_common(t, offset_0, offset_1, vec_tilt, vec_norm, dim_in_0, dim_in_1, surf_enl_fac,
+                             elevation, mask, sw_dir_cor_fill, ang_max, refrac_cor);
+    if (rc) terrain_release_arrays(t);
+    return rc;
+}
+
+int hz_terrain_initialise_scene(hz_terrain *terrain, const hz_scene *scene, int offset_0, int offset_1,
+                                const float *vec_tilt, const float *vec_norm, int dim_in_0, int dim_in_1,
+                                const float *surf_enl_fac, const float *elevation, const uint8_t *mask,
+                                float sw_dir_cor_fill, float ang_max, int refrac_cor) {
+    if (!terrain || !scene) return set_error(HZ_ERR_ARG, "terrain / scene is NULL");
+    Terrain *t = reinterpret_cast<Terrain *>(terrain);
+    terrain_release_arrays(t);
+    t->scene = const_cast<Scene *>(reinterpret_cast<const Scene *>(scene));
+    t->owns_scene = false;
+    int rc = terrain_init_common(t, offset_0, offset_1, vec_tilt, vec_norm, dim_in_0, dim_in_1, surf_enl_fac,
+                                 elevation, mask, sw_dir_cor_fill, ang_max, refrac_cor);
+    if (rc) terrain_release_arrays(t);
+    return rc;
+}
+
+static int terrain_run(Terrain *t, const float *sun_positions, int num_sun, int which, uint8_t *out_u8,
+                       float *out_f32, hz_stats *stats) {
+    if (!t || !t->initialised) return set_error(HZ_ERR_ARG, "Terrain is not initialised");
+    if (!sun_positions || num_sun <= 0) return set_error(HZ_ERR_ARG, "array 'sun_position' has incorrect shape");
+    if ((which == 0 && !out_u8) || (which == 1 && !out_f32)) return set_error(HZ_ERR_ARG, "output buffer is NULL");
+    HZ_HIP(hipSetDevice(t->device));
+    hipStream_t st = t->stream;
+    Timer t_total; t_total.start();
+    const size_t nc = (size_t)t->dim_in_0 * t->dim_in_1;
+    std::vector<float> sun((size_t)num_sun * 3);
+    if (is_device_ptr(sun_positions)) HZ_HIP(hipMemcpy(sun.data(), sun_positions, sun.size() * 4, hipMemcpyDeviceToHost));
+    else memcpy(sun.data(), sun_positions, sun.size() * 4);
+    DevOut<uint8_t> d_u8; DevOut<float> d_f32;
+    int rc;
+    if (which == 0) { if ((rc = d_u8.bind(out_u8, nc * (size_t)num_sun))) return rc; }
+    else { if ((rc = d_f32.bind(out_f32, nc * (size_t)num_sun))) return rc; }
+    HZ_HIP(hipMemsetAsync(t->counters, 0, 8 * sizeof(unsigned long long), st));
+    ShadowArgs a;
+    a.vec_tilt = (const float *)t->tilt; a.vec_norm = (const float *)t->norm;
+    a.surf_enl_fac = (const float *)t->enl; a.elevation = (const float *)t->elev; a.mask = (const uint8_t *)t->mask;
+    a.offset_0 = t->offset_0; a.offset_1 = t->offset_1; a.dim_in_0 = t->dim_in_0; a.dim_in_1 = t->dim_in_1;
+    a.sw_dir_cor_fill = t->fill;
+    a.dot_prod_min = cosf(deg2rad_f(t->ang_max));            // shadow_comp.cpp:498
+    a.refrac_cor = t->refrac; a.which = which; a.top_nodes = -1; a.counters = t->counters;
+    hipEvent_t e0, e1;
+    HZ_HIP(hipEventCreate(&e0)); HZ_HIP(hipEventCreate(&e1));
+    HZ_HIP(hipEventRecord(e0, st));
+    for (int s = 0; s < num_sun; s++) {
+        a.sun[0] = sun[3 * (size_t)s]; a.sun[1] = sun[3 * (size_t)s + 1]; a.sun[2] = sun[3 * (size_t)s + 2];
+        a.out_u8 = d_u8.dev ? d_u8.dev + nc * (size_t)s : nullptr;
+        a.out_f32 = d_f32.dev ? d_f32.dev + nc * (size_t)s : nullptr;
+        if ((rc = shadow_launch(t->scene, a, st))) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+    }
+    HZ_HIP(hipEventRecord(e1, st));
+    HZ_HIP(hipEventSynchronize(e1));
+    float ms = 0.0f;
+    HZ_HIP(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    Timer t_d2h; t_d2h.start();
+    unsigned long long cnt[8];
+    HZ_HIP(hipMemcpyAsync(cnt, t->counters, sizeof(cnt), hipMemcpyDeviceToHost, st));
+    if ((rc = d_u8.finish(st))) return rc;
+    if ((rc = d_f32.finish(st))) return rc;
+    HZ_HIP(hipStreamSynchronize(st));
+    if (stats) {
+        stats->num_rays += cnt[0];
+        stats->t_kernel_s += (double)ms * 1e-3;
+        stats->t_d2h_s += t_d2h.stop();
+        stats->t_total_s += t_total.stop();
+        stats->bvh_height = t->scene->hdr.height; stats->scene_bytes = t->scene->hdr.total_bytes;
+    }
+    return HZ_OK;
+}
+
+int hz_terrain_shadow(hz_terrain *terrain, const float *sun_position, uint8_t *shadow_buffer, hz_stats *stats) {
+    return terrain_run(reinterpret_cast<Terrain *>(terrain), sun_position, 1, 0, shadow_buffer, nullptr, stats);
+}
+int hz_terrain_sw_dir_cor(hz_terrain *terrain, const float *sun_position, float *sw_dir_cor_buffer, hz_stats *stats) {
+    return terrain_run(reinterpret_cast<Terrain *>(terrain), sun_position, 1, 1, nullptr, sw_dir_cor_buffer, stats);
+}
+int hz_terrain_shadow_batch(hz_terrain *terrain, const float *sun_positions, int num_sun,
+                            uint8_t *shadow_buffers, hz_stats *stats) {
+    return terrain_run(reinterpret_cast<Terrain *>(terrain), sun_positions, num_sun, 0, shadow_buffers, nullptr, stats);
+}
+int hz_terrain_sw_dir_cor_batch(hz_terrain *terrain, const float *sun_positions, int num_sun,
+                                float *sw_dir_cor_buffers, hz_stats *stats) {
+    return terrain_run(reinterpret_cast<Terrain *>(terrain), sun_positions, num_sun, 1, nullptr, sw_dir_cor_buffers, stats);
+}
+
+int hz_terrain_destroy(hz_terrain *terrain) {
+    Terrain *t = reinterpret_cast<Terrain *>(terrain);
+    if (!t) return HZ_OK;
+    (void)hipSetDevice(t->device);
+    terrain_release_arrays(t);
+    if (t->counters) (void)hipFree(t->counters);
+    delete t;
+    return HZ_OK;
+}
+
+}  // extern "C"

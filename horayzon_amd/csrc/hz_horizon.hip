@@ -1,0 +1,433 @@
+// hz_horizon.hip -- terrain horizon kernels for gfx950 (wave64).
+//
+// Replaces the TBB row loop + per-cell search functions + Embree rtcOccluded1 of
+// the reference (horizon_comp.cpp:739-800, :302-498, :241-262).
+//
+// Work decomposition
+//   one lane      = one inner-domain grid cell; it walks ALL azimuth sectors
+//                   sequentially (guess_constant carries the elevation index from
+//                   one azimuth to the next, horizon_comp.cpp:431-496)
+//   one wavefront = an 8 x 8 tile of cells -> neighbouring lanes shoot nearly
+//                   parallel rays and fetch the same BVH nodes (coalesced by the TA)
+//   one workgroup = 4 wavefronts = a 16 x 16 tile; stages the breadth-first top of
+//                   the LBVH in LDS once and keeps the per-lane traversal stacks in LDS
+//   blockIdx      -> tile mapping is XCD aware: the 8 XCDs each take a contiguous
+//                   band of tiles so that one XCD's L2 sees one region of the BVH
+//
+// Per lane a small state machine (Search) produces the next elevation sample as
+// soon as the previous occlusion query finishes; lanes never wait for an azimuth
+// barrier.  When fewer than `regroup` lanes of a wave are still traversing, the
+// wave leaves the traversal loop (ballot + popcount) so idle lanes can fetch
+// their next ray: this is the ray compaction step.
+//
+// The float/double promotion pattern of the reference's index arithmetic is
+// reproduced exactly (hard part 2); tables are built on the
+// host with the reference's expressions (hz_api.cpp) and only read here.
+#include "hz_internal.h"
+
+namespace hz {
+
+#define HZ_EMPTY ((int)0x80000000)
+#define HZ_TPB 256
+
+enum { ALG_DISCRETE = 0, ALG_BINARY = 1, ALG_GUESS = 2 };
+enum { PH_NEWAZ = 0, PH_BIN = 1, PH_UP = 2, PH_DOWN = 3 };
+
+struct Tables {
+    const float *azim_sin, *azim_cos, *elev_ang, *elev_sin, *elev_cos;
+    int azim_num, elev_num;
+    float hori_acc, low, up;
+    double step;   // (double)hori_acc / 5.0
+};
+
+struct Search {
+    int k, phase, ind, prev, pazim, count;
+    float lim_up, lim_low, elev_samp;
+};
+
+// (int)roundf((elev_samp - low) / (hori_acc / 5.0)), horizon_comp.cpp:351-352
+__device__ __forceinline__ int ind_of(const Tables &t, float elev_samp) {
+    return (int)__builtin_roundf((float)((double)(elev_samp - t.low) / t.step));
+}
+// (a + b) / 2.0 -> float, horizon_comp.cpp:350, :330, :462, :490
+__device__ __forceinline__ float half_sum(float a, float b) {
+    return (float)((double)(a + b) / 2.0);
+}
+
+// per-cell output sink: horizon array and/or fused sky view factor
+struct Sink {
+    float *hori;         // &hori_buffer[cell * azim_num] or null
+    bool svf_on;
+    float tx, ty, tz;    // tilted normal (svf)
+    float agg;           // svf accumulator (float32, topo_param.pyx:431)
+};
+
+// one term of _sky_view_factor_cy, topo_param.pyx:439-456 (float32 state, double trig)
+__device__ __forceinline__ void svf_accumulate(Sink &s, const Tables &t, int k, float h) {
+    // azim[k] as horizon.pyx:191-195 computes it; sin/cos in double, stored as float (topo_param.pyx:425-426)
+    const float azim = (float)(((2.0 * 3.14159265358979323846) / (double)t.azim_num) * (double)k);
+    const float as = (float)sin((double)azim), ac = (float)cos((double)azim);
+    const float hori_plane = (float)atan((double)(-as * s.tx / s.tz - ac * s.ty / s.tz));
+    const float he = (h >= hori_plane) ? h : hori_plane;
+    const double ce = cos((double)he);
+    s.agg = (float)((double)s.agg + ((double)(s.tx * as + s.ty * ac)
+                    * ((3.14159265358979323846 / 2.0) - (double)he - (sin(2.0 * (double)he) / 2.0))
+                    + (double)s.tz * (ce * ce)));
+}
+
+__device__ __forceinline__ void emit(Sink &s, const Tables &t, int k, float h) {
+    if (s.hori) s.hori[k] = h;
+    if (s.svf_on) svf_accumulate(s, t, k, h);
+}
+
+// Consume the result of the previous ray (if any) and produce the next sample.
+// Returns true with s.ind / s.k identifying the next ray, false when the cell is finished.
+template <int ALG>
+__device__ __forceinline__ bool advance(Search &s, bool hit, const Tables &t, Sink &out,
+                                        unsigned &guards) {
+    const int top = t.elev_num - 1;
+    for (;;) {
+        if (s.phase == PH_NEWAZ) {
+            if (s.k >= t.azim_num) return false;
+            const bool binary = (ALG == ALG_BINARY) || (ALG == ALG_GUESS && s.k == 0);
+            if (binary) {                                   // horizon_comp.cpp:348-354 / :398-404
+                s.lim_up = t.up; s.lim_low = t.low;
+                s.elev_samp = half_sum(s.lim_up, s.lim_low);
+                s.ind = ind_of(t, s.elev_samp);
+                s.phase = PH_BIN;
+                const float e = t.elev_ang[s.ind];
+                if (__builtin_fmaxf(s.lim_up - e, e - s.lim_low) > t.hori_acc) return true;
+                emit(out, t, s.k, s.elev_samp);
+                s.pazim = s.ind; s.k++; s.phase = PH_NEWAZ;
+                continue;
+            }
+            // move upwards: horizon_comp.cpp:311-317 (discrete, from index 0) / :439-446
+            s.ind = (ALG == ALG_DISCRETE) ? 0 : max(s.pazim - 5, 0);
+            s.prev = s.ind;
+            s.ind = min(s.ind + 10, top);
+            s.count = 1;
+            s.phase = PH_UP;
+            return true;
+        }
+        if (s.phase == PH_BIN) {                             // :367-374 / :417-424
+            const float e0 = t.elev_ang[s.ind];
+            if (hit) s.lim_low = e0; else s.lim_up = e0;
+            s.elev_samp = half_sum(s.lim_up, s.lim_low);
+            s.ind = ind_of(t, s.elev_samp);
+            const float e = t.elev_ang[s.ind];
+            if (__builtin_fmaxf(s.lim_up - e, e - s.lim_low) > t.hori_acc) return true;
+            emit(out, t, s.k, s.elev_samp);                  // :376 / :428
+            s.pazim = s.ind; s.k++; s.phase = PH_NEWAZ;
+            continue;
+        }
+        if (s.phase == PH_UP) {
+            const bool guard = hit && (s.ind == top);        // the reference never leaves this loop
+            if (hit && !guard) {
+                s.prev = s.ind;
+                s.ind = min(s.ind + 10, top);
+                s.count++;
+                return true;
+            }
+            if (guard) guards++;
+            if (ALG == ALG_DISCRETE) {                       // :330
+                emit(out, t, s.k, half_sum(t.elev_ang[s.prev], t.elev_ang[s.ind]));
+                s.k++; s.phase = PH_NEWAZ;
+                continue;
+            }
+            if (s.count > 1) {                               // :460-467
+                const float es = half_sum(t.elev_ang[s.prev], t.elev_ang[s.ind]);
+                s.ind = ind_of(t, es);
+                emit(out, t, s.k, t.elev_ang[s.ind]);
+                s.pazim = s.ind; s.k++; s.phase = PH_NEWAZ;
+                continue;
+            }
+            // move downwards: :472-477
+            s.ind = min(s.pazim + 5, top);
+            s.prev = s.ind;
+            s.ind = max(s.ind - 10, 0);
+            s.phase = PH_DOWN;
+            return true;
+        }
+        // PH_DOWN: :474-488
+        {
+            const bool guard = (!hit) && (s.ind == 0);
+            if (!hit && !guard) {
+                s.prev = s.ind;
+                s.ind = max(s.ind - 10, 0);
+                return true;
+            }
+            if (guard) guards++;
+            const float es = half_sum(t.elev_ang[s.prev], t.elev_ang[s.ind]);   // :490-494
+            s.ind = ind_of(t, es);
+            emit(out, t, s.k, t.elev_ang[s.ind]);
+            s.pazim = s.ind; s.k++; s.phase = PH_NEWAZ;
+            continue;
+        }
+    }
+}
+
+struct HorizonParams {
+    SceneView sv;
+    Tables tb;
+    const float *vec_norm, *vec_north, *vec_tilt;
+    const uint8_t *mask;
+    float *hori, *svf;
+    int offset_0, offset_1, dim_in_1;
+    int row_begin, row_end;
+    int tiles_j, n_tiles, chunk;   // tile grid of the slab; chunk = ceil(n_tiles / 8)
+    float dist, hori_fill, ray_org_elev;
+    int top_nodes, regroup;
+    unsigned long long *counters;
+};
+
+template <int ALG, int STACK, bool COUNT>
+__global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *stack = reinterpret_cast<int *>(smem);                                  // [STACK][256]
+    const float4 *top = reinterpret_cast<const float4 *>(smem + STACK * HZ_TPB * 4);
+    const int tid = threadIdx.x;
+    const int ntop = p.top_nodes;
+    {   // stage the breadth-first top of the tree in LDS (coalesced 16 B per lane)
+        float4 *dst = reinterpret_cast<float4 *>(smem + STACK * HZ_TPB * 4);
+        const float4 *src = reinterpret_cast<const float4 *>(p.sv.nodes);
+        for (int i = tid; i < ntop * 4; i += HZ_TPB) dst[i] = src[i];
+    }
+    __syncthreads();
+
+    // XCD-aware block -> tile mapping: block b runs on XCD b % 8; give XCD x the tile band [x*chunk, (x+1)*chunk)
+    const int b = blockIdx.x;
+    const int tile = (b & 7) * p.chunk + (b >> 3);
+    const int ti = tile / p.tiles_j, tj = tile - ti * p.tiles_j;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int i = p.row_begin + ti * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int j = tj * 16 + (wave & 1) * 8 + (lane & 7);
+    const bool in_dom = (tile < p.n_tiles) && (i < p.row_end) && (j < p.dim_in_1);
+
+    const Tables &t = p.tb;
+    const size_t cell = in_dom ? ((size_t)i * p.dim_in_1 + j) : 0;
+    bool done = !in_dom;
+    Sink out;
+    out.hori = (p.hori && in_dom) ? p.hori + cell * (size_t)t.azim_num : nullptr;
+    out.svf_on = (p.svf != nullptr) && in_dom;
+    out.agg = 0.0f; out.tx = 0.0f; out.ty = 0.0f; out.tz = 1.0f;
+    if (out.svf_on) {
+        out.tx = p.vec_tilt[3 * cell]; out.ty = p.vec_tilt[3 * cell + 1]; out.tz = p.vec_tilt[3 * cell + 2];
+    }
+    float ox = 0, oy = 0, oz = 0;
+    float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
+    if (in_dom) {
+        if (p.mask[cell] != 1) {                              // horizon_comp.cpp:789-794
+            for (int k = 0; k < t.azim_num; k++) emit(out, t, k, p.hori_fill);
+            done = true;
+        } else {                                              // :751-779
+            const float norm_x = p.vec_norm[3 * cell], norm_y = p.vec_norm[3 * cell + 1], norm_z = p.vec_norm[3 * cell + 2];
+            const float north_x = p.vec_north[3 * cell], north_y = p.vec_north[3 * cell + 1], north_z = p.vec_north[3 * cell + 2];
+            const float *v = p.sv.verts + 3 * ((size_t)(i + p.offset_0) * p.sv.d1 + (size_t)(j + p.offset_1));
+            ox = v[0] + norm_x * p.ray_org_elev;
+            oy = v[1] + norm_y * p.ray_org_elev;
+            oz = v[2] + norm_z * p.ray_org_elev;
+            const float east_x = north_y * norm_z - north_z * norm_y;
+            const float east_y = north_z * norm_x - north_x * norm_z;
+            const float east_z = north_x * norm_y - north_y * norm_x;
+            r00 = east_x; r01 = north_x; r02 = norm_x;
+            r10 = east_y; r11 = north_y; r12 = norm_y;
+            r20 = east_z; r21 = north_z; r22 = norm_z;
+        }
+    }
+    const float ocx = ox - p.sv.cx, ocy = oy - p.sv.cy, ocz = oz - p.sv.cz;
+    const float tfar = p.dist;
+
+    Search s;
+    s.k = 0; s.phase = PH_NEWAZ; s.ind = 0; s.prev = 0; s.pazim = 0; s.count = 0;
+    s.lim_up = 0; s.lim_low = 0; s.elev_samp = 0;
+    unsigned rays = 0, guards = 0, nodes_cnt = 0, tris_cnt = 0;
+    const unsigned cells_cnt = (in_dom && !done) ? 1u : 0u;
+    bool ray_active = false, last_hit = false;
+    float dx = 0, dy = 0, dz = 1;
+    RayBox rb = hz_raybox(0, 0, 0, 0, 0, 1);
+    int node = HZ_EMPTY, sp = 0;
+
+    while (__ballot(!done) != 0ull) {
+        if (!done && !ray_active) {
+            if (advance<ALG>(s, last_hit, t, out, guards)) {
+                // local direction (east, north, up) and rotation: horizon_comp.cpp:357-361, :55-62
+                const float ec = t.elev_cos[s.ind], es = t.elev_sin[s.ind];
+                const float rx = ec * t.azim_sin[s.k], ry = ec * t.azim_cos[s.k], rz = es;
+                dx = (r00 * rx + r01 * ry) + r02 * rz;
+                dy = (r10 * rx + r11 * ry) + r12 * rz;
+                dz = (r20 * rx + r21 * ry) + r22 * rz;
+                rb = hz_raybox(ocx, ocy, ocz, dx, dy, dz);
+                node = 0; sp = 0;
+                ray_active = true;
+                rays++;
+            } else {
+                done = true;
+            }
+        }
+        if (ray_active) {
+            for (;;) {
+                // ---- inner nodes: descend until a leaf (or the stack runs dry) -------------
+                while (node >= 0) {
+                    float4 n0, n1, n2; int2 ch;
+                    if (node < ntop) {
+                        const float4 *q = top + 4 * node;
+                        n0 = q[0]; n1 = q[1]; n2 = q[2];
+                        ch = *reinterpret_cast<const int2 *>(q + 3);
+                    } else {
+                        const float4 *q = reinterpret_cast<const float4 *>(p.sv.nodes + node);
+                        n0 = q[0]; n1 = q[1]; n2 = q[2];
+                        ch = *reinterpret_cast<const int2 *>(q + 3);
+                    }
+                    if (COUNT) nodes_cnt++;
+                    float ta, tb;
+                    const bool ha = hz_box_hit(rb, tfar, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, &ta);
+                    const bool hb = hz_box_hit(rb, tfar, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, &tb);
+                    if (ha && hb) {
+                        const bool sw = tb < ta;
+                        stack[sp * HZ_TPB + tid] = sw ? ch.x : ch.y;
+                        sp++;
+                        node = sw ? ch.y : ch.x;
+                    } else if (ha) {
+                        node = ch.x;
+                    } else if (hb) {
+                        node = ch.y;
+                    } else if (sp > 0) {
+                        sp--; node = stack[sp * HZ_TPB + tid];
+                    } else {
+                        node = HZ_EMPTY;
+                    }
+                }
+                if (node == HZ_EMPTY) { ray_active = false; last_hit = false; break; }
+                // ---- leaf: the two triangles of a DEM quad (or one TIN triangle) ------------
+                {
+                    const float4 *q = reinterpret_cast<const float4 *>(p.sv.prims + (~node));
+                    const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+                    // a = (q0.x q0.y q0.z) b = (q0.w q1.x q1.y) c = (q1.z q1.w q2.x) d = (q2.y q2.z q2.w)
+                    if (COUNT) tris_cnt += (q2.y == q2.y) ? 2 : 1;
+                    bool h = hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y,
+                                        q1.z, q1.w, q2.x);
+                    if (!h && (q2.y == q2.y))
+                        h = hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, q0.w, q1.x, q1.y, q2.y, q2.z, q2.w,
+                                       q1.z, q1.w, q2.x);
+                    if (h) { ray_active = false; last_hit = true; break; }
+                }
+                if (sp > 0) { sp--; node = stack[sp * HZ_TPB + tid]; }
+                else { ray_active = false; last_hit = false; break; }
+                // ---- ray compaction: too few lanes left in this loop -> let the others refill
+                if (__popcll(__ballot(1)) < p.regroup) break;
+            }
+        }
+    }
+
+    if (out.svf_on)   // topo_param.pyx:458: (azim_spac / (2 pi)) * agg, azim_spac = azim[1] - azim[0]
+        p.svf[cell] = (float)(((double)(float)((2.0 * 3.14159265358979323846) / (double)t.azim_num)
+                               / (2.0 * 3.14159265358979323846)) * (double)out.agg);
+
+    // one atomic per wave and counter
+    unsigned long long r = rays, g = guards, nc = nodes_cnt, tc = tris_cnt, cc = cells_cnt;
+    for (int off = 32; off > 0; off >>= 1) {
+        r += __shfl_xor(r, off); g += __shfl_xor(g, off); cc += __shfl_xor(cc, off);
+        if (COUNT) { nc += __shfl_xor(nc, off); tc += __shfl_xor(tc, off); }
+    }
+    if (lane == 0) {
+        if (r) atomicAdd(&p.counters[0], r);
+        if (g) atomicAdd(&p.counters[1], g);
+        if (cc) atomicAdd(&p.counters[4], cc);
+        if (COUNT) { atomicAdd(&p.counters[2], nc); atomicAdd(&p.counters[3], tc); }
+    }
+}
+
+template <int ALG, int STACK>
+static int launch_alg(const HorizonParams &p, int grid, size_t lds, bool count, hipStream_t st) {
+    if (count) {
+        HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_horizon<ALG, STACK, true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_horizon<ALG, STACK, true>), dim3(grid), dim3(HZ_TPB), lds, st, p);
+    } else {
+        HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_horizon<ALG, STACK, false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_horizon<ALG, STACK, false>), dim3(grid), dim3(HZ_TPB), lds, st, p);
+    }
+    HZ_HIP(hipGetLastError());
+    return HZ_OK;
+}
+
+template <int STACK>
+static int launch_stack(const HorizonParams &p, int alg, int grid, size_t lds, bool count, hipStream_t st) {
+    switch (alg) {
+        case ALG_DISCRETE: return launch_alg<ALG_DISCRETE, STACK>(p, grid, lds, count, st);
+        case ALG_BINARY: return launch_alg<ALG_BINARY, STACK>(p, grid, lds, count, st);
+        default: return launch_alg<ALG_GUESS, STACK>(p, grid, lds, count, st);
+    }
+}
+
+int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
+    HorizonParams p;
+    p.sv = scene_view(sc);
+    p.tb.azim_sin = a.azim_sin; p.tb.azim_cos = a.azim_cos;
+    p.tb.elev_ang = a.elev_ang; p.tb.elev_sin = a.elev_sin; p.tb.elev_cos = a.elev_cos;
+    p.tb.azim_num = a.azim_num; p.tb.elev_num = a.elev_num;
+    p.tb.hori_acc = a.hori_acc; p.tb.low = a.low; p.tb.up = a.up;
+    p.tb.step = (double)a.hori_acc / 5.0;
+    p.vec_norm = a.vec_norm; p.vec_north = a.vec_north; p.vec_tilt = a.vec_tilt;
+    p.mask = a.mask; p.hori = a.hori; p.svf = a.svf;
+    p.offset_0 = a.offset_0; p.offset_1 = a.offset_1; p.dim_in_1 = a.dim_in_1;
+    p.row_begin = a.row_begin; p.row_end = a.row_end;
+    const int rows = a.row_end - a.row_begin;
+    if (rows <= 0 || a.dim_in_1 <= 0) return HZ_OK;
+    const int tiles_i = (rows + 15) / 16;
+    p.tiles_j = (a.dim_in_1 + 15) / 16;
+    p.n_tiles = tiles_i * p.tiles_j;
+    p.chunk = (p.n_tiles + 7) / 8;
+    p.dist = a.dist; p.hori_fill = a.hori_fill; p.ray_org_elev = a.ray_org_elev;
+    const int height = sc->hdr.height;
+    const int stack = (height <= 32) ? 32 : 64;
+    int top = (a.top_nodes < 0) ? 511 : a.top_nodes;
+    top = std::min(top, sc->hdr.n_top);
+    p.top_nodes = top;
+    p.regroup = (a.regroup < 0) ? 0 : std::min(a.regroup, 64);
+    p.counters = a.counters;
+    const size_t lds = (size_t)stack * HZ_TPB * 4 + (size_t)top * sizeof(Node);
+    const int grid = p.chunk * 8;
+    if (stack == 32) return launch_stack<32>(p, a.alg, grid, lds, a.count_work != 0, st);
+    return launch_stack<64>(p, a.alg, grid, lds, a.count_work != 0, st);
+}
+
+// ---------------------------------------------------------------------------------------
+// stand-alone sky view factor from a horizon array (topo_param.pyx:412-460).
+// One lane per cell; the 4*A bytes of a cell are read by consecutive k, so a wave streams
+// 64 rows of A floats (HBM bound: 4*A + 12 B in, 4 B out per cell).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_svf(const float *__restrict__ azim, const float *__restrict__ hori,
+                                            const float *__restrict__ vec_tilt, size_t ncell, int A,
+                                            float *__restrict__ svf) {
+    const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncell) return;
+    const float tx = vec_tilt[3 * c], ty = vec_tilt[3 * c + 1], tz = vec_tilt[3 * c + 2];
+    const float *h = hori + c * (size_t)A;
+    float agg = 0.0f;
+    for (int k = 0; k < A; k++) {
+        const float as = (float)sin((double)azim[k]), ac = (float)cos((double)azim[k]);
+        const float hori_plane = (float)atan((double)(-as * tx / tz - ac * ty / tz));
+        const float hv = h[k];
+        const float he = (hv >= hori_plane) ? hv : hori_plane;
+        const double ce = cos((double)he);
+        agg = (float)((double)agg + ((double)(tx * as + ty * ac)
+                      * ((3.14159265358979323846 / 2.0) - (double)he - (sin(2.0 * (double)he) / 2.0))
+                      + (double)tz * (ce * ce)));
+    }
+    const float azim_spac = azim[1] - azim[0];
+    svf[c] = (float)(((double)azim_spac / (2.0 * 3.14159265358979323846)) * (double)agg);
+}
+
+int svf_launch(const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
+               int len_2, float *svf, hipStream_t st) {
+    const size_t ncell = (size_t)len_0 * len_1;
+    if (ncell == 0) return HZ_OK;
+    hipLaunchKernelGGL(k_svf, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, azim, hori, vec_tilt,
+                       ncell, len_2, svf);
+    HZ_HIP(hipGetLastError());
+    return HZ_OK;
+}
+
+}  // namespace hz

@@ -1,0 +1,104 @@
+// hz_internal.h -- host-side internals of libhorayzon_hip (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include "../../include/horayzon_hip.h"
+#include "hz_common.h"
+
+#define HZ_MAX_TOP_NODES 2047   // upper bound of BFS-ordered top nodes (LDS staging)
+#define HZ_MAX_STACK 64         // deepest tree the traversal kernels accept
+
+namespace hz {
+
+int set_error(int code, const char *fmt, ...);
+
+#define HZ_HIP(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return ::hz::set_error(HZ_ERR_HIP, "%s failed: %s (%s:%d)", #expr,            \
+                                   hipGetErrorString(e_), __FILE__, __LINE__);            \
+    } while (0)
+
+struct Timer {
+    std::chrono::high_resolution_clock::time_point t0;
+    void start() { t0 = std::chrono::high_resolution_clock::now(); }
+    double stop() const {
+        return std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - t0).count();
+    }
+};
+
+struct Scene {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    void *blob = nullptr;
+    size_t blob_bytes = 0;
+    bool owns_blob = false;
+    BlobHeader hdr;
+    const float *verts() const { return (const float *)((const char *)blob + hdr.off_verts); }
+    const Node *nodes() const { return (const Node *)((const char *)blob + hdr.off_nodes); }
+    const Prim *prims() const { return (const Prim *)((const char *)blob + hdr.off_prims); }
+};
+
+// hz_scene.hip
+int scene_build(Scene *sc, const float *vert_grid, int d0, int d1, const float *vert_simp, int nvs,
+                const int32_t *tri_simp, int nts, hz_stats *stats);
+
+// device-side view handed to the traversal kernels
+struct SceneView {
+    const float *verts;
+    const Node *nodes;
+    const Prim *prims;
+    int d1;          // DEM row length (vertices)
+    int n_top;       // BFS-ordered top nodes available for LDS staging
+    float cx, cy, cz;
+};
+
+inline SceneView scene_view(const Scene *sc) {
+    SceneView v;
+    v.verts = sc->verts(); v.nodes = sc->nodes(); v.prims = sc->prims();
+    v.d1 = sc->hdr.d1; v.n_top = sc->hdr.n_top;
+    v.cx = sc->hdr.center[0]; v.cy = sc->hdr.center[1]; v.cz = sc->hdr.center[2];
+    return v;
+}
+
+// true if p points to device memory (HBM); false for host memory
+bool is_device_ptr(const void *p);
+
+// hz_horizon.hip
+struct HorizonArgs {
+    const float *vec_norm, *vec_north;   // device
+    const uint8_t *mask;                 // device
+    float *hori;                         // device, may be null (skip_hori)
+    float *svf; const float *vec_tilt;   // device, optional
+    int offset_0, offset_1, dim_in_0, dim_in_1;
+    int row_begin, row_end;
+    int azim_num, elev_num, alg;
+    float hori_acc, low, up, dist;       // radians / metres
+    float hori_fill, ray_org_elev;
+    const float *azim_sin, *azim_cos, *elev_ang, *elev_sin, *elev_cos;  // device tables
+    int top_nodes, regroup, count_work;
+    unsigned long long *counters;        // device u64[8]: [0] rays, [1] guards, [2] nodes, [3] tris, [4] cells
+};
+int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st);
+int svf_launch(const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
+               int len_2, float *svf, hipStream_t st);
+
+// hz_shadow.hip
+struct ShadowArgs {
+    const float *vec_tilt, *vec_norm, *surf_enl_fac, *elevation;   // device
+    const uint8_t *mask;
+    int offset_0, offset_1, dim_in_0, dim_in_1;
+    float sun[3];
+    float sw_dir_cor_fill, dot_prod_min;
+    int refrac_cor;
+    int which;                           // 0 shadow (u8), 1 sw_dir_cor (f32)
+    uint8_t *out_u8; float *out_f32;
+    int top_nodes;
+    unsigned long long *counters;        // [0] rays
+};
+int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st);
+
+}  // namespace hz

@@ -1,0 +1,222 @@
+// hz_shadow.hip -- shadow mask / direct-shortwave correction kernels for gfx950.
+//
+// Replaces CppTerrain::shadow and CppTerrain::sw_dir_cor (shadow_comp.cpp:386-491,
+// :495-605): one lane per inner-domain cell, at most one any-hit ray with
+// tfar = infinity towards the sun (optionally bent by atmospheric refraction,
+// shadow_comp.cpp:430-446).  Same tile / XCD mapping and LDS staging as the horizon
+// kernel; the BVH is persistent in the Terrain handle (built once, :318-380).
+#include "hz_internal.h"
+
+namespace hz {
+
+#define HZ_EMPTY ((int)0x80000000)
+#define HZ_TPB 256
+
+struct ShadowParams {
+    SceneView sv;
+    const float *vec_tilt, *vec_norm, *surf_enl_fac, *elevation;
+    const uint8_t *mask;
+    int offset_0, offset_1, dim_in_0, dim_in_1;
+    int tiles_j, n_tiles, chunk;
+    float sun_x, sun_y, sun_z;
+    float fill, dot_prod_min;
+    int refrac, which;
+    uint8_t *out_u8; float *out_f32;
+    int top_nodes;
+    unsigned long long *counters;
+};
+
+// float-precision libm calls of the reference (acos/tan/pow/cos/sin on float arguments
+// resolve to the float overloads, shadow_comp.cpp:19) evaluated through double and
+// rounded once: agrees with glibc's float routines to <= 1 ulp.
+__device__ __forceinline__ float f_acos(float x) { return (float)acos((double)x); }
+__device__ __forceinline__ float f_tan(float x) { return (float)tan((double)x); }
+__device__ __forceinline__ float f_cos(float x) { return (float)cos((double)x); }
+__device__ __forceinline__ float f_sin(float x) { return (float)sin((double)x); }
+__device__ __forceinline__ float f_pow(float x, float y) { return (float)pow((double)x, (double)y); }
+
+__device__ __forceinline__ float deg2rad_f(float a) { return (float)(((double)a / 180.0) * 3.14159265358979323846); }
+__device__ __forceinline__ float rad2deg_f(float a) { return (float)(((double)a / 3.14159265358979323846) * 180.0); }
+
+// shadow_comp.cpp:96-106
+__device__ __forceinline__ void vec_unit(float &x, float &y, float &z) {
+    const float mag = __builtin_sqrtf((x * x + y * y) + z * z);
+    x = x / mag; y = y / mag; z = z / mag;
+}
+
+// shadow_comp.cpp:135-159 (Saemundsson), float/double promotions as there
+__device__ __forceinline__ float atmos_refrac(float elev_ang_true, float temp, float pressure) {
+    elev_ang_true = __builtin_fmaxf(-1.0f, __builtin_fminf(elev_ang_true, 90.0f));
+    float refrac_cor = (float)(1.02 / (double)f_tan(deg2rad_f(
+        (float)((double)elev_ang_true + 10.3 / ((double)elev_ang_true + 5.11)))));
+    refrac_cor = (float)((double)refrac_cor + 0.0019279);
+    refrac_cor = (float)((double)refrac_cor * (((double)pressure / 101.0) * (283.0 / (273.0 + (double)temp))));
+    return (float)((double)refrac_cor * (1.0 / 60.0));
+}
+
+// any-hit traversal to completion; per-lane stack in LDS
+template <int STACK>
+__device__ __forceinline__ bool occluded(const SceneView &sv, const float4 *top, int ntop, int *stack, int tid,
+                                         float ox, float oy, float oz, float dx, float dy, float dz,
+                                         float tfar) {
+    const RayBox rb = hz_raybox(ox - sv.cx, oy - sv.cy, oz - sv.cz, dx, dy, dz);
+    int node = 0, sp = 0;
+    for (;;) {
+        while (node >= 0) {
+            float4 n0, n1, n2; int2 ch;
+            if (node < ntop) {
+                const float4 *q = top + 4 * node;
+                n0 = q[0]; n1 = q[1]; n2 = q[2]; ch = *reinterpret_cast<const int2 *>(q + 3);
+            } else {
+                const float4 *q = reinterpret_cast<const float4 *>(sv.nodes + node);
+                n0 = q[0]; n1 = q[1]; n2 = q[2]; ch = *reinterpret_cast<const int2 *>(q + 3);
+            }
+            float ta, tb;
+            const bool ha = hz_box_hit(rb, tfar, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, &ta);
+            const bool hb = hz_box_hit(rb, tfar, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, &tb);
+            if (ha && hb) {
+                const bool sw = tb < ta;
+                stack[sp * HZ_TPB + tid] = sw ? ch.x : ch.y;
+                sp++;
+                node = sw ? ch.y : ch.x;
+            } else if (ha) node = ch.x;
+            else if (hb) node = ch.y;
+            else if (sp > 0) { sp--; node = stack[sp * HZ_TPB + tid]; }
+            else node = HZ_EMPTY;
+        }
+        if (node == HZ_EMPTY) return false;
+        const float4 *q = reinterpret_cast<const float4 *>(sv.prims + (~node));
+        const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+        if (hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x))
+            return true;
+        if ((q2.y == q2.y) &&
+            hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, q0.w, q1.x, q1.y, q2.y, q2.z, q2.w, q1.z, q1.w, q2.x))
+            return true;
+        if (sp > 0) { sp--; node = stack[sp * HZ_TPB + tid]; }
+        else return false;
+    }
+}
+
+template <int STACK>
+__global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *stack = reinterpret_cast<int *>(smem);
+    const float4 *top = reinterpret_cast<const float4 *>(smem + STACK * HZ_TPB * 4);
+    const int tid = threadIdx.x;
+    const int ntop = p.top_nodes;
+    {
+        float4 *dst = reinterpret_cast<float4 *>(smem + STACK * HZ_TPB * 4);
+        const float4 *src = reinterpret_cast<const float4 *>(p.sv.nodes);
+        for (int i = tid; i < ntop * 4; i += HZ_TPB) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int b = blockIdx.x;
+    const int tile = (b & 7) * p.chunk + (b >> 3);
+    const int ti = tile / p.tiles_j, tj = tile - ti * p.tiles_j;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int i = ti * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int j = tj * 16 + (wave & 1) * 8 + (lane & 7);
+    const bool in_dom = (tile < p.n_tiles) && (i < p.dim_in_0) && (j < p.dim_in_1);
+    const size_t cell = in_dom ? ((size_t)i * p.dim_in_1 + j) : 0;
+    unsigned rays = 0;
+    if (in_dom) {
+        if (p.mask[cell] != 1) {                                   // shadow_comp.cpp:480-484 / :594-598
+            if (p.which == 0) p.out_u8[cell] = 3; else p.out_f32[cell] = p.fill;
+        } else {
+            const float tilt_x = p.vec_tilt[3 * cell], tilt_y = p.vec_tilt[3 * cell + 1], tilt_z = p.vec_tilt[3 * cell + 2];
+            const float norm_x = p.vec_norm[3 * cell], norm_y = p.vec_norm[3 * cell + 1], norm_z = p.vec_norm[3 * cell + 2];
+            const float ray_org_elev = 0.05f;                      // :388, :497
+            const float *v = p.sv.verts + 3 * ((size_t)(i + p.offset_0) * p.sv.d1 + (size_t)(j + p.offset_1));
+            const float ox = v[0] + norm_x * ray_org_elev;
+            const float oy = v[1] + norm_y * ray_org_elev;
+            const float oz = v[2] + norm_z * ray_org_elev;
+            float sun_x = p.sun_x - ox, sun_y = p.sun_y - oy, sun_z = p.sun_z - oz;   // :422-425
+            vec_unit(sun_x, sun_y, sun_z);
+            float dot_prod_ns = (norm_x * sun_x + norm_y * sun_y) + norm_z * sun_z;
+            if (p.refrac == 1) {                                   // :430-446
+                const float elev_ang_true = (float)(90.0 - (double)rad2deg_f(f_acos(dot_prod_ns)));
+                const float temperature_ref = 283.15f, pressure_ref = 101.0f, lapse_rate = 0.0065f;
+                const float g = 9.81f, R_d = 287.0f;
+                const float expo = g / (R_d * lapse_rate);         // :353-354
+                const float temperature = temperature_ref - (lapse_rate * p.elevation[cell]);
+                const float pressure = pressure_ref * f_pow(temperature / temperature_ref, expo);
+                const float refrac_cor = atmos_refrac(elev_ang_true, (float)((double)temperature - 273.15), pressure);
+                float k_x = sun_y * norm_z - sun_z * norm_y;
+                float k_y = sun_z * norm_x - sun_x * norm_z;
+                float k_z = sun_x * norm_y - sun_y * norm_x;
+                vec_unit(k_x, k_y, k_z);
+                const float theta = deg2rad_f(refrac_cor);        // vec_rot, :109-132
+                const float ct = f_cos(theta), st = f_sin(theta);
+                const float part = (float)((double)((k_x * sun_x + k_y * sun_y) + k_z * sun_z) * (1.0 - (double)ct));
+                const float rx = (sun_x * ct + (k_y * sun_z - k_z * sun_y) * st) + k_x * part;
+                const float ry = (sun_y * ct + (k_z * sun_x - k_x * sun_z) * st) + k_y * part;
+                const float rz = (sun_z * ct + (k_x * sun_y - k_y * sun_x) * st) + k_z * part;
+                sun_x = rx; sun_y = ry; sun_z = rz;
+                dot_prod_ns = (norm_x * sun_x + norm_y * sun_y) + norm_z * sun_z;
+            }
+            const float dot_prod_ts = (tilt_x * sun_x + tilt_y * sun_y) + tilt_z * sun_z;
+            const float inf = __builtin_inff();
+            if (p.which == 0) {                                    // :451-478
+                if (dot_prod_ts > 0.0f) {
+                    rays = 1;
+                    const bool h = occluded<STACK>(p.sv, top, ntop, stack, tid, ox, oy, oz, sun_x, sun_y, sun_z, inf);
+                    p.out_u8[cell] = h ? 2 : 0;
+                } else {
+                    p.out_u8[cell] = 1;
+                }
+            } else {                                               // :561-592
+                if (dot_prod_ts > p.dot_prod_min) {
+                    rays = 1;
+                    const bool h = occluded<STACK>(p.sv, top, ntop, stack, tid, ox, oy, oz, sun_x, sun_y, sun_z, inf);
+                    if (h) p.out_f32[cell] = 0.0f;
+                    else {
+                        if (dot_prod_ns < p.dot_prod_min) dot_prod_ns = p.dot_prod_min;
+                        p.out_f32[cell] = (dot_prod_ts / dot_prod_ns) * p.surf_enl_fac[cell];
+                    }
+                } else {
+                    p.out_f32[cell] = 0.0f;
+                }
+            }
+        }
+    }
+    unsigned long long r = rays;
+    for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off);
+    if (lane == 0 && r) atomicAdd(&p.counters[0], r);
+}
+
+int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st) {
+    ShadowParams p;
+    p.sv = scene_view(sc);
+    p.vec_tilt = a.vec_tilt; p.vec_norm = a.vec_norm; p.surf_enl_fac = a.surf_enl_fac; p.elevation = a.elevation;
+    p.mask = a.mask;
+    p.offset_0 = a.offset_0; p.offset_1 = a.offset_1; p.dim_in_0 = a.dim_in_0; p.dim_in_1 = a.dim_in_1;
+    if (a.dim_in_0 <= 0 || a.dim_in_1 <= 0) return HZ_OK;
+    const int tiles_i = (a.dim_in_0 + 15) / 16;
+    p.tiles_j = (a.dim_in_1 + 15) / 16;
+    p.n_tiles = tiles_i * p.tiles_j;
+    p.chunk = (p.n_tiles + 7) / 8;
+    p.sun_x = a.sun[0]; p.sun_y = a.sun[1]; p.sun_z = a.sun[2];
+    p.fill = a.sw_dir_cor_fill; p.dot_prod_min = a.dot_prod_min;
+    p.refrac = a.refrac_cor; p.which = a.which;
+    p.out_u8 = a.out_u8; p.out_f32 = a.out_f32;
+    const int stack = (sc->hdr.height <= 32) ? 32 : 64;
+    int top = (a.top_nodes < 0) ? 511 : a.top_nodes;
+    top = std::min(top, sc->hdr.n_top);
+    p.top_nodes = top;
+    p.counters = a.counters;
+    const size_t lds = (size_t)stack * HZ_TPB * 4 + (size_t)top * sizeof(Node);
+    const int grid = p.chunk * 8;
+    if (stack == 32) {
+        HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shadow<32>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_shadow<32>, dim3(grid), dim3(HZ_TPB), lds, st, p);
+    } else {
+        HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shadow<64>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_shadow<64>, dim3(grid), dim3(HZ_TPB), lds, st, p);
+    }
+    HZ_HIP(hipGetLastError());
+    return HZ_OK;
+}
+
+}  // namespace hz

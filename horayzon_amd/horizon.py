@@ -1,0 +1,180 @@
+"""horayzon.horizon -- terrain horizon on MI355X.
+
+Host-side mirror of the reference's Cython boundary ``horayzon/horizon.pyx``:
+same function name, positional order, defaults, validation order and
+exception classes (horizon.pyx:29-49, 109-156); the computation runs in
+hand-written HIP kernels behind the C ABI (hz_horizon_gridded).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Scene, hz_opts, hz_stats, ptr
+
+last_stats = None   # hz_stats of the most recent call as a dict (timers, ray count)
+
+
+def _check_f32(a, ndim, name):
+    # Cython's typed-buffer arguments raise ValueError on dtype/ndim mismatch
+    if not isinstance(a, np.ndarray):
+        raise TypeError("Argument '%s' has incorrect type (expected numpy.ndarray, got %s)"
+                        % (name, type(a).__name__))
+    if a.ndim != ndim:
+        raise ValueError("Buffer has wrong number of dimensions (expected %d, got %d)" % (ndim, a.ndim))
+    if a.dtype != np.float32:
+        raise ValueError("Buffer dtype mismatch, expected 'float32_t' but got '%s'" % a.dtype.name)
+
+
+def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
+                    offset_0, offset_1, dist_search, azim_num=360, hori_acc=0.25,
+                    ray_algorithm="guess_constant", geom_type="grid",
+                    vert_simp=np.array([0.0, 0.0, 0.0, 0.0], dtype=np.float32),
+                    num_vert_simp=1,
+                    tri_ind_simp=np.array([0, 0, 0, 0], dtype=np.int32),
+                    num_tri_simp=1, elev_ang_low_lim=-15.0, mask=None,
+                    hori_fill=0.0, ray_org_elev=0.01, *, device=0, verbose=False,
+                    scene=None, svf_vec_tilt=None, rows=None, count_work=False):
+    """Horizon computation for gridded domain.
+
+    Parameters, units and return values are those of the reference
+    (horizon.pyx:50-106): ``hori_buffer`` float32 (y, x, azim_num) [radian],
+    ``azim`` float32 (azim_num) [radian].
+
+    Additional keyword-only arguments (not in the reference): ``device`` (HIP
+    ordinal), ``verbose`` (print the reference's stdout report), ``scene`` (a
+    prebuilt ``Scene`` to skip the BVH build), ``svf_vec_tilt`` (tilted normals;
+    when given the sky view factor is accumulated in the same kernel and
+    returned as a third value), ``rows`` ((begin, end) slab of inner-domain rows
+    to compute; the rest of ``hori_buffer`` stays NaN), ``count_work``.
+    """
+    global last_stats
+    _check_f32(vert_grid, 1, "vert_grid")
+    _check_f32(vec_norm, 3, "vec_norm")
+    _check_f32(vec_north, 3, "vec_north")
+    _check_f32(vert_simp, 1, "vert_simp")
+    if not isinstance(tri_ind_simp, np.ndarray) or tri_ind_simp.ndim != 1 or tri_ind_simp.dtype != np.int32:
+        raise ValueError("Buffer dtype mismatch, expected 'int32_t' for tri_ind_simp")
+    if mask is not None and (not isinstance(mask, np.ndarray) or mask.ndim != 2):
+        raise ValueError("Buffer has wrong number of dimensions (expected 2) for mask")
+
+    # Check consistency and validity of input arguments (horizon.pyx:109-146)
+    if len(vert_grid) < (dem_dim_0 * dem_dim_1 * 3):
+        raise ValueError("inconsistency between input arguments vert_grid, "
+                         "dem_dim_0 and dem_dim_1")
+    if ((offset_0 + vec_norm.shape[0] > dem_dim_0)
+            or (offset_1 + vec_norm.shape[1] > dem_dim_1)):
+        raise ValueError("inconsistency between input arguments dem_dim_0, "
+                         "dem_dim_1, offset_0, offset_1 and vec_norm")
+    if ((vec_norm.ndim != 3) or (vec_north.ndim != 3)
+            or (vec_norm.shape[0] != vec_north.shape[0])
+            or (vec_norm.shape[1] != vec_north.shape[1])
+            or (vec_norm.shape[2] != vec_north.shape[2])):
+        raise ValueError("dimension (lengths) of vec_norm and/or vec_north "
+                         "is/are erroneous")
+    if ray_algorithm not in ("discrete_sampling", "binary_search",
+                             "guess_constant"):
+        raise ValueError("invalid input argument for ray_algorithm")
+    if geom_type not in ("triangle", "quad", "grid"):
+        raise ValueError("invalid input argument for geom_type")
+    if len(vert_simp) < (num_vert_simp * 3):
+        raise ValueError("inconsistency between input arguments vert_simp "
+                         "and num_vert_simp")
+    if len(tri_ind_simp) < (num_tri_simp * 3):
+        raise ValueError("inconsistency between input arguments tri_ind_simp "
+                         "and num_tri_simp")
+    if tri_ind_simp.max() > (num_vert_simp - 1):
+        raise ValueError("triangle indices of simplified outer domain exceed "
+                         "number of vertices")
+    if hori_acc > 10.0:
+        raise ValueError("limit of hori_acc (10 degree) is exceeded")
+    if mask is None:
+        mask = np.ones((vec_norm.shape[0], vec_norm.shape[1]), dtype=np.uint8)
+    if (mask.shape[0] != vec_norm.shape[0]) \
+            or (mask.shape[1] != vec_norm.shape[1]):
+        raise ValueError("shape of mask is inconsistent with other input")
+    if mask.dtype != "uint8":
+        raise TypeError("data type of mask must be 'uint8'")
+    if ray_org_elev < 0.005:
+        raise TypeError("minimal allowed value for 'ray_org_elev' is 0.005 m")
+
+    # Check size of input geometries (horizon.pyx:149-153)
+    if (dem_dim_0 > 32767) or (dem_dim_1 > 32767):
+        raise ValueError("maximal allowed input length for dem_dim_0 and "
+                         "dem_dim_1 is 32'767")
+    if vert_simp.nbytes > (16.0 * 10 ** 9):
+        raise ValueError("vertex buffer vert_simp is larger than 16 GB")
+
+    # Ensure that passed arrays are contiguous in memory (horizon.pyx:159-163)
+    vert_grid = np.ascontiguousarray(vert_grid)
+    vec_norm = np.ascontiguousarray(vec_norm)
+    vec_north = np.ascontiguousarray(vec_north)
+    vert_simp = np.ascontiguousarray(vert_simp)
+    tri_ind_simp = np.ascontiguousarray(tri_ind_simp)
+    mask = np.ascontiguousarray(mask)
+
+    dim_in_0, dim_in_1 = vec_norm.shape[0], vec_norm.shape[1]
+    # Allocate horizon array (horizon.pyx:170-173)
+    hori_buffer = np.empty((dim_in_0, dim_in_1, azim_num), dtype=np.float32)
+    hori_buffer.fill(np.nan)
+
+    opts = hz_opts()
+    opts.device = device
+    opts.verbose = int(bool(verbose))
+    opts.top_nodes = -1
+    opts.regroup = -1
+    opts.count_work = int(bool(count_work))
+    if rows is not None:
+        opts.row_begin, opts.row_end = int(rows[0]), int(rows[1])
+    svf = None
+    if svf_vec_tilt is not None:
+        _check_f32(svf_vec_tilt, 3, "svf_vec_tilt")
+        if svf_vec_tilt.shape != vec_norm.shape:
+            raise ValueError("Inconsistent/incorrect shapes of input arrays")
+        svf_vec_tilt = np.ascontiguousarray(svf_vec_tilt)
+        svf = np.full((dim_in_0, dim_in_1), np.nan, dtype=np.float32)
+        opts.svf = ptr(svf)
+        opts.vec_tilt = ptr(svf_vec_tilt)
+    stats = hz_stats()
+    L = _lib.lib()
+    if scene is None:
+        rc = L.hz_horizon_gridded(
+            ptr(vert_grid), dem_dim_0, dem_dim_1, ptr(vec_norm), ptr(vec_north),
+            offset_0, offset_1, ptr(hori_buffer), dim_in_0, dim_in_1, azim_num,
+            dist_search, hori_acc, ray_algorithm.encode("utf-8"),
+            geom_type.encode("utf-8"), ptr(vert_simp), num_vert_simp,
+            ptr(tri_ind_simp), num_tri_simp, elev_ang_low_lim, ptr(mask),
+            hori_fill, ray_org_elev, C.byref(opts), C.byref(stats))
+    else:
+        opts.device = scene.device
+        rc = L.hz_horizon_gridded_scene(
+            scene._h, ptr(vec_norm), ptr(vec_north), offset_0, offset_1,
+            ptr(hori_buffer), dim_in_0, dim_in_1, azim_num, dist_search, hori_acc,
+            ray_algorithm.encode("utf-8"), elev_ang_low_lim, ptr(mask), hori_fill,
+            ray_org_elev, C.byref(opts), C.byref(stats))
+    _lib.check(rc)
+    last_stats = stats.as_dict()
+
+    # Recompute azimuth (horizon.pyx:191-195)
+    azim = np.empty(azim_num, dtype=np.float32)
+    for i in range(azim_num):
+        azim[i] = ((2 * np.pi) / azim_num * i)
+
+    if svf is not None:
+        return hori_buffer, azim, svf
+    return hori_buffer, azim
+
+
+def horizon_tables(azim_num, hori_acc, elev_ang_low_lim):
+    """The trig tables the library builds on the host (for bit-for-bit checks)."""
+    L = _lib.lib()
+    n = C.c_int(0)
+    _lib.check(L.hz_horizon_tables(azim_num, hori_acc, elev_ang_low_lim, None, None, 0,
+                                   None, None, None, C.byref(n)))
+    out = {k: np.empty(azim_num, np.float32) for k in ("azim_sin", "azim_cos")}
+    out.update({k: np.empty(n.value, np.float32) for k in ("elev_ang", "elev_sin", "elev_cos")})
+    _lib.check(L.hz_horizon_tables(azim_num, hori_acc, elev_ang_low_lim, ptr(out["azim_sin"]),
+                                   ptr(out["azim_cos"]), n.value, ptr(out["elev_ang"]),
+                                   ptr(out["elev_sin"]), ptr(out["elev_cos"]), C.byref(n)))
+    out["elev_num"] = n.value
+    return out

@@ -1,0 +1,182 @@
+/*
+ * horayzon_hip.h -- C ABI of libhorayzon_hip.so (MI355X / gfx950).
+ *
+ * Drop-in boundary for the ray-casting core of HORAYZON.  Each entry point
+ * names the reference interface it replaces (paths relative to the reference
+ * tree).  The reference exposes C++-linkage functions to Cython
+ * (horizon.pyx:13-27, shadow.pyx:8-15); a maintainer binds these C symbols
+ * instead (see INTEGRATION.md for the Cython / ctypes stubs).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every array is caller-owned and is never
+ *     retained after the call returns (the reference keeps raw pointers in
+ *     CppTerrain, shadow_comp.cpp:332-346; this library copies to HBM).
+ *   - every data pointer may be HOST memory (NumPy) or DEVICE memory (HBM) of
+ *     the selected GPU; the library detects which (hipPointerGetAttributes).
+ *   - every function returns 0 on success and a non-zero status otherwise;
+ *     hz_last_error() returns the message (thread local).  The reference
+ *     returns void and only prints (horizon_comp.cpp:74-76).
+ *   - units and meaning of the scalar arguments are exactly the reference's
+ *     (degrees, kilometres, ... as in horizon_comp.h:8-20, shadow_comp.h:22-38).
+ */
+#ifndef HORAYZON_HIP_H
+#define HORAYZON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HZ_OK 0
+#define HZ_ERR_ARG 1      /* invalid argument                                  */
+#define HZ_ERR_HIP 2      /* HIP runtime failure (message has the HIP error)   */
+#define HZ_ERR_NODEV 3    /* no usable gfx950 device                           */
+#define HZ_ERR_DEPTH 4    /* BVH deeper than the traversal stack               */
+
+/* Optional controls; pass NULL for the reference's behaviour on device 0.     */
+typedef struct hz_opts {
+    int32_t device;        /* HIP device ordinal                               */
+    int32_t verbose;       /* 1: print the reference's stdout report           */
+    int32_t row_begin;     /* inner-domain row slab [row_begin, row_end) to    */
+    int32_t row_end;       /*   compute; row_end <= 0 means dim_in_0           */
+    int32_t top_nodes;     /* BVH nodes staged in LDS per workgroup (-1 auto)  */
+    int32_t regroup;       /* wave regroup threshold in lanes (-1 auto)        */
+    int32_t count_work;    /* 1: also count BVH nodes / triangle tests (slow)  */
+    int32_t reserved;
+    float  *svf;           /* optional fused sky view factor out, f32[y][x]    */
+    const float *vec_tilt; /* tilted normals f32[y][x][3] for svf              */
+    int32_t skip_hori;     /* 1: hori_buffer may be NULL, only svf is written  */
+    int32_t reserved2;
+} hz_opts;
+
+/* Run-time self report (the quantities the reference prints,                  */
+/* horizon_comp.cpp:225-227, 805-810, 816-818).                                */
+typedef struct hz_stats {
+    uint64_t num_rays;     /* occlusion queries, counted as the reference does */
+    uint64_t num_cells;    /* cells with mask == 1 in the computed slab        */
+    uint64_t guard_events; /* searches stopped where the reference never ends  */
+    uint64_t nodes_visited;/* only with count_work                             */
+    uint64_t tris_tested;  /* only with count_work                             */
+    double t_bvh_s;        /* "BVH build time"                                 */
+    double t_h2d_s;        /* host -> HBM copies                               */
+    double t_kernel_s;     /* "Ray tracing time" (traversal kernels only)      */
+    double t_d2h_s;        /* HBM -> host copies                               */
+    double t_total_s;      /* "Total run time"                                 */
+    int32_t bvh_height;
+    int32_t elev_num;
+    uint64_t scene_bytes;  /* HBM bytes of vertices + LBVH                     */
+} hz_stats;
+
+const char *hz_last_error(void);
+int hz_device_count(int *count);
+/* name[0..cap) <- device name, *cu <- compute units, *hbm_bytes <- total HBM  */
+int hz_device_info(int device, char *name, int cap, int *cu, uint64_t *hbm_bytes);
+
+/* ------------------------------------------------------------------------- */
+/* Scene = vertices + flat LBVH, resident in HBM as ONE contiguous blob        */
+/* (so that a multi-GPU job can broadcast it with a single collective).        */
+/* Replaces initializeDevice/initializeScene, horizon_comp.cpp:74-231,         */
+/* shadow_comp.cpp:171-298 (Embree rtcNewScene ... rtcCommitScene).            */
+/* ------------------------------------------------------------------------- */
+typedef struct hz_scene hz_scene;
+
+int hz_scene_create(const float *vert_grid, int dem_dim_0, int dem_dim_1,
+                    const char *geom_type,
+                    const float *vert_simp, int num_vert_simp,
+                    const int32_t *tri_ind_simp, int num_tri_simp,
+                    int device, hz_scene **scene, hz_stats *stats);
+/* the blob: position independent, valid on any gfx950 device                  */
+int hz_scene_blob(const hz_scene *scene, void **device_ptr, size_t *nbytes);
+/* wrap a blob that already sits in HBM of `device` (e.g. received by an RCCL  */
+/* broadcast into caller-owned memory); the scene does not own the memory      */
+int hz_scene_adopt(void *device_ptr, size_t nbytes, int device, hz_scene **scene);
+int hz_scene_destroy(hz_scene *scene);
+
+/* ------------------------------------------------------------------------- */
+/* Horizon                                                                     */
+/* ------------------------------------------------------------------------- */
+
+/* One-shot call; argument list mirrors horizon_gridded_comp                   */
+/* (horizon_comp.h:8-20, horizon_comp.cpp:629-822).  Builds the scene,         */
+/* computes, releases (the reference also rebuilds per call, :813-814).        */
+int hz_horizon_gridded(const float *vert_grid, int dem_dim_0, int dem_dim_1,
+                       const float *vec_norm, const float *vec_north,
+                       int offset_0, int offset_1,
+                       float *hori_buffer, int dim_in_0, int dim_in_1,
+                       int azim_num, float dist_search, float hori_acc,
+                       const char *ray_algorithm, const char *geom_type,
+                       const float *vert_simp, int num_vert_simp,
+                       const int32_t *tri_ind_simp, int num_tri_simp,
+                       float elev_ang_low_lim, const uint8_t *mask,
+                       float hori_fill, float ray_org_elev,
+                       const hz_opts *opts, hz_stats *stats);
+
+/* Same computation on an existing scene (persistent BVH; additive API).       */
+int hz_horizon_gridded_scene(const hz_scene *scene,
+                             const float *vec_norm, const float *vec_north,
+                             int offset_0, int offset_1,
+                             float *hori_buffer, int dim_in_0, int dim_in_1,
+                             int azim_num, float dist_search, float hori_acc,
+                             const char *ray_algorithm,
+                             float elev_ang_low_lim, const uint8_t *mask,
+                             float hori_fill, float ray_org_elev,
+                             const hz_opts *opts, hz_stats *stats);
+
+/* Trig tables exactly as horizon_comp.cpp:711-731 builds them (host side;     */
+/* exported so tests can compare them bit for bit with the oracle).            */
+/* Returns elev_num through *elev_num; arrays may be NULL to query the size.   */
+int hz_horizon_tables(int azim_num, float hori_acc, float elev_ang_low_lim,
+                      float *azim_sin, float *azim_cos, int elev_cap,
+                      float *elev_ang, float *elev_sin, float *elev_cos,
+                      int *elev_num);
+
+/* Sky view factor from a horizon array: _sky_view_factor_cy,                  */
+/* topo_param.pyx:412-460.                                                     */
+int hz_sky_view_factor(const float *azim, const float *hori, const float *vec_tilt,
+                       int len_0, int len_1, int len_2, float *svf, int device);
+
+/* ------------------------------------------------------------------------- */
+/* Shadow: handle API mirroring class CppTerrain (shadow_comp.h:4-39)          */
+/* ------------------------------------------------------------------------- */
+typedef struct hz_terrain hz_terrain;
+
+/* CppTerrain::CppTerrain, shadow_comp.cpp:304-308 */
+int hz_terrain_create(int device, hz_terrain **terrain);
+/* CppTerrain::initialise, shadow_comp.cpp:318-380 (argument order as there)   */
+int hz_terrain_initialise(hz_terrain *terrain, const float *vert_grid,
+                          int dem_dim_0, int dem_dim_1, int offset_0, int offset_1,
+                          const float *vec_tilt, const float *vec_norm,
+                          int dim_in_0, int dim_in_1,
+                          const float *surf_enl_fac, const float *elevation,
+                          const uint8_t *mask, const char *geom_type,
+                          float sw_dir_cor_fill, float ang_max, int refrac_cor,
+                          hz_stats *stats);
+/* additive: initialise on an existing scene (scene must outlive the terrain)  */
+int hz_terrain_initialise_scene(hz_terrain *terrain, const hz_scene *scene,
+                                int offset_0, int offset_1,
+                                const float *vec_tilt, const float *vec_norm,
+                                int dim_in_0, int dim_in_1,
+                                const float *surf_enl_fac, const float *elevation,
+                                const uint8_t *mask,
+                                float sw_dir_cor_fill, float ang_max, int refrac_cor);
+/* CppTerrain::shadow, shadow_comp.cpp:386-491: u8[y][x], 0/1/2/3              */
+int hz_terrain_shadow(hz_terrain *terrain, const float *sun_position,
+                      uint8_t *shadow_buffer, hz_stats *stats);
+/* CppTerrain::sw_dir_cor, shadow_comp.cpp:495-605: f32[y][x]                  */
+int hz_terrain_sw_dir_cor(hz_terrain *terrain, const float *sun_position,
+                          float *sw_dir_cor_buffer, hz_stats *stats);
+/* additive batch forms: num_sun positions f32[num_sun][3] ->                  */
+/* buffers [num_sun][y][x]; one launch per position on one stream              */
+int hz_terrain_shadow_batch(hz_terrain *terrain, const float *sun_positions,
+                            int num_sun, uint8_t *shadow_buffers, hz_stats *stats);
+int hz_terrain_sw_dir_cor_batch(hz_terrain *terrain, const float *sun_positions,
+                                int num_sun, float *sw_dir_cor_buffers, hz_stats *stats);
+/* CppTerrain::~CppTerrain, shadow_comp.cpp:310-316 */
+int hz_terrain_destroy(hz_terrain *terrain);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HORAYZON_HIP_H */

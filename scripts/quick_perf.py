@@ -1,0 +1,42 @@
+"""Quick performance probe: central window of the 3601^2 synthetic tile, 360 azimuths."""
+import argparse
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+import horayzon_amd as hz
+from horayzon_amd import synth
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--n", type=int, default=3601)
+ap.add_argument("--win", type=int, default=512)
+ap.add_argument("--azim", type=int, default=360)
+ap.add_argument("--dist", type=float, default=50.0)
+ap.add_argument("--alg", default="guess_constant")
+ap.add_argument("--count", action="store_true")
+ap.add_argument("--reps", type=int, default=2)
+args = ap.parse_args()
+
+t = time.time()
+g = synth.fractal_tile(n=args.n, offset=16)
+print("synth %.1fs" % (time.time() - t), flush=True)
+n, w = args.n, args.win
+off = (n - w) // 2
+vec_norm, vec_north = synth.planar_frames(w, w)
+t = time.time()
+sc = hz.Scene.create(g["vert_grid"], n, n)
+print("scene create %.2fs" % (time.time() - t), json.dumps(sc.stats), flush=True)
+for rep in range(args.reps):
+    t = time.time()
+    hori, azim = hz.horizon.horizon_gridded(g["vert_grid"], n, n, vec_norm, vec_north, off, off,
+                                            args.dist, azim_num=args.azim, ray_algorithm=args.alg,
+                                            scene=sc, count_work=args.count and rep == args.reps - 1)
+    st = hz.horizon.last_stats
+    print("rep %d wall %.2fs kernel %.3fs rays %d rays/(cell*az) %.2f Mray/s %.1f cells/s %.0f nodes/ray %.1f tris/ray %.1f"
+          % (rep, time.time() - t, st["t_kernel_s"], st["num_rays"], st["num_rays"] / (w * w * args.azim),
+             st["num_rays"] / st["t_kernel_s"] / 1e6, w * w / st["t_kernel_s"],
+             st["nodes_visited"] / max(st["num_rays"], 1), st["tris_tested"] / max(st["num_rays"], 1)), flush=True)
+print("hori range deg", np.rad2deg(np.nanmin(hori)), np.rad2deg(np.nanmax(hori)))

@@ -1,0 +1,69 @@
+"""Seeded synthetic inputs shared by the CPU and GPU tests."""
+import numpy as np
+
+from horayzon_amd import synth
+
+GRID_KEYS = ("vert_grid", "dem_dim_0", "dem_dim_1", "vec_norm", "vec_north", "offset_0", "offset_1")
+
+
+def grid_kwargs(g):
+    return {k: g[k] for k in GRID_KEYS}
+
+
+def c2_hill(height=1000.0):
+    """BASELINE config 1/2: 200 x 200 Gaussian hill (1000 m: no search of the
+    reference runs into its non-terminating loops; 1500 m does)."""
+    return synth.gaussian_hill(n=200, dx=50.0, height=height, sigma=1500.0, offset=10)
+
+
+def rough_terrain(n0, n1, seed, dx=30.0, dy=30.0, relief=800.0, offset=4, tilt_frames=False,
+                  origin=(0.0, 0.0)):
+    """Small fractal terrain; optionally with per-cell rotated (norm, north) frames that
+    mimic a curved-earth ENU set-up (non axis-aligned rays)."""
+    rng = np.random.default_rng(seed)
+    z = synth.fractal_elevation(n0, n1, seed=seed, z_min=100.0, z_max=100.0 + relief)
+    x = (origin[0] + np.arange(n1) * dx).astype(np.float32)
+    y = (origin[1] + (n0 - 1 - np.arange(n0)) * dy).astype(np.float32)
+    xx, yy = np.meshgrid(x, y)
+    in0, in1 = n0 - 2 * offset, n1 - 2 * offset
+    vec_norm, vec_north = synth.planar_frames(in0, in1)
+    if tilt_frames:
+        # small smooth rotations of the local frame (as on a curved DEM)
+        ax = (0.02 * (np.arange(in0)[:, None] - in0 / 2) / in0 + 0 * np.arange(in1)[None, :]).astype(np.float64)
+        ay = (0.02 * (np.arange(in1)[None, :] - in1 / 2) / in1 + 0 * np.arange(in0)[:, None]).astype(np.float64)
+        nrm = np.stack([np.sin(ay), -np.sin(ax) * np.cos(ay), np.cos(ax) * np.cos(ay)], axis=2)
+        north0 = np.array([0.0, 1.0, 0.0])
+        north = north0[None, None, :] - (nrm * north0).sum(axis=2, keepdims=True) * nrm
+        north /= np.linalg.norm(north, axis=2, keepdims=True)
+        # rotate north slightly about the normal
+        ang = 0.01 * rng.standard_normal((in0, in1, 1))
+        east = np.cross(north, nrm)
+        north = np.cos(ang) * north + np.sin(ang) * east
+        vec_norm = np.ascontiguousarray(nrm, np.float32)
+        vec_north = np.ascontiguousarray(north, np.float32)
+    return dict(vert_grid=synth.pack_vertices(xx, yy, z), dem_dim_0=n0, dem_dim_1=n1,
+                vec_norm=vec_norm, vec_north=vec_north, offset_0=offset, offset_1=offset,
+                x=x, y=y, z=z)
+
+
+def outer_tin(g, margin=3000.0, zval=900.0):
+    """A coarse ring of triangles around the DEM (simplified outer domain,
+    horizon_comp.cpp:199-218): 8 vertices, 8 triangles."""
+    x0, x1 = float(g["x"].min()), float(g["x"].max())
+    y0, y1 = float(g["y"].min()), float(g["y"].max())
+    v = np.array([[x0, y0, zval * 0.2], [x1, y0, zval * 0.3], [x1, y1, zval * 0.25], [x0, y1, zval * 0.2],
+                  [x0 - margin, y0 - margin, zval], [x1 + margin, y0 - margin, zval * 1.1],
+                  [x1 + margin, y1 + margin, zval * 0.9], [x0 - margin, y1 + margin, zval]], np.float32)
+    t = np.array([[0, 4, 5], [0, 5, 1], [1, 5, 6], [1, 6, 2], [2, 6, 7], [2, 7, 3], [3, 7, 4], [3, 4, 0]], np.int32)
+    return v.ravel().copy(), v.shape[0], t.ravel().copy(), t.shape[0]
+
+
+def terrain_inputs(g):
+    """Terrain.initialise inputs for a planar case dict."""
+    o = g["offset_0"]
+    vec_tilt, surf_enl_fac = synth.tilt_from_planar_dem(g["x"], g["y"], g["z"], o)
+    in0, in1 = vec_tilt.shape[:2]
+    vec_norm, _ = synth.planar_frames(in0, in1)
+    elevation = np.ascontiguousarray(g["z"][o:o + in0, o:o + in1], np.float32)
+    mask = np.ones((in0, in1), np.uint8)
+    return vec_tilt, vec_norm, surf_enl_fac, elevation, mask

