@@ -6,6 +6,7 @@ no GPU is usable, calls fail loudly.
 """
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -52,6 +53,26 @@ SYMBOLS = (
 )
 
 
+def _preload_hip_runtime():
+    """One process can hold only one HIP runtime.  PyTorch-ROCm wheels bundle their own
+    libamdhip64.so.7 (same SONAME as /opt/rocm's); whichever is mapped first serves both
+    this library and torch.  If torch is installed but not imported yet, map ITS runtime
+    first so that a later ``import torch`` (bench.py uses torch.distributed / RCCL for the
+    multi-GPU path) still finds the GPU.  HORAYZON_HIP_RUNTIME=system skips this."""
+    if os.environ.get("HORAYZON_HIP_RUNTIME", "") == "system" or "torch" in sys.modules:
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass
+
+
 def lib():
     """Load libhorayzon_hip.so (built by horayzon_amd/csrc/Makefile or
     __graft_entry__.build())."""
@@ -63,6 +84,7 @@ def lib():
             "libhorayzon_hip.so not found at %s -- build it with "
             "`make -C horayzon_amd/csrc` (hipcc, gfx950). There is no CPU "
             "fallback in this package." % LIB_PATH)
+    _preload_hip_runtime()
     L = C.CDLL(LIB_PATH)
     vp, ip = C.c_void_p, C.c_int
     L.hz_last_error.restype = C.c_char_p

@@ -382,7 +382,7 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
     p.dist = a.dist; p.hori_fill = a.hori_fill; p.ray_org_elev = a.ray_org_elev;
     const int height = sc->hdr.height;
     const int stack = (height <= 32) ? 32 : 64;
-    int top = (a.top_nodes < 0) ? 511 : a.top_nodes;
+    int top = (a.top_nodes < 0) ? 127 : a.top_nodes;
     top = std::min(top, sc->hdr.n_top);
     p.top_nodes = top;
     p.regroup = (a.regroup < 0) ? 0 : std::min(a.regroup, 64);

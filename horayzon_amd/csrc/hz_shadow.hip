@@ -200,7 +200,7 @@ int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st) {
     p.refrac = a.refrac_cor; p.which = a.which;
     p.out_u8 = a.out_u8; p.out_f32 = a.out_f32;
     const int stack = (sc->hdr.height <= 32) ? 32 : 64;
-    int top = (a.top_nodes < 0) ? 511 : a.top_nodes;
+    int top = (a.top_nodes < 0) ? 127 : a.top_nodes;
     top = std::min(top, sc->hdr.n_top);
     p.top_nodes = top;
     p.counters = a.counters;

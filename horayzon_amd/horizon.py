@@ -34,7 +34,8 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
                     tri_ind_simp=np.array([0, 0, 0, 0], dtype=np.int32),
                     num_tri_simp=1, elev_ang_low_lim=-15.0, mask=None,
                     hori_fill=0.0, ray_org_elev=0.01, *, device=0, verbose=False,
-                    scene=None, svf_vec_tilt=None, rows=None, count_work=False):
+                    scene=None, svf_vec_tilt=None, rows=None, count_work=False,
+                    _top_nodes=-1, _regroup=-1):
     """Horizon computation for gridded domain.
 
     Parameters, units and return values are those of the reference
@@ -121,8 +122,8 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
     opts = hz_opts()
     opts.device = device
     opts.verbose = int(bool(verbose))
-    opts.top_nodes = -1
-    opts.regroup = -1
+    opts.top_nodes = _top_nodes
+    opts.regroup = _regroup
     opts.count_work = int(bool(count_work))
     if rows is not None:
         opts.row_begin, opts.row_end = int(rows[0]), int(rows[1])
