@@ -43,7 +43,7 @@ class hz_stats(C.Structure):
 
 # every symbol include/horayzon_hip.h declares (tests check that all are exported)
 SYMBOLS = (
-    "hz_last_error", "hz_device_count", "hz_device_info",
+    "hz_last_error", "hz_abi_struct_sizes", "hz_device_count", "hz_device_info",
     "hz_scene_create", "hz_scene_blob", "hz_scene_adopt", "hz_scene_destroy",
     "hz_horizon_gridded", "hz_horizon_gridded_scene", "hz_horizon_tables",
     "hz_sky_view_factor",
@@ -88,6 +88,7 @@ def lib():
     L = C.CDLL(LIB_PATH)
     vp, ip = C.c_void_p, C.c_int
     L.hz_last_error.restype = C.c_char_p
+    L.hz_abi_struct_sizes.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.hz_device_count.argtypes = [C.POINTER(C.c_int)]
     L.hz_device_info.argtypes = [ip, C.c_char_p, ip, C.POINTER(C.c_int), C.POINTER(C.c_uint64)]
     L.hz_scene_create.argtypes = [vp, ip, ip, C.c_char_p, vp, ip, vp, ip, ip,
@@ -118,6 +119,12 @@ def lib():
     for name in SYMBOLS:
         if name != "hz_last_error":
             getattr(L, name).restype = C.c_int
+    a, b = C.c_int(0), C.c_int(0)
+    L.hz_abi_struct_sizes(C.byref(a), C.byref(b))
+    if a.value != C.sizeof(hz_opts) or b.value != C.sizeof(hz_stats):
+        raise HorayzonHipError("ABI mismatch between _lib.py and libhorayzon_hip.so "
+                               "(hz_opts %d/%d, hz_stats %d/%d bytes)"
+                               % (C.sizeof(hz_opts), a.value, C.sizeof(hz_stats), b.value))
     _lib = L
     return L
 

@@ -306,6 +306,12 @@ extern "C" {
 
 const char *hz_last_error(void) { return g_error.c_str(); }
 
+int hz_abi_struct_sizes(int *opts_bytes, int *stats_bytes) {
+    if (opts_bytes) *opts_bytes = (int)sizeof(hz_opts);
+    if (stats_bytes) *stats_bytes = (int)sizeof(hz_stats);
+    return HZ_OK;
+}
+
 int hz_device_count(int *count) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }

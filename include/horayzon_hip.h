@@ -70,6 +70,8 @@ typedef struct hz_stats {
 } hz_stats;
 
 const char *hz_last_error(void);
+/* sizeof(hz_opts), sizeof(hz_stats) as compiled: lets a binding verify its mirror */
+int hz_abi_struct_sizes(int *opts_bytes, int *stats_bytes);
 int hz_device_count(int *count);
 /* name[0..cap) <- device name, *cu <- compute units, *hbm_bytes <- total HBM  */
 int hz_device_info(int device, char *name, int cap, int *cu, uint64_t *hbm_bytes);

@@ -132,8 +132,11 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
                     vert_simp=None, num_vert_simp=1, tri_ind_simp=None,
                     num_tri_simp=1, elev_ang_low_lim=-15.0, mask=None,
                     hori_fill=0.0, ray_org_elev=0.01, *, mode=MODE_BVH,
-                    rows=None, count_work=False, return_stats=False):
-    """CPU restatement of horayzon.horizon.horizon_gridded (horizon.pyx:29-197)."""
+                    rows=None, slab_only=False, count_work=False, return_stats=False):
+    """CPU restatement of horayzon.horizon.horizon_gridded (horizon.pyx:29-197).
+
+    ``rows=(begin, end)`` restricts the computation to a slab of inner-domain rows;
+    with ``slab_only`` only that slab is allocated and returned (large tiles)."""
     if vert_simp is None:
         vert_simp = np.zeros(4, np.float32)
     if tri_ind_simp is None:
@@ -147,12 +150,18 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
     if mask is None:
         mask = np.ones((d0, d1), np.uint8)
     mask = np.ascontiguousarray(mask, np.uint8)
-    hori = np.full((d0, d1, azim_num), np.nan, np.float32)
-    stats = np.zeros(4, np.uint64)
     rb, re = (0, d0) if rows is None else rows
+    stats = np.zeros(8, np.uint64)
+    if slab_only:
+        hori = np.full((max(re - rb, 0), d1, azim_num), np.nan, np.float32)
+        # the C driver indexes by global cell: shift the slab back by rb rows
+        hori_ptr = C.cast(C.c_void_p(hori.ctypes.data - 4 * rb * d1 * azim_num), C.POINTER(C.c_float))
+    else:
+        hori = np.full((d0, d1, azim_num), np.nan, np.float32)
+        hori_ptr = _f(hori)
     rc = lib().orc_horizon_gridded(
         _f(vert_grid), dem_dim_0, dem_dim_1, _f(vec_norm), _f(vec_north),
-        offset_0, offset_1, _f(hori), d0, d1, azim_num, dist_search, hori_acc,
+        offset_0, offset_1, hori_ptr, d0, d1, azim_num, dist_search, hori_acc,
         ray_algorithm.encode(), geom_type.encode(), _f(vert_simp), num_vert_simp,
         _i32(tri_ind_simp), num_tri_simp, elev_ang_low_lim, _u8(mask), hori_fill,
         ray_org_elev, mode, rb, re, int(count_work),
@@ -164,7 +173,8 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
         azim[i] = ((2 * np.pi) / azim_num * i)
     if return_stats:
         return hori, azim, dict(rays=int(stats[0]), guards=int(stats[1]),
-                                nodes=int(stats[2]), tris=int(stats[3]))
+                                nodes=int(stats[2]), tris=int(stats[3]),
+                                t_build_s=float(stats[4]) * 1e-9, t_rays_s=float(stats[5]) * 1e-9)
     return hori, azim
 
 

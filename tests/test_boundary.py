@@ -1,0 +1,194 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads here (hipcc cross-compiles),
+exports every symbol the header declares, builds the reference's trig tables bit for bit,
+and the Python mirror raises the reference's exceptions.  No compute call is made: without
+a GPU the library must fail loudly, never fall back."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import horayzon_amd
+from horayzon_amd import _lib, synth
+from tests import cases
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "horayzon_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(hz_[a-z_0-9]+)\s*\(", hdr))
+    assert len(declared) >= 20
+    assert declared == set(_lib.SYMBOLS)
+    L = _lib.lib()
+    for name in declared:
+        assert hasattr(L, name), name
+
+
+def test_no_torch_types_in_abi():
+    hdr = open(os.path.join(ROOT, "include", "horayzon_hip.h")).read()
+    assert "torch" not in hdr.lower() and "at::" not in hdr
+
+
+def test_tables_bit_identical_to_oracle(orc):
+    for azim_num, acc, low in ((36, 0.25, -15.0), (360, 0.25, -15.0), (7, 0.1, -89.98), (45, 1.0, -40.0),
+                               (360, 0.15, -15.0), (13, 10.0, 0.0)):
+        t = horayzon_amd.horizon.horizon_tables(azim_num, acc, low)
+        o = orc.tables(azim_num, acc, low, 10.0)
+        assert t["elev_num"] == o["elev_num"]
+        for k in ("azim_sin", "azim_cos", "elev_ang", "elev_sin", "elev_cos"):
+            assert np.array_equal(t[k], o[k]), (k, azim_num, acc, low)
+    # elev_num of SURVEY.md appendix A
+    assert horayzon_amd.horizon.horizon_tables(360, 0.25, -15.0)["elev_num"] == 2101
+    assert horayzon_amd.horizon.horizon_tables(360, 0.1, -89.98)["elev_num"] == 9000
+
+
+def test_fails_loudly_without_gpu():
+    if _lib.device_count() > 0:
+        pytest.skip("a GPU is visible; the no-device error path cannot be exercised")
+    g = cases.rough_terrain(12, 12, seed=1, offset=2)
+    with pytest.raises(horayzon_amd.HorayzonHipError, match="no HIP device"):
+        horayzon_amd.horizon.horizon_gridded(**cases.grid_kwargs(g), dist_search=1.0, azim_num=4)
+    with pytest.raises(horayzon_amd.HorayzonHipError, match="no HIP device"):
+        horayzon_amd.shadow.Terrain()
+    with pytest.raises(horayzon_amd.HorayzonHipError):
+        horayzon_amd.topo_param.sky_view_factor(np.zeros(4, np.float32), np.zeros((2, 2, 4), np.float32),
+                                                np.ones((2, 2, 3), np.float32))
+
+
+def test_drop_in_alias_package():
+    import horayzon
+    import horayzon.horizon
+    import horayzon.shadow
+    assert horayzon.horizon.horizon_gridded is horayzon_amd.horizon.horizon_gridded
+    assert horayzon.shadow.Terrain is horayzon_amd.shadow.Terrain
+    assert horayzon.topo_param.sky_view_factor is horayzon_amd.topo_param.sky_view_factor
+
+
+def test_signature_matches_reference():
+    import inspect
+    sig = inspect.signature(horayzon_amd.horizon.horizon_gridded)
+    names = [p for p in sig.parameters]
+    assert names[:20] == ["vert_grid", "dem_dim_0", "dem_dim_1", "vec_norm", "vec_north", "offset_0", "offset_1",
+                          "dist_search", "azim_num", "hori_acc", "ray_algorithm", "geom_type", "vert_simp",
+                          "num_vert_simp", "tri_ind_simp", "num_tri_simp", "elev_ang_low_lim", "mask",
+                          "hori_fill", "ray_org_elev"]                      # horizon.pyx:29-49
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert (d["azim_num"], d["hori_acc"], d["ray_algorithm"], d["geom_type"]) == (360, 0.25, "guess_constant", "grid")
+    assert (d["num_vert_simp"], d["num_tri_simp"], d["elev_ang_low_lim"], d["mask"]) == (1, 1, -15.0, None)
+    assert (d["hori_fill"], d["ray_org_elev"]) == (0.0, 0.01)
+    for extra in names[20:]:
+        assert sig.parameters[extra].kind is inspect.Parameter.KEYWORD_ONLY
+    sig = inspect.signature(horayzon_amd.shadow.Terrain.initialise)
+    assert [p for p in sig.parameters][1:15] == [
+        "vert_grid", "dem_dim_0", "dem_dim_1", "offset_0", "offset_1", "vec_tilt", "vec_norm", "surf_enl_fac",
+        "elevation", "mask", "geom_type", "sw_dir_cor_fill", "ang_max", "refrac_cor"]   # shadow.pyx:27-38
+    d = {k: v.default for k, v in sig.parameters.items()}
+    assert d["geom_type"] == "grid" and d["ang_max"] == 89.0 and d["refrac_cor"] is False and np.isnan(d["sw_dir_cor_fill"])
+
+
+def test_horizon_validation_errors():
+    """Exception classes and order of horizon.pyx:109-153 (raised before any device work)."""
+    g = cases.rough_terrain(20, 24, seed=2, offset=3)
+    kw = cases.grid_kwargs(g)
+    f = horayzon_amd.horizon.horizon_gridded
+
+    def call(**over):
+        a = dict(kw, dist_search=1.0, azim_num=8)
+        a.update(over)
+        return f(**a)
+    with pytest.raises(ValueError, match="vert_grid"):
+        call(vert_grid=kw["vert_grid"][:100])
+    with pytest.raises(ValueError, match="offset_0"):
+        call(offset_0=10)
+    with pytest.raises(ValueError, match="vec_norm and/or vec_north"):
+        call(vec_north=kw["vec_north"][:, :-1])
+    with pytest.raises(ValueError, match="ray_algorithm"):
+        call(ray_algorithm="fast")
+    with pytest.raises(ValueError, match="geom_type"):
+        call(geom_type="mesh")
+    with pytest.raises(ValueError, match="vert_simp"):
+        call(num_vert_simp=5)
+    with pytest.raises(ValueError, match="tri_ind_simp"):
+        call(num_tri_simp=9)
+    with pytest.raises(ValueError, match="exceed"):
+        call(tri_ind_simp=np.array([0, 1, 2, 0], np.int32))
+    with pytest.raises(ValueError, match="hori_acc"):
+        call(hori_acc=11.0)
+    with pytest.raises(ValueError, match="mask"):
+        call(mask=np.ones((3, 3), np.uint8))
+    with pytest.raises(TypeError, match="uint8"):
+        call(mask=np.ones(kw["vec_norm"].shape[:2], np.int32))
+    with pytest.raises(TypeError, match="ray_org_elev"):
+        call(ray_org_elev=0.001)
+    with pytest.raises(ValueError, match="dtype mismatch"):
+        call(vert_grid=kw["vert_grid"].astype(np.float64))
+    with pytest.raises(ValueError, match="dimensions"):
+        call(vec_norm=kw["vec_norm"][0])
+
+
+def test_terrain_validation_errors(monkeypatch):
+    """shadow.pyx:87-133; the handle is never touched because validation raises first."""
+    g = cases.rough_terrain(20, 24, seed=2, offset=3)
+    vec_tilt, vec_norm, enl, elev, mask = cases.terrain_inputs(g)
+    T = horayzon_amd.shadow.Terrain
+    t = T.__new__(T)            # no device needed for the validation layer
+    t._h = None; t._shape = None
+
+    def init(**over):
+        a = dict(vert_grid=g["vert_grid"], dem_dim_0=20, dem_dim_1=24, offset_0=3, offset_1=3, vec_tilt=vec_tilt,
+                 vec_norm=vec_norm, surf_enl_fac=enl, elevation=elev, mask=mask)
+        a.update(over)
+        return t.initialise(**a)
+    with pytest.raises(ValueError, match="vert_grid"):
+        init(vert_grid=g["vert_grid"][:50])
+    with pytest.raises(ValueError, match="offset_1"):
+        init(offset_1=20)
+    with pytest.raises(ValueError, match="vec_tilt"):
+        init(vec_norm=vec_norm[:, :-1])
+    with pytest.raises(ValueError, match="surf_enl_fac"):
+        init(elevation=elev[:-1])
+    with pytest.raises(ValueError, match="C-contiguous"):
+        init(surf_enl_fac=np.asfortranarray(enl))
+    with pytest.raises(ValueError, match="normalised"):
+        init(vec_tilt=(vec_tilt * np.float32(1.01)))
+    with pytest.raises(ValueError, match="geom_type"):
+        init(geom_type="x")
+    with pytest.raises(TypeError, match="ang_max"):
+        init(ang_max=80.0)
+    with pytest.raises(ValueError, match="dtype mismatch"):
+        init(mask=mask.astype(np.int32))
+    t._shape = mask.shape
+    with pytest.raises(ValueError, match="sun_position"):
+        t.shadow(np.zeros(4, np.float32), np.zeros(mask.shape, np.uint8))
+    with pytest.raises(ValueError, match="C-contiguous"):
+        t.sw_dir_cor(np.zeros(3, np.float32), np.asfortranarray(np.zeros(mask.shape, np.float32)))
+
+
+def test_svf_validation_errors():
+    f = horayzon_amd.topo_param.sky_view_factor
+    azim = np.zeros(4, np.float32); hori = np.zeros((2, 2, 4), np.float32); tilt = np.ones((2, 2, 3), np.float32)
+    with pytest.raises(ValueError, match="shapes"):
+        f(azim[:3], hori, tilt)
+    with pytest.raises(ValueError, match="data type"):
+        f(azim, hori.astype(np.float64), tilt)
+
+
+def test_pack_vertices_layout():
+    """vert_grid layout defined by reference auxiliary.py:49-95: interleaved xyz, row-major,
+    >= 16 trailing zeros, byte size divisible by 16."""
+    x = np.arange(6, dtype=np.float32).reshape(2, 3)
+    buf = synth.pack_vertices(x, x + 10, x + 20)
+    assert buf.dtype == np.float32 and buf.ndim == 1 and buf.nbytes % 16 == 0 and buf.size >= 18 + 16
+    assert np.array_equal(buf[:6], [0, 10, 20, 1, 11, 21]) and np.all(buf[18:] == 0)
+
+
+def test_row_slabs_balanced():
+    from horayzon_amd.dist import row_slabs
+    m = np.ones((100, 7), np.uint8); m[:50] = 0
+    s = row_slabs(m, 4)
+    assert s[0][0] == 0 and s[-1][1] == 100 and all(a[1] == b[0] for a, b in zip(s, s[1:]))
+    cnt = [int((m[b:e] == 1).sum()) for b, e in s]
+    assert max(cnt) - min(cnt) <= 7
+    assert row_slabs(3, 8)[-1][1] == 3

@@ -56,6 +56,20 @@ def test_large_coordinates(hip, orc):
     _compare(hip, orc, cases.grid_kwargs(g), dist_search=1.5, azim_num=30, elev_ang_low_lim=-70.0)
 
 
+def test_curved_dem_reference_fixture(hip, orc):
+    """ENU geometry and per-cell frames produced by the reference's own transform/direction
+    modules (tests/golden/curved_dem_reference.npz)."""
+    import os
+    from horayzon_amd import synth
+    d = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "curved_dem_reference.npz"))
+    off = int(d["offset"])
+    n0, n1 = d["x_enu"].shape
+    kw = dict(vert_grid=synth.pack_vertices(d["x_enu"], d["y_enu"], d["z_enu"]), dem_dim_0=n0, dem_dim_1=n1,
+              vec_norm=d["vec_norm"], vec_north=d["vec_north"], offset_0=off, offset_1=off)
+    for alg in ALGS:
+        _compare(hip, orc, kw, dist_search=3.0, azim_num=18, elev_ang_low_lim=-89.98, ray_algorithm=alg)
+
+
 def test_mask_and_fill(hip, orc):
     g = cases.rough_terrain(70, 70, seed=3, offset=5)
     kw = cases.grid_kwargs(g)

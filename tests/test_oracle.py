@@ -1,0 +1,221 @@
+"""CPU tests of the oracle (oracle/hz_oracle.c): golden vectors generated from the
+reference's importable modules, analytic known answers, and agreement of the oracle's
+three intersection paths.  These pin the checker the GPU parity tests rely on."""
+import os
+
+import numpy as np
+import pytest
+
+from horayzon_amd import synth
+from tests import cases
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ---------------------------------------------------------------------------------------
+# golden vectors from the reference (topo_param.sky_view_factor, tests/golden/make_fixtures.py)
+# ---------------------------------------------------------------------------------------
+def test_svf_golden_reference(orc):
+    d = np.load(os.path.join(GOLD, "svf_reference.npz"))
+    for n in "abc":
+        svf = orc.sky_view_factor(d["azim_" + n], d["hori_" + n], d["tilt_" + n])
+        assert np.abs(svf - d["svf_" + n]).max() <= 1.0e-5, n     # north-star SVF tolerance
+    azim = d["azim_a"]
+    flat = np.zeros((2, 2, 36), np.float32)
+    up = np.zeros((2, 2, 3), np.float32); up[..., 2] = 1.0
+    assert np.abs(orc.sky_view_factor(azim, flat, up) - d["svf_flat"]).max() <= 1e-6
+    assert np.abs(d["svf_flat"] - 1.0).max() <= 1e-6              # closed form
+    h30 = flat + np.float32(np.deg2rad(30.0))
+    assert np.abs(orc.sky_view_factor(azim, h30, up) - d["svf_30deg"]).max() <= 1e-6
+    assert np.abs(d["svf_30deg"] - 0.75).max() <= 1e-6            # cos^2(30 deg)
+
+
+def test_svf_argument_checks(orc):
+    azim = np.zeros(4, np.float32); hori = np.zeros((2, 2, 4), np.float32); tilt = np.zeros((2, 2, 3), np.float32)
+    with pytest.raises(ValueError):
+        orc.sky_view_factor(azim[:3], hori, tilt)
+    with pytest.raises(ValueError):
+        orc.sky_view_factor(azim.astype(np.float64), hori, tilt)
+
+
+# ---------------------------------------------------------------------------------------
+# analytic known answers
+# ---------------------------------------------------------------------------------------
+def _flat(n=41, dx=25.0, off=8):
+    x = (np.arange(n) * dx).astype(np.float32)
+    xx, yy = np.meshgrid(x, x)
+    z = np.zeros_like(xx)
+    vn, vo = synth.planar_frames(n - 2 * off, n - 2 * off)
+    return dict(vert_grid=synth.pack_vertices(xx, yy, z), dem_dim_0=n, dem_dim_1=n, vec_norm=vn,
+                vec_north=vo, offset_0=off, offset_1=off), x, z
+
+
+@pytest.mark.parametrize("alg", ("binary_search", "guess_constant", "discrete_sampling"))
+def test_flat_plane(orc, alg):
+    """Flat plane: every ray below 0 deg hits within the DEM, every ray above misses ->
+    the horizon sits in the bracket just below 0."""
+    kw, _, _ = _flat()
+    acc = np.deg2rad(0.25)
+    h, azim, st = orc.horizon_gridded(**kw, dist_search=5.0, azim_num=24, ray_algorithm=alg,
+                                      elev_ang_low_lim=-60.0, return_stats=True)
+    assert st["guards"] == 0
+    assert (h <= acc + 1e-6).all() and (h >= -2.0 * acc - 1e-6).all()   # bracket midpoint around 0
+    assert np.allclose(azim, np.float32(2 * np.pi / 24) * np.arange(24), atol=1e-6)
+
+
+def test_wall_known_angle(orc):
+    """A ridge of height H at distance D north of a cell: horizon(azimuth 0) = atan((H - e) / D)."""
+    n, dx, off = 61, 20.0, 10
+    x = (np.arange(n) * dx).astype(np.float32)
+    y = ((n - 1 - np.arange(n)) * dx).astype(np.float32)       # row 0 is the northern edge
+    xx, yy = np.meshgrid(x, y)
+    z = np.zeros_like(xx)
+    H = 300.0
+    z[5, :] = H                                                 # east-west ridge
+    vn, vo = synth.planar_frames(n - 2 * off, n - 2 * off)
+    kw = dict(vert_grid=synth.pack_vertices(xx, yy, z), dem_dim_0=n, dem_dim_1=n, vec_norm=vn,
+              vec_north=vo, offset_0=off, offset_1=off)
+    acc_deg = 0.25
+    h, _ = orc.horizon_gridded(**kw, dist_search=5.0, azim_num=4, ray_algorithm="binary_search",
+                               hori_acc=acc_deg, elev_ang_low_lim=-30.0)
+    for i_in in (0, 10, 25):
+        D = (i_in + off - 5) * dx
+        expect = np.arctan((H - 0.01) / D)
+        assert abs(h[i_in, 20, 0] - expect) <= np.deg2rad(acc_deg) + 1e-6
+    # looking south / east / west only the flat plane is visible
+    assert (np.abs(h[:, 10:30, 2]) <= np.deg2rad(acc_deg) + 1e-6).all()
+
+
+def test_gaussian_hill_symmetry_and_algorithms(orc):
+    """180-degree rotational symmetry of the mesh (the quad diagonal keeps its orientation
+    under a half turn) and agreement of the three search algorithms within their accuracy."""
+    g = cases.c2_hill()
+    kw = cases.grid_kwargs(g)
+    acc = np.deg2rad(0.25)
+    res = {}
+    for alg in ("guess_constant", "binary_search"):
+        res[alg], _, st = orc.horizon_gridded(**kw, dist_search=10.0, azim_num=36, ray_algorithm=alg,
+                                              return_stats=True)
+        assert st["guards"] == 0
+    hb = res["binary_search"]
+    rot = np.roll(hb[::-1, ::-1, :], 18, axis=2)                # (i, j, k) -> (N-1-i, N-1-j, k + 18)
+    assert np.abs(hb - rot).max() <= 2.0 * acc
+    assert (np.abs(hb - rot) > 1e-6).mean() < 0.02
+    assert np.abs(res["guess_constant"] - hb).max() <= 2.5 * acc
+    # looking from the plain towards the hill: horizon close to the apparent summit angle
+    i, j = 90, 0                                                # inner cell west of the summit row
+    d = np.hypot(g["x"][j + 10] - g["x"].mean(), g["y"][i + 10] - g["y"].mean())
+    assert hb[i, j, 9] > 0.5 * np.arctan(1000.0 / d)            # azimuth 90 deg = east
+
+
+# ---------------------------------------------------------------------------------------
+# the three intersection paths agree
+# ---------------------------------------------------------------------------------------
+def test_bvh_equals_brute_force(orc):
+    g = cases.rough_terrain(40, 44, seed=5, offset=0, relief=600.0)
+    sc = orc.Scene(g["vert_grid"], 40, 44)
+    rng = np.random.default_rng(1)
+    nray = 60000
+    ci = rng.integers(0, 40, nray); cj = rng.integers(0, 44, nray)
+    org = np.stack([g["x"][cj], g["y"][ci], g["z"][ci, cj] + np.float32(0.01)], axis=1).astype(np.float32)
+    az = rng.uniform(0, 2 * np.pi, nray); el = np.deg2rad(rng.uniform(-30.0, 45.0, nray))
+    # include exactly axis-aligned and diagonal rays (they run along mesh edges)
+    az[:8000] = np.deg2rad(rng.choice([0.0, 45.0, 90.0, 135.0, 180.0, 225.0, 270.0, 315.0], 8000))
+    d = np.stack([np.cos(el) * np.sin(az), np.cos(el) * np.cos(az), np.sin(el)], axis=1).astype(np.float32)
+    tfar = np.where(rng.random(nray) < 0.3, np.inf, rng.uniform(50.0, 3000.0, nray)).astype(np.float32)
+    h_bvh = sc.occluded(org, d, tfar, orc.MODE_BVH)
+    h_brute = sc.occluded(org, d, tfar, orc.MODE_BRUTE)
+    h_f64 = sc.occluded(org, d, tfar, orc.MODE_BRUTE_F64)
+    assert np.array_equal(h_bvh, h_brute)          # the tree never changes a decision
+    assert 0.2 < h_brute.mean() < 0.95
+    assert (h_brute != h_f64).mean() < 2e-3         # float32 vs exact geometry: only grazing rays
+
+
+def test_horizon_bvh_equals_brute_force_and_tin(orc):
+    g = cases.rough_terrain(34, 38, seed=15, offset=3, relief=500.0)
+    kw = cases.grid_kwargs(g)
+    vs, nvs, ts, nts = cases.outer_tin(g, margin=1500.0, zval=500.0)
+    for extra in ({}, dict(vert_simp=vs, num_vert_simp=nvs, tri_ind_simp=ts, num_tri_simp=nts)):
+        a, _, sa = orc.horizon_gridded(**kw, dist_search=4.0, azim_num=16, elev_ang_low_lim=-50.0,
+                                       return_stats=True, **extra)
+        b, _, sb = orc.horizon_gridded(**kw, dist_search=4.0, azim_num=16, elev_ang_low_lim=-50.0,
+                                       mode=orc.MODE_BRUTE, return_stats=True, **extra)
+        assert np.array_equal(a, b) and sa["rays"] == sb["rays"]
+    # num_vert_simp < 3 -> the TIN is ignored (horizon_comp.cpp:199)
+    c, _ = orc.horizon_gridded(**kw, dist_search=4.0, azim_num=16, elev_ang_low_lim=-50.0,
+                               vert_simp=vs, num_vert_simp=2, tri_ind_simp=ts, num_tri_simp=nts)
+    d, _ = orc.horizon_gridded(**kw, dist_search=4.0, azim_num=16, elev_ang_low_lim=-50.0)
+    assert np.array_equal(c, d)
+
+
+def test_curved_dem_fixture(orc):
+    """ENU vertices / normals / north vectors produced by the REFERENCE's transform and
+    direction modules (tests/golden/make_fixtures.py): non axis-aligned frames."""
+    d = np.load(os.path.join(GOLD, "curved_dem_reference.npz"))
+    off = int(d["offset"])
+    n0, n1 = d["x_enu"].shape
+    kw = dict(vert_grid=synth.pack_vertices(d["x_enu"], d["y_enu"], d["z_enu"]), dem_dim_0=n0,
+              dem_dim_1=n1, vec_norm=d["vec_norm"], vec_north=d["vec_north"], offset_0=off, offset_1=off)
+    assert np.abs((d["vec_norm"] * d["vec_north"]).sum(axis=2)).max() < 1e-5     # orthogonal frames
+    h, _, st = orc.horizon_gridded(**kw, dist_search=3.0, azim_num=18, elev_ang_low_lim=-89.98,
+                                   return_stats=True)
+    b, _ = orc.horizon_gridded(**kw, dist_search=3.0, azim_num=18, elev_ang_low_lim=-89.98,
+                               mode=orc.MODE_BRUTE)
+    assert np.array_equal(h, b)
+    assert st["guards"] == 0 and not np.isnan(h).any()
+    assert -1.58 < h.min() and h.max() < 1.3
+
+
+# ---------------------------------------------------------------------------------------
+# shadow
+# ---------------------------------------------------------------------------------------
+def test_shadow_known_answers(orc):
+    g = cases.c2_hill(height=1500.0)
+    vec_tilt, vec_norm, enl, elev, mask = cases.terrain_inputs(g)
+    mask[0, :3] = 0
+    t = orc.Terrain()
+    t.initialise(g["vert_grid"], 200, 200, 10, 10, vec_tilt, vec_norm, enl, elev, mask, sw_dir_cor_fill=-1.0)
+    centre = np.array([4975.0, 4975.0, 0.0], np.float32)
+    sh = np.empty(mask.shape, np.uint8)
+    # sun at the zenith: nothing is shaded
+    t.shadow(centre + np.array([0, 0, 1.5e11], np.float32), sh)
+    assert np.all(sh[mask == 1] == 0) and np.all(sh[mask == 0] == 3)
+    # sun below the horizontal plane: every cell of the plain is self-shaded
+    t.shadow(centre + np.array([1e10, 0, -1e9], np.float32), sh)
+    plain = (vec_tilt[..., 2] > 0.99999) & (mask == 1)
+    assert plain.sum() > 1000 and np.all(sh[plain] == 1)
+    # low sun in the east: terrain shadow west of the hill, none on the sunlit plain east of it
+    t.shadow(centre + np.array([1.5e11, 0, 1.5e11 * np.tan(np.deg2rad(8.0))], np.float32), sh)
+    assert np.all(sh[85:95, 0:15] == 2)          # plain behind the hill: terrain shadow
+    assert np.all(sh[85:95, 30:80] == 1)         # west flank: tilted away from the sun
+    assert np.all(sh[85:95, 100:178] == 0)       # east flank and plain: lit
+    # sw_dir_cor: flat, lit cells have tilt == norm and enlargement 1 -> exactly 1
+    f = np.empty(mask.shape, np.float32)
+    t.sw_dir_cor(centre + np.array([1.5e11, 0, 1.5e11 * np.tan(np.deg2rad(40.0))], np.float32), f)
+    assert np.all(f[mask == 0] == -1.0)
+    assert np.abs(f[2:6, 150:175] - 1.0).max() < 1e-2 and f[90, 120] > 1.5 and f[90, 60] < 0.5
+    # refraction lifts the apparent sun: more (or equally many) lit cells than without it
+    tr = orc.Terrain()
+    tr.initialise(g["vert_grid"], 200, 200, 10, 10, vec_tilt, vec_norm, enl, elev, mask, refrac_cor=True)
+    sun = centre + np.array([1.5e11, 0, 1.5e11 * np.tan(np.deg2rad(3.0))], np.float32)
+    a = np.empty(mask.shape, np.uint8); b = a.copy()
+    t.shadow(sun, a); tr.shadow(sun, b)
+    assert (b == 0).sum() >= (a == 0).sum() and (a != b).any()
+
+
+def test_shadow_consistent_with_horizon(orc):
+    """A cell is terrain-shaded exactly when the sun is below its horizon at the sun's azimuth."""
+    g = cases.c2_hill(height=1500.0)
+    kw = cases.grid_kwargs(g)
+    vec_tilt, vec_norm, enl, elev, mask = cases.terrain_inputs(g)
+    h, azim = orc.horizon_gridded(**kw, dist_search=20.0, azim_num=36, ray_algorithm="binary_search",
+                                  hori_acc=0.1, elev_ang_low_lim=-25.0, ray_org_elev=0.05)
+    t = orc.Terrain()
+    t.initialise(g["vert_grid"], 200, 200, 10, 10, vec_norm.copy(), vec_norm, enl, elev, mask)
+    k, sun_el = 9, np.deg2rad(6.0)                              # azimuth 90 deg (east)
+    far = 1.0e9
+    sun = np.array([4975.0 + far * np.cos(sun_el), 4975.0, far * np.sin(sun_el)], np.float32)
+    sh = np.empty(mask.shape, np.uint8)
+    t.shadow(sun, sh)
+    clear = np.abs(h[:, :, k] - sun_el) > np.deg2rad(0.3)       # skip cells within the accuracy band
+    assert np.array_equal(sh[clear] == 2, h[:, :, k][clear] > sun_el)
