@@ -231,10 +231,31 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     if ((rc = d_es.bind(tb.elev_sin.data(), (size_t)tb.elev_num, st))) return rc;
     if ((rc = d_ec.bind(tb.elev_cos.data(), (size_t)tb.elev_num, st))) return rc;
     DevOut<float> d_hori, d_svf;
+    DevIn<float> d_azim;
+    const bool want_svf = opts && opts->svf;
     float *hori_slab_host = hori_buffer ? hori_buffer + (size_t)row_begin * dim_in_1 * azim_num : nullptr;
-    if (!skip_hori) if ((rc = d_hori.bind(hori_slab_host, slab_cells * (size_t)azim_num))) return rc;
-    float *svf_slab = (opts && opts->svf) ? opts->svf + (size_t)row_begin * dim_in_1 : nullptr;
+    float *svf_slab = want_svf ? opts->svf + (size_t)row_begin * dim_in_1 : nullptr;
     if ((rc = d_svf.bind(svf_slab, svf_slab ? slab_cells : 0))) return rc;
+    // rows per launch: the whole slab, unless only the SVF is wanted -- then the horizon of a
+    // chunk of rows lives in a bounded temporary (<= 2 GiB) that the SVF kernel consumes
+    int chunk_rows = row_end - row_begin;
+    void *tmp_hori = nullptr;
+    struct TmpFree { void **p; ~TmpFree() { if (*p) (void)hipFree(*p); } } tmp_free{&tmp_hori};
+    if (skip_hori) {
+        if (!want_svf) return set_error(HZ_ERR_ARG, "skip_hori without svf: nothing to compute");
+        const size_t row_bytes = (size_t)dim_in_1 * azim_num * 4;
+        chunk_rows = (int)std::max<size_t>(16, std::min<size_t>((size_t)chunk_rows, ((size_t)2 << 30) / row_bytes));
+        chunk_rows = std::min(chunk_rows, row_end - row_begin);
+        HZ_HIP(hipMalloc(&tmp_hori, (size_t)chunk_rows * row_bytes));
+    } else {
+        if ((rc = d_hori.bind(hori_slab_host, slab_cells * (size_t)azim_num))) return rc;
+    }
+    std::vector<float> azim_h;
+    if (want_svf) {   // azim as the wrapper recomputes it, horizon.pyx:191-195
+        azim_h.resize((size_t)azim_num);
+        for (int i = 0; i < azim_num; i++) azim_h[(size_t)i] = (float)(((2 * M_PI) / azim_num) * i);
+        if ((rc = d_azim.bind(azim_h.data(), (size_t)azim_num, st))) return rc;
+    }
     DevIn<unsigned long long> d_cnt;
     unsigned long long zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     void *cnt_dev = nullptr;
@@ -246,12 +267,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
 
     HorizonArgs a;
     a.vec_norm = d_norm.dev; a.vec_north = d_north.dev; a.mask = d_mask.dev;
-    // kernels index by global cell: shift slab-local buffers back by row_begin rows
-    a.hori = d_hori.dev ? d_hori.dev - (size_t)row_begin * dim_in_1 * azim_num : nullptr;
-    a.svf = d_svf.dev ? d_svf.dev - (size_t)row_begin * dim_in_1 : nullptr;
-    a.vec_tilt = d_tilt.dev;
     a.offset_0 = offset_0; a.offset_1 = offset_1; a.dim_in_0 = dim_in_0; a.dim_in_1 = dim_in_1;
-    a.row_begin = row_begin; a.row_end = row_end;
     a.azim_num = azim_num; a.elev_num = tb.elev_num; a.alg = alg;
     a.hori_acc = tb.hori_acc; a.low = tb.low; a.up = tb.up; a.dist = dist_m;
     a.hori_fill = hori_fill; a.ray_org_elev = ray_org_elev;
@@ -264,8 +280,18 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     hipEvent_t e0, e1;
     HZ_HIP(hipEventCreate(&e0)); HZ_HIP(hipEventCreate(&e1));
     HZ_HIP(hipEventRecord(e0, st));
-    rc = horizon_launch(sc, a, st);
-    if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+    for (int rb = row_begin; rb < row_end; rb += chunk_rows) {
+        const int re = std::min(rb + chunk_rows, row_end);
+        // the kernels index hori by global cell: shift the (slab- or chunk-local) buffer back
+        float *hori_chunk = skip_hori ? (float *)tmp_hori : d_hori.dev + (size_t)(rb - row_begin) * dim_in_1 * azim_num;
+        a.hori = hori_chunk - (size_t)rb * dim_in_1 * azim_num;
+        a.row_begin = rb; a.row_end = re;
+        rc = horizon_launch(sc, a, st);
+        if (!rc && want_svf)
+            rc = svf_launch(d_azim.dev, hori_chunk, d_tilt.dev + 3 * (size_t)rb * dim_in_1, re - rb, dim_in_1,
+                            azim_num, d_svf.dev + (size_t)(rb - row_begin) * dim_in_1, st);
+        if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+    }
     HZ_HIP(hipEventRecord(e1, st));
     HZ_HIP(hipEventSynchronize(e1));
     float ms = 0.0f;
@@ -284,6 +310,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     if (stats) {
         stats->num_rays += cnt[0]; stats->guard_events += cnt[1];
         stats->nodes_visited += cnt[2]; stats->tris_tested += cnt[3]; stats->num_cells += cnt[4];
+        stats->wave_node_iters += cnt[5]; stats->wave_leaf_iters += cnt[6]; stats->wave_refills += cnt[7];
         stats->t_h2d_s += h2d_s; stats->t_kernel_s += (double)ms * 1e-3; stats->t_d2h_s += d2h_s;
         stats->t_total_s += t_total.stop();
         stats->elev_num = tb.elev_num; stats->bvh_height = sc->hdr.height; stats->scene_bytes = sc->hdr.total_bytes;

@@ -140,4 +140,30 @@ __device__ __forceinline__ bool hz_box_hit(const RayBox &r, float tfar,
     return tmin <= tmax * 1.000001f;
 }
 
+// One 64 B node = 4 x 16 B global loads issued back to back and waited for once.
+// (hipcc was seen to put an s_waitcnt between the halves of the plain C++ form.)
+__device__ __forceinline__ void hz_load_node(const Node *n, float4 &n0, float4 &n1, float4 &n2, int2 &ch) {
+    float4 t3;
+    asm volatile("global_load_dwordx4 %0, %4, off\n\t"
+                 "global_load_dwordx4 %1, %4, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %4, off offset:32\n\t"
+                 "global_load_dwordx4 %3, %4, off offset:48\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(t3)
+                 : "v"(n)
+                 : "memory");
+    ch.x = __float_as_int(t3.x); ch.y = __float_as_int(t3.y);
+}
+
+// One 48 B leaf record = 3 x 16 B global loads, one wait.
+__device__ __forceinline__ void hz_load_prim(const Prim *q, float4 &q0, float4 &q1, float4 &q2) {
+    asm volatile("global_load_dwordx4 %0, %3, off\n\t"
+                 "global_load_dwordx4 %1, %3, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %3, off offset:32\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(q0), "=&v"(q1), "=&v"(q2)
+                 : "v"(q)
+                 : "memory");
+}
+
 #endif  // __HIPCC__

@@ -54,31 +54,12 @@ __device__ __forceinline__ float half_sum(float a, float b) {
     return (float)((double)(a + b) / 2.0);
 }
 
-// per-cell output sink: horizon array and/or fused sky view factor
+// per-cell output sink
 struct Sink {
-    float *hori;         // &hori_buffer[cell * azim_num] or null
-    bool svf_on;
-    float tx, ty, tz;    // tilted normal (svf)
-    float agg;           // svf accumulator (float32, topo_param.pyx:431)
+    float *hori;         // &hori_buffer[cell * azim_num]
 };
 
-// one term of _sky_view_factor_cy, topo_param.pyx:439-456 (float32 state, double trig)
-__device__ __forceinline__ void svf_accumulate(Sink &s, const Tables &t, int k, float h) {
-    // azim[k] as horizon.pyx:191-195 computes it; sin/cos in double, stored as float (topo_param.pyx:425-426)
-    const float azim = (float)(((2.0 * 3.14159265358979323846) / (double)t.azim_num) * (double)k);
-    const float as = (float)sin((double)azim), ac = (float)cos((double)azim);
-    const float hori_plane = (float)atan((double)(-as * s.tx / s.tz - ac * s.ty / s.tz));
-    const float he = (h >= hori_plane) ? h : hori_plane;
-    const double ce = cos((double)he);
-    s.agg = (float)((double)s.agg + ((double)(s.tx * as + s.ty * ac)
-                    * ((3.14159265358979323846 / 2.0) - (double)he - (sin(2.0 * (double)he) / 2.0))
-                    + (double)s.tz * (ce * ce)));
-}
-
-__device__ __forceinline__ void emit(Sink &s, const Tables &t, int k, float h) {
-    if (s.hori) s.hori[k] = h;
-    if (s.svf_on) svf_accumulate(s, t, k, h);
-}
+__device__ __forceinline__ void emit(Sink &s, const Tables &, int k, float h) { s.hori[k] = h; }
 
 // Consume the result of the previous ray (if any) and produce the next sample.
 // Returns true with s.ind / s.k identifying the next ray, false when the cell is finished.
@@ -169,30 +150,31 @@ __device__ __forceinline__ bool advance(Search &s, bool hit, const Tables &t, Si
 struct HorizonParams {
     SceneView sv;
     Tables tb;
-    const float *vec_norm, *vec_north, *vec_tilt;
+    const float *vec_norm, *vec_north;
     const uint8_t *mask;
-    float *hori, *svf;
+    float *hori;
     int offset_0, offset_1, dim_in_1;
     int row_begin, row_end;
     int tiles_j, n_tiles, chunk;   // tile grid of the slab; chunk = ceil(n_tiles / 8)
     float dist, hori_fill, ray_org_elev;
-    int top_nodes, regroup;
+    int top_nodes, regroup, stack_bytes;
     unsigned long long *counters;
 };
 
-template <int ALG, int STACK, bool COUNT>
+// LDS: [ per-lane stacks int[depth][256] | top-of-tree nodelet Node[top_nodes] ]
+template <int ALG, bool COUNT>
 __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int *stack = reinterpret_cast<int *>(smem);                                  // [STACK][256]
-    const float4 *top = reinterpret_cast<const float4 *>(smem + STACK * HZ_TPB * 4);
+    int *stack = reinterpret_cast<int *>(smem);
+    const float4 *top = reinterpret_cast<const float4 *>(smem + p.stack_bytes);
     const int tid = threadIdx.x;
     const int ntop = p.top_nodes;
-    {   // stage the breadth-first top of the tree in LDS (coalesced 16 B per lane)
-        float4 *dst = reinterpret_cast<float4 *>(smem + STACK * HZ_TPB * 4);
+    if (ntop > 0) {   // stage the breadth-first top of the tree in LDS (coalesced 16 B per lane)
+        float4 *dst = reinterpret_cast<float4 *>(smem + p.stack_bytes);
         const float4 *src = reinterpret_cast<const float4 *>(p.sv.nodes);
         for (int i = tid; i < ntop * 4; i += HZ_TPB) dst[i] = src[i];
+        __syncthreads();
     }
-    __syncthreads();
 
     // XCD-aware block -> tile mapping: block b runs on XCD b % 8; give XCD x the tile band [x*chunk, (x+1)*chunk)
     const int b = blockIdx.x;
@@ -207,17 +189,12 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
     const size_t cell = in_dom ? ((size_t)i * p.dim_in_1 + j) : 0;
     bool done = !in_dom;
     Sink out;
-    out.hori = (p.hori && in_dom) ? p.hori + cell * (size_t)t.azim_num : nullptr;
-    out.svf_on = (p.svf != nullptr) && in_dom;
-    out.agg = 0.0f; out.tx = 0.0f; out.ty = 0.0f; out.tz = 1.0f;
-    if (out.svf_on) {
-        out.tx = p.vec_tilt[3 * cell]; out.ty = p.vec_tilt[3 * cell + 1]; out.tz = p.vec_tilt[3 * cell + 2];
-    }
+    out.hori = p.hori + cell * (size_t)t.azim_num;
     float ox = 0, oy = 0, oz = 0;
     float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
     if (in_dom) {
         if (p.mask[cell] != 1) {                              // horizon_comp.cpp:789-794
-            for (int k = 0; k < t.azim_num; k++) emit(out, t, k, p.hori_fill);
+            for (int k = 0; k < t.azim_num; k++) out.hori[k] = p.hori_fill;
             done = true;
         } else {                                              // :751-779
             const float norm_x = p.vec_norm[3 * cell], norm_y = p.vec_norm[3 * cell + 1], norm_z = p.vec_norm[3 * cell + 2];
@@ -241,14 +218,20 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
     s.k = 0; s.phase = PH_NEWAZ; s.ind = 0; s.prev = 0; s.pazim = 0; s.count = 0;
     s.lim_up = 0; s.lim_low = 0; s.elev_samp = 0;
     unsigned rays = 0, guards = 0, nodes_cnt = 0, tris_cnt = 0;
+    unsigned w_nodes = 0, w_leaves = 0, w_adv = 0;   // wave-level section executions (COUNT only)
     const unsigned cells_cnt = (in_dom && !done) ? 1u : 0u;
     bool ray_active = false, last_hit = false;
     float dx = 0, dy = 0, dz = 1;
     RayBox rb = hz_raybox(0, 0, 0, 0, 0, 1);
-    int node = HZ_EMPTY, sp = 0;
+    int node = HZ_EMPTY, leaf = HZ_EMPTY, sp = 0;
+
+#define HZ_POP() do { if (sp > 0) { sp--; node = stack[sp * HZ_TPB + tid]; } else node = HZ_EMPTY; } while (0)
+#define HZ_WAVE_TICK(c) do { const unsigned long long m_ = __ballot(1); if (lane == __ffsll((long long)m_) - 1) (c)++; } while (0)
 
     while (__ballot(!done) != 0ull) {
+        // ---- refill: lanes without a ray take the next sample of their search -----------------
         if (!done && !ray_active) {
+            if (COUNT) HZ_WAVE_TICK(w_adv);
             if (advance<ALG>(s, last_hit, t, out, guards)) {
                 // local direction (east, north, up) and rotation: horizon_comp.cpp:357-361, :55-62
                 const float ec = t.elev_cos[s.ind], es = t.elev_sin[s.ind];
@@ -257,28 +240,30 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
                 dy = (r10 * rx + r11 * ry) + r12 * rz;
                 dz = (r20 * rx + r21 * ry) + r22 * rz;
                 rb = hz_raybox(ocx, ocy, ocz, dx, dy, dz);
-                node = 0; sp = 0;
+                node = 0; sp = 0; leaf = HZ_EMPTY;
                 ray_active = true;
                 rays++;
             } else {
                 done = true;
             }
         }
+        // ---- traversal: speculative while-while with one postponed leaf per lane ---------------
         if (ray_active) {
             for (;;) {
-                // ---- inner nodes: descend until a leaf (or the stack runs dry) -------------
+                // inner nodes.  A lane that reaches its first leaf postpones it and keeps descending
+                // while any other lane of the wave still has no leaf (keeps the node step full).
                 while (node >= 0) {
                     float4 n0, n1, n2; int2 ch;
-                    if (node < ntop) {
+                    // top-of-tree nodelet: taken from LDS only when the whole wave is inside it
+                    // (a per-lane LDS/global select would turn into slow flat loads)
+                    if (ntop > 0 && __all(node < ntop)) {
                         const float4 *q = top + 4 * node;
                         n0 = q[0]; n1 = q[1]; n2 = q[2];
                         ch = *reinterpret_cast<const int2 *>(q + 3);
                     } else {
-                        const float4 *q = reinterpret_cast<const float4 *>(p.sv.nodes + node);
-                        n0 = q[0]; n1 = q[1]; n2 = q[2];
-                        ch = *reinterpret_cast<const int2 *>(q + 3);
+                        hz_load_node(p.sv.nodes + node, n0, n1, n2, ch);
                     }
-                    if (COUNT) nodes_cnt++;
+                    if (COUNT) { nodes_cnt++; HZ_WAVE_TICK(w_nodes); }
                     float ta, tb;
                     const bool ha = hz_box_hit(rb, tfar, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, &ta);
                     const bool hb = hz_box_hit(rb, tfar, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, &tb);
@@ -291,74 +276,74 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
                         node = ch.x;
                     } else if (hb) {
                         node = ch.y;
-                    } else if (sp > 0) {
-                        sp--; node = stack[sp * HZ_TPB + tid];
                     } else {
-                        node = HZ_EMPTY;
+                        HZ_POP();
                     }
+                    if (node < 0 && node != HZ_EMPTY && leaf == HZ_EMPTY) {   // postpone the first leaf
+                        leaf = node;
+                        HZ_POP();
+                    }
+                    if (!__any(leaf == HZ_EMPTY)) break;      // every lane in the loop holds a leaf
                 }
-                if (node == HZ_EMPTY) { ray_active = false; last_hit = false; break; }
-                // ---- leaf: the two triangles of a DEM quad (or one TIN triangle) ------------
-                {
-                    const float4 *q = reinterpret_cast<const float4 *>(p.sv.prims + (~node));
-                    const float4 q0 = q[0], q1 = q[1], q2 = q[2];
+                // leaves: the two triangles of a DEM quad (or one TIN triangle); consecutive leaves chain
+                bool hit = false;
+                while (leaf != HZ_EMPTY) {
+                    float4 q0, q1, q2;
+                    hz_load_prim(p.sv.prims + (~leaf), q0, q1, q2);
                     // a = (q0.x q0.y q0.z) b = (q0.w q1.x q1.y) c = (q1.z q1.w q2.x) d = (q2.y q2.z q2.w)
-                    if (COUNT) tris_cnt += (q2.y == q2.y) ? 2 : 1;
-                    bool h = hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y,
-                                        q1.z, q1.w, q2.x);
-                    if (!h && (q2.y == q2.y))
-                        h = hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, q0.w, q1.x, q1.y, q2.y, q2.z, q2.w,
-                                       q1.z, q1.w, q2.x);
-                    if (h) { ray_active = false; last_hit = true; break; }
+                    if (COUNT) { tris_cnt += (q2.y == q2.y) ? 2 : 1; HZ_WAVE_TICK(w_leaves); }
+                    hit = hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y,
+                                     q1.z, q1.w, q2.x);
+                    if (!hit && (q2.y == q2.y))
+                        hit = hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, q0.w, q1.x, q1.y, q2.y, q2.z, q2.w,
+                                         q1.z, q1.w, q2.x);
+                    if (hit) break;
+                    leaf = HZ_EMPTY;
+                    if (node < 0 && node != HZ_EMPTY) { leaf = node; HZ_POP(); }
                 }
-                if (sp > 0) { sp--; node = stack[sp * HZ_TPB + tid]; }
-                else { ray_active = false; last_hit = false; break; }
+                if (hit) { ray_active = false; last_hit = true; break; }
+                if (node == HZ_EMPTY) { ray_active = false; last_hit = false; break; }
                 // ---- ray compaction: too few lanes left in this loop -> let the others refill
                 if (__popcll(__ballot(1)) < p.regroup) break;
             }
         }
     }
-
-    if (out.svf_on)   // topo_param.pyx:458: (azim_spac / (2 pi)) * agg, azim_spac = azim[1] - azim[0]
-        p.svf[cell] = (float)(((double)(float)((2.0 * 3.14159265358979323846) / (double)t.azim_num)
-                               / (2.0 * 3.14159265358979323846)) * (double)out.agg);
+#undef HZ_POP
 
     // one atomic per wave and counter
     unsigned long long r = rays, g = guards, nc = nodes_cnt, tc = tris_cnt, cc = cells_cnt;
+    unsigned long long wn = w_nodes, wl = w_leaves, wa = w_adv;
     for (int off = 32; off > 0; off >>= 1) {
         r += __shfl_xor(r, off); g += __shfl_xor(g, off); cc += __shfl_xor(cc, off);
-        if (COUNT) { nc += __shfl_xor(nc, off); tc += __shfl_xor(tc, off); }
+        if (COUNT) {
+            nc += __shfl_xor(nc, off); tc += __shfl_xor(tc, off);
+            wn += __shfl_xor(wn, off); wl += __shfl_xor(wl, off); wa += __shfl_xor(wa, off);
+        }
     }
     if (lane == 0) {
         if (r) atomicAdd(&p.counters[0], r);
         if (g) atomicAdd(&p.counters[1], g);
         if (cc) atomicAdd(&p.counters[4], cc);
-        if (COUNT) { atomicAdd(&p.counters[2], nc); atomicAdd(&p.counters[3], tc); }
+        if (COUNT) {
+            atomicAdd(&p.counters[2], nc); atomicAdd(&p.counters[3], tc);
+            atomicAdd(&p.counters[5], wn); atomicAdd(&p.counters[6], wl); atomicAdd(&p.counters[7], wa);
+        }
     }
 }
 
-template <int ALG, int STACK>
+template <int ALG>
 static int launch_alg(const HorizonParams &p, int grid, size_t lds, bool count, hipStream_t st) {
     if (count) {
-        HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_horizon<ALG, STACK, true>),
+        HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_horizon<ALG, true>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_horizon<ALG, STACK, true>), dim3(grid), dim3(HZ_TPB), lds, st, p);
+        hipLaunchKernelGGL((k_horizon<ALG, true>), dim3(grid), dim3(HZ_TPB), lds, st, p);
     } else {
-        HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_horizon<ALG, STACK, false>),
+        HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_horizon<ALG, false>),
                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_horizon<ALG, STACK, false>), dim3(grid), dim3(HZ_TPB), lds, st, p);
+        hipLaunchKernelGGL((k_horizon<ALG, false>), dim3(grid), dim3(HZ_TPB), lds, st, p);
     }
     HZ_HIP(hipGetLastError());
     return HZ_OK;
-}
-
-template <int STACK>
-static int launch_stack(const HorizonParams &p, int alg, int grid, size_t lds, bool count, hipStream_t st) {
-    switch (alg) {
-        case ALG_DISCRETE: return launch_alg<ALG_DISCRETE, STACK>(p, grid, lds, count, st);
-        case ALG_BINARY: return launch_alg<ALG_BINARY, STACK>(p, grid, lds, count, st);
-        default: return launch_alg<ALG_GUESS, STACK>(p, grid, lds, count, st);
-    }
 }
 
 int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
@@ -369,8 +354,8 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
     p.tb.azim_num = a.azim_num; p.tb.elev_num = a.elev_num;
     p.tb.hori_acc = a.hori_acc; p.tb.low = a.low; p.tb.up = a.up;
     p.tb.step = (double)a.hori_acc / 5.0;
-    p.vec_norm = a.vec_norm; p.vec_north = a.vec_north; p.vec_tilt = a.vec_tilt;
-    p.mask = a.mask; p.hori = a.hori; p.svf = a.svf;
+    p.vec_norm = a.vec_norm; p.vec_north = a.vec_north;
+    p.mask = a.mask; p.hori = a.hori;
     p.offset_0 = a.offset_0; p.offset_1 = a.offset_1; p.dim_in_1 = a.dim_in_1;
     p.row_begin = a.row_begin; p.row_end = a.row_end;
     const int rows = a.row_end - a.row_begin;
@@ -380,17 +365,22 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
     p.n_tiles = tiles_i * p.tiles_j;
     p.chunk = (p.n_tiles + 7) / 8;
     p.dist = a.dist; p.hori_fill = a.hori_fill; p.ray_org_elev = a.ray_org_elev;
-    const int height = sc->hdr.height;
-    const int stack = (height <= 32) ? 32 : 64;
+    // stack: one entry per tree level is enough (only the far child of a level is ever pushed)
+    const int depth = std::max(sc->hdr.height, 1);
+    p.stack_bytes = depth * HZ_TPB * 4;
     int top = (a.top_nodes < 0) ? 127 : a.top_nodes;
     top = std::min(top, sc->hdr.n_top);
     p.top_nodes = top;
     p.regroup = (a.regroup < 0) ? 0 : std::min(a.regroup, 64);
     p.counters = a.counters;
-    const size_t lds = (size_t)stack * HZ_TPB * 4 + (size_t)top * sizeof(Node);
+    const size_t lds = (size_t)p.stack_bytes + (size_t)top * sizeof(Node);
     const int grid = p.chunk * 8;
-    if (stack == 32) return launch_stack<32>(p, a.alg, grid, lds, a.count_work != 0, st);
-    return launch_stack<64>(p, a.alg, grid, lds, a.count_work != 0, st);
+    const bool count = a.count_work != 0;
+    switch (a.alg) {
+        case ALG_DISCRETE: return launch_alg<ALG_DISCRETE>(p, grid, lds, count, st);
+        case ALG_BINARY: return launch_alg<ALG_BINARY>(p, grid, lds, count, st);
+        default: return launch_alg<ALG_GUESS>(p, grid, lds, count, st);
+    }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -72,7 +72,6 @@ struct HorizonArgs {
     const float *vec_norm, *vec_north;   // device
     const uint8_t *mask;                 // device
     float *hori;                         // device, may be null (skip_hori)
-    float *svf; const float *vec_tilt;   // device, optional
     int offset_0, offset_1, dim_in_0, dim_in_1;
     int row_begin, row_end;
     int azim_num, elev_num, alg;

@@ -67,6 +67,9 @@ typedef struct hz_stats {
     int32_t bvh_height;
     int32_t elev_num;
     uint64_t scene_bytes;  /* HBM bytes of vertices + LBVH                     */
+    uint64_t wave_node_iters; /* count_work: wave-level executions of the node  */
+    uint64_t wave_leaf_iters; /*   step / leaf step / ray refill section (SIMT  */
+    uint64_t wave_refills;    /*   efficiency = lane count / (64 x wave count)) */
 } hz_stats;
 
 const char *hz_last_error(void);

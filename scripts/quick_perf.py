@@ -6,7 +6,8 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import horayzon_amd as hz
 from horayzon_amd import synth
 
@@ -17,6 +18,7 @@ ap.add_argument("--azim", type=int, default=360)
 ap.add_argument("--dist", type=float, default=50.0)
 ap.add_argument("--alg", default="guess_constant")
 ap.add_argument("--count", action="store_true")
+ap.add_argument("--count-all", action="store_true")
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--top", type=int, default=-1)
 ap.add_argument("--regroup", type=int, default=-1)
@@ -35,10 +37,14 @@ for rep in range(args.reps):
     t = time.time()
     hori, azim = hz.horizon.horizon_gridded(g["vert_grid"], n, n, vec_norm, vec_north, off, off,
                                             args.dist, azim_num=args.azim, ray_algorithm=args.alg,
-                                            scene=sc, _top_nodes=args.top, _regroup=args.regroup, count_work=args.count and rep == args.reps - 1)
+                                            scene=sc, _top_nodes=args.top, _regroup=args.regroup, count_work=args.count_all or (args.count and rep == args.reps - 1))
     st = hz.horizon.last_stats
     print("rep %d wall %.2fs kernel %.3fs rays %d rays/(cell*az) %.2f Mray/s %.1f cells/s %.0f nodes/ray %.1f tris/ray %.1f"
           % (rep, time.time() - t, st["t_kernel_s"], st["num_rays"], st["num_rays"] / (w * w * args.azim),
              st["num_rays"] / st["t_kernel_s"] / 1e6, w * w / st["t_kernel_s"],
              st["nodes_visited"] / max(st["num_rays"], 1), st["tris_tested"] / max(st["num_rays"], 1)), flush=True)
+if args.count:
+    print("SIMT efficiency: node step %.3f  leaf step %.3f  refill %.3f   (wave iters: node %.3g leaf %.3g refill %.3g)"
+          % (st["nodes_visited"] / max(64 * st["wave_node_iters"], 1), st["tris_tested"] / 2 / max(64 * st["wave_leaf_iters"], 1),
+             st["num_rays"] / max(64 * st["wave_refills"], 1), st["wave_node_iters"], st["wave_leaf_iters"], st["wave_refills"]))
 print("hori range deg", np.rad2deg(np.nanmin(hori)), np.rad2deg(np.nanmax(hori)))
