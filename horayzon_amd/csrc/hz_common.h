@@ -6,13 +6,18 @@
 //
 // vertices : the caller's vert_grid, untouched (ray origins read them;
 //            reference: shared vertex buffer, horizon_comp.cpp:126-127).
-// nodes    : flat LBVH, 64 B per internal node holding BOTH child AABBs, so one
-//            fetch decides both children.  The first `n_top` nodes are the top
-//            of the tree in breadth-first order (staged in LDS by the kernels).
-//            AABBs live in a frame centred on the scene (`center`) and are
-//            padded by `pad`, which makes the box test conservative with
-//            respect to the float32 triangle test: hit decisions depend on the
-//            triangle test only, never on the tree.
+// nodes    : flat LBVH collapsed to 4-wide nodes along the 2-bit digits of the
+//            Morton key (= a quadtree over the (x, y) centroids).  One node is
+//            64 B and holds the conservatively quantised AABBs (8 bit x/y,
+//            16 bit z, relative to the node's own box) and the links of up to 4
+//            children, stored in Morton-digit order (slot = 2*ybit + xbit), so
+//            a front-to-back order follows from the ray's direction signs.
+//            The first `n_top` nodes are the top of the tree in breadth-first
+//            order (staged in LDS by the kernels).  AABBs live in a frame
+//            centred on the scene (`center`) and are padded by `pad`, which
+//            makes the box test conservative with respect to the float32
+//            triangle test: hit decisions depend on the triangle test only,
+//            never on the tree.
 // prims    : one 48 B record per leaf in Morton order = the 4 corner vertices
 //            of a DEM quad (two triangles a,b,c / b,d,c -- the split of
 //            horizon_comp.cpp:139-151) or the 3 vertices of a TIN triangle
@@ -22,7 +27,7 @@
 #include <hip/hip_runtime.h>
 
 #define HZ_BLOB_MAGIC 0x485a4c42u /* "HZLB" */
-#define HZ_BLOB_VERSION 2u
+#define HZ_BLOB_VERSION 3u
 #define HZ_WAVE 64
 
 struct BlobHeader {
@@ -39,12 +44,14 @@ struct BlobHeader {
 };
 static_assert(sizeof(BlobHeader) == 256, "BlobHeader must be 256 bytes");
 
-// child >= 0: internal node index; child < 0: leaf, prim index = ~child
+// link >= 0: internal node index; link < 0: leaf, prim index = ~link; HZ_EMPTY: no child
+#define HZ_EMPTY ((int)0x80000000)
 struct __attribute__((aligned(64))) Node {
-    float lo0[3], hi0[3];
-    float lo1[3], hi1[3];
-    int32_t c0, c1;
-    int32_t pad_[2];
+    float org[3];        // lower corner of the node's box (centred frame)
+    uint32_t scale;      // biased float exponents of the x | y<<8 | z<<16 quantisation steps
+    uint32_t qxy[4];     // per child slot: xlo | xhi<<8 | ylo<<16 | yhi<<24   (8 bit, 0..255)
+    uint32_t qz[4];      // per child slot: zlo | zhi<<16                      (16 bit)
+    int32_t link[4];
 };
 static_assert(sizeof(Node) == 64, "Node must be 64 bytes");
 
@@ -111,6 +118,7 @@ __device__ __forceinline__ bool hz_tri_hit(float ox, float oy, float oz,
 struct RayBox {
     float rdx, rdy, rdz;     // 1 / d (clamped away from inf)
     float ordx, ordy, ordz;  // (o - center) * rd
+    int order;               // (dy < 0 ? 2 : 0) | (dx < 0 ? 1 : 0): slot visited r-th = r ^ order
 };
 
 __device__ __forceinline__ float hz_safe_rcp(float d) {
@@ -122,37 +130,50 @@ __device__ __forceinline__ RayBox hz_raybox(float ocx, float ocy, float ocz,
     RayBox r;
     r.rdx = hz_safe_rcp(dx); r.rdy = hz_safe_rcp(dy); r.rdz = hz_safe_rcp(dz);
     r.ordx = ocx * r.rdx; r.ordy = ocy * r.rdy; r.ordz = ocz * r.rdz;
+    r.order = ((dy < 0.0f) ? 2 : 0) | ((dx < 0.0f) ? 1 : 0);
     return r;
 }
 
-// entry distance in *tn; returns whether [0, tfar] overlaps the box
-__device__ __forceinline__ bool hz_box_hit(const RayBox &r, float tfar,
-                                           float lox, float loy, float loz,
-                                           float hix, float hiy, float hiz, float *tn) {
-    const float t0x = __builtin_fmaf(lox, r.rdx, -r.ordx), t1x = __builtin_fmaf(hix, r.rdx, -r.ordx);
-    const float t0y = __builtin_fmaf(loy, r.rdy, -r.ordy), t1y = __builtin_fmaf(hiy, r.rdy, -r.ordy);
-    const float t0z = __builtin_fmaf(loz, r.rdz, -r.ordz), t1z = __builtin_fmaf(hiz, r.rdz, -r.ordz);
+// per-node constants: t = q * a + b maps a quantised coordinate to a ray parameter
+struct NodeRay { float ax, bx, ay, by, az, bz; };
+
+__device__ __forceinline__ NodeRay hz_node_ray(const RayBox &r, float ox, float oy, float oz, uint32_t scale) {
+    NodeRay n;
+    const float sx = __uint_as_float((scale & 0xffu) << 23);
+    const float sy = __uint_as_float(((scale >> 8) & 0xffu) << 23);
+    const float sz = __uint_as_float(((scale >> 16) & 0xffu) << 23);
+    n.ax = sx * r.rdx; n.bx = __builtin_fmaf(ox, r.rdx, -r.ordx);
+    n.ay = sy * r.rdy; n.by = __builtin_fmaf(oy, r.rdy, -r.ordy);
+    n.az = sz * r.rdz; n.bz = __builtin_fmaf(oz, r.rdz, -r.ordz);
+    return n;
+}
+
+// does [0, tfar] overlap the quantised child box (qxy, qz)?
+__device__ __forceinline__ bool hz_qbox_hit(const NodeRay &n, float tfar, uint32_t qxy, uint32_t qz) {
+    const float xl = (float)(qxy & 0xffu), xh = (float)((qxy >> 8) & 0xffu);
+    const float yl = (float)((qxy >> 16) & 0xffu), yh = (float)(qxy >> 24);
+    const float zl = (float)(qz & 0xffffu), zh = (float)(qz >> 16);
+    const float t0x = __builtin_fmaf(xl, n.ax, n.bx), t1x = __builtin_fmaf(xh, n.ax, n.bx);
+    const float t0y = __builtin_fmaf(yl, n.ay, n.by), t1y = __builtin_fmaf(yh, n.ay, n.by);
+    const float t0z = __builtin_fmaf(zl, n.az, n.bz), t1z = __builtin_fmaf(zh, n.az, n.bz);
     const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
                                        __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
     const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
                                        __builtin_fminf(__builtin_fmaxf(t0z, t1z), tfar));
-    *tn = tmin;
     return tmin <= tmax * 1.000001f;
 }
 
 // One 64 B node = 4 x 16 B global loads issued back to back and waited for once.
 // (hipcc was seen to put an s_waitcnt between the halves of the plain C++ form.)
-__device__ __forceinline__ void hz_load_node(const Node *n, float4 &n0, float4 &n1, float4 &n2, int2 &ch) {
-    float4 t3;
+__device__ __forceinline__ void hz_load_node(const Node *n, float4 &n0, uint4 &n1, uint4 &n2, int4 &n3) {
     asm volatile("global_load_dwordx4 %0, %4, off\n\t"
                  "global_load_dwordx4 %1, %4, off offset:16\n\t"
                  "global_load_dwordx4 %2, %4, off offset:32\n\t"
                  "global_load_dwordx4 %3, %4, off offset:48\n\t"
                  "s_waitcnt vmcnt(0)"
-                 : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(t3)
+                 : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3)
                  : "v"(n)
                  : "memory");
-    ch.x = __float_as_int(t3.x); ch.y = __float_as_int(t3.y);
 }
 
 // One 48 B leaf record = 3 x 16 B global loads, one wait.
@@ -164,6 +185,90 @@ __device__ __forceinline__ void hz_load_prim(const Prim *q, float4 &q0, float4 &
                  : "=&v"(q0), "=&v"(q1), "=&v"(q2)
                  : "v"(q)
                  : "memory");
+}
+
+// ---------------------------------------------------------------------------
+// any-hit traversal of one ray, resumable.
+//   state   : node (current link), leaf (one postponed leaf), sp (stack pointer)
+//   stack   : per-lane LDS stack, entry k of lane tid at stack[k * TPB + tid]
+//   top     : LDS copy of the first ntop nodes (may be null / ntop = 0)
+//   regroup : leave when fewer than `regroup` lanes of the wave are still traversing
+// Speculative while-while: a lane that reaches its first leaf postpones it and keeps
+// descending while any other lane of the wave still has none (keeps the node step full).
+// returns 0 = miss, 1 = hit, 2 = suspended (state is valid, call again)
+// ---------------------------------------------------------------------------
+struct TravCounters { unsigned nodes, tris, w_nodes, w_leaves; };
+
+#define HZ_WAVE_TICK(c, lane_) do { const unsigned long long m_ = __ballot(1); if ((lane_) == __ffsll((long long)m_) - 1) (c)++; } while (0)
+
+template <int TPB, bool COUNT>
+__device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Prim *__restrict__ prims,
+                                        const float4 *top, int ntop, int *stack, int tid,
+                                        float ox, float oy, float oz, float dx, float dy, float dz, float tfar,
+                                        const RayBox &rb, int &node, int &leaf, int &sp, int regroup,
+                                        TravCounters &cnt) {
+    const int lane = tid & 63;
+#define HZ_POP() do { if (sp > 0) { sp--; node = stack[sp * TPB + tid]; } else node = HZ_EMPTY; } while (0)
+    for (;;) {
+        while (node >= 0) {
+            float4 n0; uint4 n1, n2; int4 n3;
+            if (ntop > 0 && __all(node < ntop)) {   // whole wave inside the LDS nodelet
+                const float4 *q = top + 4 * node;
+                n0 = q[0];
+                n1 = *reinterpret_cast<const uint4 *>(q + 1);
+                n2 = *reinterpret_cast<const uint4 *>(q + 2);
+                n3 = *reinterpret_cast<const int4 *>(q + 3);
+            } else {
+                hz_load_node(nodes + node, n0, n1, n2, n3);
+            }
+            if (COUNT) { cnt.nodes++; HZ_WAVE_TICK(cnt.w_nodes, lane); }
+            const NodeRay nr = hz_node_ray(rb, n0.x, n0.y, n0.z, __float_as_uint(n0.w));
+            const bool h0 = hz_qbox_hit(nr, tfar, n1.x, n2.x);
+            const bool h1 = hz_qbox_hit(nr, tfar, n1.y, n2.y);
+            const bool h2 = hz_qbox_hit(nr, tfar, n1.z, n2.z);
+            const bool h3 = hz_qbox_hit(nr, tfar, n1.w, n2.w);
+            // visit order: slot r ^ order for r = 0..3 (front to back in x / y); far ones are pushed first
+            const int o = rb.order;
+            const int l0 = (o == 0) ? n3.x : (o == 1) ? n3.y : (o == 2) ? n3.z : n3.w;
+            const int l1 = (o == 0) ? n3.y : (o == 1) ? n3.x : (o == 2) ? n3.w : n3.z;
+            const int l2 = (o == 0) ? n3.z : (o == 1) ? n3.w : (o == 2) ? n3.x : n3.y;
+            const int l3 = (o == 0) ? n3.w : (o == 1) ? n3.z : (o == 2) ? n3.y : n3.x;
+            const bool g0 = (o == 0) ? h0 : (o == 1) ? h1 : (o == 2) ? h2 : h3;
+            const bool g1 = (o == 0) ? h1 : (o == 1) ? h0 : (o == 2) ? h3 : h2;
+            const bool g2 = (o == 0) ? h2 : (o == 1) ? h3 : (o == 2) ? h0 : h1;
+            const bool g3 = (o == 0) ? h3 : (o == 1) ? h2 : (o == 2) ? h1 : h0;
+            int next = HZ_EMPTY;
+            // r = 3 .. 0: the last hit seen (smallest r) becomes `next`, the previous `next` is pushed
+            if (g3) next = l3;
+            if (g2) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = l2; }
+            if (g1) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = l1; }
+            if (g0) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = l0; }
+            if (next != HZ_EMPTY) node = next; else HZ_POP();
+            if (node < 0 && node != HZ_EMPTY && leaf == HZ_EMPTY) {   // postpone the first leaf
+                leaf = node;
+                HZ_POP();
+            }
+            if (!__any(leaf == HZ_EMPTY)) break;      // every lane in the loop holds a leaf
+        }
+        // leaves: the two triangles of a DEM quad (or one TIN triangle); consecutive leaves chain
+        bool hit = false;
+        while (leaf != HZ_EMPTY) {
+            float4 q0, q1, q2;
+            hz_load_prim(prims + (~leaf), q0, q1, q2);
+            // a = (q0.x q0.y q0.z) b = (q0.w q1.x q1.y) c = (q1.z q1.w q2.x) d = (q2.y q2.z q2.w)
+            if (COUNT) { cnt.tris += (q2.y == q2.y) ? 2 : 1; HZ_WAVE_TICK(cnt.w_leaves, lane); }
+            hit = hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x);
+            if (!hit && (q2.y == q2.y))
+                hit = hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, q0.w, q1.x, q1.y, q2.y, q2.z, q2.w, q1.z, q1.w, q2.x);
+            if (hit) break;
+            leaf = HZ_EMPTY;
+            if (node < 0 && node != HZ_EMPTY) { leaf = node; HZ_POP(); }
+        }
+        if (hit) return 1;
+        if (node == HZ_EMPTY) return 0;
+        if (__popcll(__ballot(1)) < regroup) return 2;   // ray compaction: let idle lanes refill
+    }
+#undef HZ_POP
 }
 
 #endif  // __HIPCC__

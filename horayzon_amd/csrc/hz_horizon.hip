@@ -27,7 +27,6 @@
 
 namespace hz {
 
-#define HZ_EMPTY ((int)0x80000000)
 #define HZ_TPB 256
 
 enum { ALG_DISCRETE = 0, ALG_BINARY = 1, ALG_GUESS = 2 };
@@ -217,21 +216,18 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
     Search s;
     s.k = 0; s.phase = PH_NEWAZ; s.ind = 0; s.prev = 0; s.pazim = 0; s.count = 0;
     s.lim_up = 0; s.lim_low = 0; s.elev_samp = 0;
-    unsigned rays = 0, guards = 0, nodes_cnt = 0, tris_cnt = 0;
-    unsigned w_nodes = 0, w_leaves = 0, w_adv = 0;   // wave-level section executions (COUNT only)
+    unsigned rays = 0, guards = 0, w_adv = 0;
+    TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.w_nodes = 0; tc.w_leaves = 0;   // COUNT only
     const unsigned cells_cnt = (in_dom && !done) ? 1u : 0u;
     bool ray_active = false, last_hit = false;
     float dx = 0, dy = 0, dz = 1;
     RayBox rb = hz_raybox(0, 0, 0, 0, 0, 1);
     int node = HZ_EMPTY, leaf = HZ_EMPTY, sp = 0;
 
-#define HZ_POP() do { if (sp > 0) { sp--; node = stack[sp * HZ_TPB + tid]; } else node = HZ_EMPTY; } while (0)
-#define HZ_WAVE_TICK(c) do { const unsigned long long m_ = __ballot(1); if (lane == __ffsll((long long)m_) - 1) (c)++; } while (0)
-
     while (__ballot(!done) != 0ull) {
         // ---- refill: lanes without a ray take the next sample of their search -----------------
         if (!done && !ray_active) {
-            if (COUNT) HZ_WAVE_TICK(w_adv);
+            if (COUNT) HZ_WAVE_TICK(w_adv, lane);
             if (advance<ALG>(s, last_hit, t, out, guards)) {
                 // local direction (east, north, up) and rotation: horizon_comp.cpp:357-361, :55-62
                 const float ec = t.elev_cos[s.ind], es = t.elev_sin[s.ind];
@@ -247,76 +243,21 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
                 done = true;
             }
         }
-        // ---- traversal: speculative while-while with one postponed leaf per lane ---------------
+        // ---- traversal (hz_common.h: speculative while-while, one postponed leaf per lane) ------
         if (ray_active) {
-            for (;;) {
-                // inner nodes.  A lane that reaches its first leaf postpones it and keeps descending
-                // while any other lane of the wave still has no leaf (keeps the node step full).
-                while (node >= 0) {
-                    float4 n0, n1, n2; int2 ch;
-                    // top-of-tree nodelet: taken from LDS only when the whole wave is inside it
-                    // (a per-lane LDS/global select would turn into slow flat loads)
-                    if (ntop > 0 && __all(node < ntop)) {
-                        const float4 *q = top + 4 * node;
-                        n0 = q[0]; n1 = q[1]; n2 = q[2];
-                        ch = *reinterpret_cast<const int2 *>(q + 3);
-                    } else {
-                        hz_load_node(p.sv.nodes + node, n0, n1, n2, ch);
-                    }
-                    if (COUNT) { nodes_cnt++; HZ_WAVE_TICK(w_nodes); }
-                    float ta, tb;
-                    const bool ha = hz_box_hit(rb, tfar, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, &ta);
-                    const bool hb = hz_box_hit(rb, tfar, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, &tb);
-                    if (ha && hb) {
-                        const bool sw = tb < ta;
-                        stack[sp * HZ_TPB + tid] = sw ? ch.x : ch.y;
-                        sp++;
-                        node = sw ? ch.y : ch.x;
-                    } else if (ha) {
-                        node = ch.x;
-                    } else if (hb) {
-                        node = ch.y;
-                    } else {
-                        HZ_POP();
-                    }
-                    if (node < 0 && node != HZ_EMPTY && leaf == HZ_EMPTY) {   // postpone the first leaf
-                        leaf = node;
-                        HZ_POP();
-                    }
-                    if (!__any(leaf == HZ_EMPTY)) break;      // every lane in the loop holds a leaf
-                }
-                // leaves: the two triangles of a DEM quad (or one TIN triangle); consecutive leaves chain
-                bool hit = false;
-                while (leaf != HZ_EMPTY) {
-                    float4 q0, q1, q2;
-                    hz_load_prim(p.sv.prims + (~leaf), q0, q1, q2);
-                    // a = (q0.x q0.y q0.z) b = (q0.w q1.x q1.y) c = (q1.z q1.w q2.x) d = (q2.y q2.z q2.w)
-                    if (COUNT) { tris_cnt += (q2.y == q2.y) ? 2 : 1; HZ_WAVE_TICK(w_leaves); }
-                    hit = hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y,
-                                     q1.z, q1.w, q2.x);
-                    if (!hit && (q2.y == q2.y))
-                        hit = hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, q0.w, q1.x, q1.y, q2.y, q2.z, q2.w,
-                                         q1.z, q1.w, q2.x);
-                    if (hit) break;
-                    leaf = HZ_EMPTY;
-                    if (node < 0 && node != HZ_EMPTY) { leaf = node; HZ_POP(); }
-                }
-                if (hit) { ray_active = false; last_hit = true; break; }
-                if (node == HZ_EMPTY) { ray_active = false; last_hit = false; break; }
-                // ---- ray compaction: too few lanes left in this loop -> let the others refill
-                if (__popcll(__ballot(1)) < p.regroup) break;
-            }
+            const int r = hz_trace<HZ_TPB, COUNT>(p.sv.nodes, p.sv.prims, top, ntop, stack, tid, ox, oy, oz,
+                                                 dx, dy, dz, tfar, rb, node, leaf, sp, p.regroup, tc);
+            if (r != 2) { ray_active = false; last_hit = (r == 1); }
         }
     }
-#undef HZ_POP
 
     // one atomic per wave and counter
-    unsigned long long r = rays, g = guards, nc = nodes_cnt, tc = tris_cnt, cc = cells_cnt;
-    unsigned long long wn = w_nodes, wl = w_leaves, wa = w_adv;
+    unsigned long long r = rays, g = guards, nc = tc.nodes, tcn = tc.tris, cc = cells_cnt;
+    unsigned long long wn = tc.w_nodes, wl = tc.w_leaves, wa = w_adv;
     for (int off = 32; off > 0; off >>= 1) {
         r += __shfl_xor(r, off); g += __shfl_xor(g, off); cc += __shfl_xor(cc, off);
         if (COUNT) {
-            nc += __shfl_xor(nc, off); tc += __shfl_xor(tc, off);
+            nc += __shfl_xor(nc, off); tcn += __shfl_xor(tcn, off);
             wn += __shfl_xor(wn, off); wl += __shfl_xor(wl, off); wa += __shfl_xor(wa, off);
         }
     }
@@ -325,7 +266,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
         if (g) atomicAdd(&p.counters[1], g);
         if (cc) atomicAdd(&p.counters[4], cc);
         if (COUNT) {
-            atomicAdd(&p.counters[2], nc); atomicAdd(&p.counters[3], tc);
+            atomicAdd(&p.counters[2], nc); atomicAdd(&p.counters[3], tcn);
             atomicAdd(&p.counters[5], wn); atomicAdd(&p.counters[6], wl); atomicAdd(&p.counters[7], wa);
         }
     }
@@ -365,10 +306,10 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
     p.n_tiles = tiles_i * p.tiles_j;
     p.chunk = (p.n_tiles + 7) / 8;
     p.dist = a.dist; p.hori_fill = a.hori_fill; p.ray_org_elev = a.ray_org_elev;
-    // stack: one entry per tree level is enough (only the far child of a level is ever pushed)
-    const int depth = std::max(sc->hdr.height, 1);
+    // stack: at most 3 pending siblings per 4-wide level
+    const int depth = 3 * std::max(sc->hdr.height, 1);
     p.stack_bytes = depth * HZ_TPB * 4;
-    int top = (a.top_nodes < 0) ? 127 : a.top_nodes;
+    int top = (a.top_nodes < 0) ? 0 : a.top_nodes;
     top = std::min(top, sc->hdr.n_top);
     p.top_nodes = top;
     p.regroup = (a.regroup < 0) ? 0 : std::min(a.regroup, 64);

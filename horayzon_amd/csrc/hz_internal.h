@@ -8,7 +8,7 @@
 #include "hz_common.h"
 
 #define HZ_MAX_TOP_NODES 2047   // upper bound of BFS-ordered top nodes (LDS staging)
-#define HZ_MAX_STACK 64         // deepest tree the traversal kernels accept
+#define HZ_MAX_STACK 96         // LDS stack entries per lane the traversal kernels accept (3 per 4-wide level)
 
 namespace hz {
 

@@ -10,8 +10,11 @@
 //   3. rocprim radix sort of (key, primitive id)
 //   4. k_karras      binary radix tree over the sorted keys (Karras 2012)
 //   5. k_refit       leaf AABBs + bottom-up union with one atomic counter per node
-//   6. k_top         breadth-first relabel of the top of the tree (for LDS staging)
-//   7. k_emit        final 64 B nodes (both child AABBs inline) and 48 B leaf records
+//   6. k_roots/scan  collapse along the 2-bit Morton digits: a binary node starts a 4-wide
+//                    node when its common-prefix length enters a new digit (quadtree level)
+//   7. k_emit4       64 B nodes with conservatively quantised child AABBs (8 bit x/y, 16 bit z)
+//   8. k_top/k_permute  breadth-first relabel of the top of the tree (for LDS staging)
+//   9. k_emit_prims  48 B leaf records in Morton order
 #include <cstring>
 #include <cstdlib>
 #include "hz_internal.h"
@@ -128,7 +131,8 @@ __device__ __forceinline__ int delta(const uint32_t *__restrict__ keys, int n, i
 // children: >= 0 internal, < 0 leaf (~sorted position)
 __global__ __launch_bounds__(256) void k_karras(const uint32_t *__restrict__ keys, int n,
                                                int2 *__restrict__ child, int *__restrict__ parent_int,
-                                               int *__restrict__ parent_leaf) {
+                                               int *__restrict__ parent_leaf, uint8_t *__restrict__ plen,
+                                               int *__restrict__ first) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
     const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
@@ -151,6 +155,8 @@ __global__ __launch_bounds__(256) void k_karras(const uint32_t *__restrict__ key
     const int left = (lo == gamma) ? ~gamma : gamma;
     const int right = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
     child[i] = make_int2(left, right);
+    plen[i] = (uint8_t)dnode;      // common prefix length of the node's key range (0..63)
+    first[i] = lo;                 // first sorted leaf of the range
     if (left >= 0) parent_int[left] = i; else parent_leaf[~left] = i;
     if (right >= 0) parent_int[right] = i; else parent_leaf[~right] = i;
     if (i == 0) parent_int[0] = -1;
@@ -162,6 +168,7 @@ __global__ __launch_bounds__(256) void k_refit(BuildParams b, const uint32_t *__
                                               const int2 *__restrict__ child,
                                               const int *__restrict__ parent_int,
                                               const int *__restrict__ parent_leaf,
+                                              const uint8_t *__restrict__ plen,
                                               float4 *leaf_lo, float4 *leaf_hi,
                                               float4 *node_lo, float4 *node_hi, int *counter) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
@@ -190,9 +197,11 @@ __global__ __launch_bounds__(256) void k_refit(BuildParams b, const uint32_t *__
         const float4 h0 = (ch.x >= 0) ? node_hi[ch.x] : leaf_hi[~ch.x];
         const float4 l1 = (ch.y >= 0) ? node_lo[ch.y] : leaf_lo[~ch.y];
         const float4 h1 = (ch.y >= 0) ? node_hi[ch.y] : leaf_hi[~ch.y];
-        const int hgt0 = (ch.x >= 0) ? __float_as_int(l0.w) : 0;
-        const int hgt1 = (ch.y >= 0) ? __float_as_int(l1.w) : 0;
-        height = max(hgt0, hgt1) + 1;
+        // 4-wide levels strictly below this node's digit group (see k_roots)
+        const int dg = plen[node] >> 1;
+        const int hgt0 = (ch.x >= 0) ? __float_as_int(l0.w) + (((plen[ch.x] >> 1) != dg) ? 1 : 0) : 0;
+        const int hgt1 = (ch.y >= 0) ? __float_as_int(l1.w) + (((plen[ch.y] >> 1) != dg) ? 1 : 0) : 0;
+        height = max(hgt0, hgt1);
         float4 nl = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), __int_as_float(height));
         float4 nh = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 0.0f);
         node_lo[node] = nl;
@@ -202,23 +211,126 @@ __global__ __launch_bounds__(256) void k_refit(BuildParams b, const uint32_t *__
     }
 }
 
-// --- breadth-first relabel of the top of the tree -------------------------------
-// perm[old] = new.  Single workgroup, single lane: n_top <= a few thousand.
-__global__ void k_top(const int2 *__restrict__ child, int n_nodes, int n_top,
+// --- collapse to 4-wide nodes --------------------------------------------------------
+// A binary node opens a 4-wide node when it is the root or when its prefix length lies in
+// another 2-bit digit than its parent's.  Inside one digit a subtree has at most 3 binary
+// nodes and 4 exits; exit k goes to child slot = the digit value of its keys (2*ybit + xbit).
+__global__ __launch_bounds__(256) void k_roots(int n_nodes, const int *__restrict__ parent_int,
+                                              const uint8_t *__restrict__ plen, uint32_t *__restrict__ flag) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_nodes) return;
+    const int par = parent_int[i];
+    flag[i] = (par < 0 || (plen[par] >> 1) != (plen[i] >> 1)) ? 1u : 0u;
+}
+
+struct Emit4 {
+    const int2 *child; const uint8_t *plen; const int *first;
+    const uint32_t *keys; const uint32_t *flag; const uint32_t *idx;
+    const float4 *leaf_lo, *leaf_hi, *node_lo, *node_hi;
+    int n_nodes;
+};
+
+__device__ __forceinline__ int digit_slot(uint32_t key, uint32_t pos, int dg) {
+    const unsigned long long k64 = ((unsigned long long)key << 32) | pos;
+    return (int)((k64 >> (62 - 2 * dg)) & 3ull);
+}
+
+// conservative quantisation of [lo, hi] against origin o and step s into [0, qmax]
+__device__ __forceinline__ uint32_t quant_lo(float lo, float o, float s, float qmax) {
+    float q = fminf(fmaxf(floorf((lo - o) / s), 0.0f), qmax);
+    while (q > 0.0f && __builtin_fmaf(q, s, o) > lo) q -= 1.0f;
+    return (uint32_t)q;
+}
+__device__ __forceinline__ uint32_t quant_hi(float hi, float o, float s, float qmax) {
+    float q = fminf(fmaxf(ceilf((hi - o) / s), 0.0f), qmax);
+    while (q < qmax && __builtin_fmaf(q, s, o) < hi) q += 1.0f;
+    return (uint32_t)q;
+}
+// smallest power-of-two step with qmax * step >= extent; returns the biased exponent
+__device__ __forceinline__ uint32_t step_exponent(float extent, float qmax) {
+    const float need = fmaxf(extent / qmax, 1.0e-30f);
+    int e;
+    frexpf(need, &e);                 // need = m * 2^e, m in [0.5, 1)  ->  2^e >= need
+    int biased = e + 127;
+    biased = min(max(biased, 1), 254);
+    while (biased < 254 && __uint_as_float((uint32_t)biased << 23) * qmax < extent) biased++;
+    return (uint32_t)biased;
+}
+
+__global__ __launch_bounds__(256) void k_emit4(Emit4 e, Node *__restrict__ nodes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= e.n_nodes || !e.flag[i]) return;
+    const int dg = e.plen[i] >> 1;
+    // gather the (<= 4) exits of the digit group rooted at i
+    int link[4]; float lo[4][3], hi[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        link[k] = HZ_EMPTY;
+#pragma unroll
+        for (int a = 0; a < 3; a++) { lo[k][a] = 0.0f; hi[k][a] = 0.0f; }
+    }
+    int pend[4]; int np = 0;
+    { const int2 ch = e.child[i]; pend[np++] = ch.x; pend[np++] = ch.y; }
+    while (np > 0) {
+        const int c = pend[--np];
+        if (c >= 0 && (e.plen[c] >> 1) == dg) {       // same digit: expand (its children leave the digit)
+            const int2 ch = e.child[c];
+            pend[np++] = ch.x; pend[np++] = ch.y;
+            continue;
+        }
+        int slot; float4 bl, bh; int lk;
+        if (c < 0) {
+            const int sidx = ~c;
+            slot = digit_slot(e.keys[sidx], (uint32_t)sidx, dg);
+            bl = e.leaf_lo[sidx]; bh = e.leaf_hi[sidx]; lk = c;
+        } else {
+            const int f = e.first[c];
+            slot = digit_slot(e.keys[f], (uint32_t)f, dg);
+            bl = e.node_lo[c]; bh = e.node_hi[c]; lk = (int)e.idx[c];
+        }
+        // slots are distinct by construction; dynamic indexing is fine here (build-time kernel)
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (k == slot) { link[k] = lk; lo[k][0] = bl.x; lo[k][1] = bl.y; lo[k][2] = bl.z;
+                             hi[k][0] = bh.x; hi[k][1] = bh.y; hi[k][2] = bh.z; }
+    }
+    const float4 nl = e.node_lo[i], nh = e.node_hi[i];
+    const float org[3] = {nl.x, nl.y, nl.z};
+    const float ext[3] = {nh.x - nl.x, nh.y - nl.y, nh.z - nl.z};
+    const uint32_t ex = step_exponent(ext[0], 255.0f), ey = step_exponent(ext[1], 255.0f);
+    const uint32_t ez = step_exponent(ext[2], 65535.0f);
+    const float sx = __uint_as_float(ex << 23), sy = __uint_as_float(ey << 23), sz = __uint_as_float(ez << 23);
+    Node n;
+    n.org[0] = org[0]; n.org[1] = org[1]; n.org[2] = org[2];
+    n.scale = ex | (ey << 8) | (ez << 16);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        n.link[k] = link[k];
+        if (link[k] == HZ_EMPTY) { n.qxy[k] = 0x00ff00ffu; n.qz[k] = 0x0000ffffu; continue; }   // lo > hi: never hit
+        const uint32_t xl = quant_lo(lo[k][0], org[0], sx, 255.0f), xh = quant_hi(hi[k][0], org[0], sx, 255.0f);
+        const uint32_t yl = quant_lo(lo[k][1], org[1], sy, 255.0f), yh = quant_hi(hi[k][1], org[1], sy, 255.0f);
+        const uint32_t zl = quant_lo(lo[k][2], org[2], sz, 65535.0f), zh = quant_hi(hi[k][2], org[2], sz, 65535.0f);
+        n.qxy[k] = xl | (xh << 8) | (yl << 16) | (yh << 24);
+        n.qz[k] = zl | (zh << 16);
+    }
+    nodes[e.idx[i]] = n;
+}
+
+// --- breadth-first relabel of the top of the tree -----------------------------------------
+// perm[old] = new.  Single lane: n_top <= a few thousand nodes.
+__global__ void k_top(const Node *__restrict__ nodes, int n_nodes, int n_top,
                       int *__restrict__ perm, int *__restrict__ top, uint8_t *__restrict__ in_top) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    // BFS
     int head = 0, tail = 0;
     top[tail++] = 0;
     while (head < tail && tail < n_top) {
-        const int2 ch = child[top[head++]];
-        if (ch.x >= 0 && tail < n_top) top[tail++] = ch.x;
-        if (ch.y >= 0 && tail < n_top) top[tail++] = ch.y;
+        const Node &nd = nodes[top[head++]];
+        for (int k = 0; k < 4; k++)
+            if (nd.link[k] >= 0 && tail < n_top) top[tail++] = nd.link[k];
     }
-    const int k = tail;  // actual number of relabelled nodes (<= n_top, <= n_nodes)
+    const int k = tail;
     for (int r = 0; r < k; r++) if (top[r] < k) in_top[top[r]] = 1;
     for (int r = 0; r < k; r++) perm[top[r]] = r;
-    // displaced low-index nodes take the vacated high indices
     int x = 0;
     for (int r = 0; r < k; r++) {
         if (top[r] >= k) {
@@ -234,27 +346,14 @@ __global__ __launch_bounds__(256) void k_iota(int *__restrict__ perm, int n) {
     if (i < n) perm[i] = i;
 }
 
-__global__ __launch_bounds__(256) void k_emit_nodes(int n_nodes, const int2 *__restrict__ child,
-                                                   const int *__restrict__ perm,
-                                                   const float4 *__restrict__ leaf_lo,
-                                                   const float4 *__restrict__ leaf_hi,
-                                                   const float4 *__restrict__ node_lo,
-                                                   const float4 *__restrict__ node_hi,
-                                                   Node *__restrict__ nodes) {
+__global__ __launch_bounds__(256) void k_permute(int n_nodes, const int *__restrict__ perm,
+                                                const Node *__restrict__ src, Node *__restrict__ dst) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_nodes) return;
-    const int2 ch = child[i];
-    const float4 l0 = (ch.x >= 0) ? node_lo[ch.x] : leaf_lo[~ch.x];
-    const float4 h0 = (ch.x >= 0) ? node_hi[ch.x] : leaf_hi[~ch.x];
-    const float4 l1 = (ch.y >= 0) ? node_lo[ch.y] : leaf_lo[~ch.y];
-    const float4 h1 = (ch.y >= 0) ? node_hi[ch.y] : leaf_hi[~ch.y];
-    Node n;
-    n.lo0[0] = l0.x; n.lo0[1] = l0.y; n.lo0[2] = l0.z; n.hi0[0] = h0.x; n.hi0[1] = h0.y; n.hi0[2] = h0.z;
-    n.lo1[0] = l1.x; n.lo1[1] = l1.y; n.lo1[2] = l1.z; n.hi1[0] = h1.x; n.hi1[1] = h1.y; n.hi1[2] = h1.z;
-    n.c0 = (ch.x >= 0) ? perm[ch.x] : ch.x;
-    n.c1 = (ch.y >= 0) ? perm[ch.y] : ch.y;
-    n.pad_[0] = 0; n.pad_[1] = 0;
-    nodes[perm[i]] = n;
+    Node n = src[i];
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (n.link[k] >= 0) n.link[k] = perm[n.link[k]];
+    dst[perm[i]] = n;
 }
 
 __global__ __launch_bounds__(256) void k_emit_prims(BuildParams b, const uint32_t *__restrict__ vals,
@@ -270,13 +369,19 @@ __global__ __launch_bounds__(256) void k_emit_prims(BuildParams b, const uint32_
     prims[s] = p;
 }
 
-// single primitive: a root node whose second child is an empty box
+// single primitive: a root whose slot 0 is the leaf, quantised against its own box
 __global__ void k_single_node(const float4 *leaf_lo, const float4 *leaf_hi, Node *nodes) {
+    const float4 l = leaf_lo[0], h = leaf_hi[0];
+    const uint32_t ex = step_exponent(h.x - l.x, 255.0f), ey = step_exponent(h.y - l.y, 255.0f);
+    const uint32_t ez = step_exponent(h.z - l.z, 65535.0f);
     Node n;
-    n.lo0[0] = leaf_lo[0].x; n.lo0[1] = leaf_lo[0].y; n.lo0[2] = leaf_lo[0].z;
-    n.hi0[0] = leaf_hi[0].x; n.hi0[1] = leaf_hi[0].y; n.hi0[2] = leaf_hi[0].z;
-    for (int k = 0; k < 3; k++) { n.lo1[k] = INFINITY; n.hi1[k] = -INFINITY; }
-    n.c0 = ~0; n.c1 = ~0; n.pad_[0] = n.pad_[1] = 0;
+    n.org[0] = l.x; n.org[1] = l.y; n.org[2] = l.z;
+    n.scale = ex | (ey << 8) | (ez << 16);
+    for (int k = 0; k < 4; k++) { n.link[k] = HZ_EMPTY; n.qxy[k] = 0x00ff00ffu; n.qz[k] = 0x0000ffffu; }
+    n.link[0] = ~0;
+    n.qxy[0] = 0u | (quant_hi(h.x, l.x, __uint_as_float(ex << 23), 255.0f) << 8)
+             | (quant_hi(h.y, l.y, __uint_as_float(ey << 23), 255.0f) << 24);
+    n.qz[0] = quant_hi(h.z, l.z, __uint_as_float(ez << 23), 65535.0f) << 16;
     nodes[0] = n;
 }
 
@@ -303,31 +408,18 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     const int n_quads = (d0 - 1) * (d1 - 1);
     const int n_tin = has_tin ? nts : 0;
     const int n_prims = n_quads + n_tin;
-    const int n_nodes = (n_prims > 1) ? n_prims - 1 : 1;
+    const int n_bin = (n_prims > 1) ? n_prims - 1 : 1;      // binary radix tree nodes
     hipStream_t st = sc->stream;
-    Timer t_total; t_total.start();
 
-    // ---- blob allocation -------------------------------------------------------
-    BlobHeader h;
-    memset(&h, 0, sizeof(h));
-    h.magic = HZ_BLOB_MAGIC; h.version = HZ_BLOB_VERSION;
-    h.d0 = d0; h.d1 = d1; h.n_quads = n_quads; h.n_tin = n_tin; h.n_prims = n_prims; h.n_nodes = n_nodes;
-    h.off_verts = sizeof(BlobHeader);
-    h.off_nodes = align_up(h.off_verts + nvert * 12, 256);
-    h.off_prims = align_up(h.off_nodes + (size_t)n_nodes * sizeof(Node), 256);
-    h.total_bytes = align_up(h.off_prims + (size_t)n_prims * sizeof(Prim), 256);
-    HZ_HIP(hipMalloc(&sc->blob, h.total_bytes));
-    sc->owns_blob = true;
-    sc->blob_bytes = h.total_bytes;
-    char *blob = (char *)sc->blob;
-    float *d_verts = (float *)(blob + h.off_verts);
-    Node *d_nodes = (Node *)(blob + h.off_nodes);
-    Prim *d_prims = (Prim *)(blob + h.off_prims);
-
-    // ---- upload vertices (host or device source) ---------------------------------
+    // ---- vertices on the device (host or device source) -------------------------------
     Timer t_h2d; t_h2d.start();
-    HZ_HIP(hipMemcpyAsync(d_verts, vert_grid, nvert * 12, hipMemcpyDefault, st));
-    TempBuf b_vs, b_ts;
+    TempBuf b_verts, b_vs, b_ts;
+    const float *d_verts_src = vert_grid;
+    if (!is_device_ptr(vert_grid)) {
+        HZ_HIP(b_verts.alloc(nvert * 12));
+        HZ_HIP(hipMemcpyAsync(b_verts.p, vert_grid, nvert * 12, hipMemcpyHostToDevice, st));
+        d_verts_src = (const float *)b_verts.p;
+    }
     if (has_tin) {
         HZ_HIP(b_vs.alloc((size_t)nvs * 12));
         HZ_HIP(b_ts.alloc((size_t)nts * 12));
@@ -338,6 +430,11 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     const double h2d_s = t_h2d.stop();
 
     Timer t_bvh; t_bvh.start();
+    BlobHeader h;
+    memset(&h, 0, sizeof(h));
+    h.magic = HZ_BLOB_MAGIC; h.version = HZ_BLOB_VERSION;
+    h.d0 = d0; h.d1 = d1; h.n_quads = n_quads; h.n_tin = n_tin; h.n_prims = n_prims;
+
     // ---- 1. bounds ----------------------------------------------------------------
     TempBuf b_bounds;
     HZ_HIP(b_bounds.alloc(6 * 4));
@@ -345,7 +442,7 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     HZ_HIP(hipMemcpyAsync(b_bounds.p, init, sizeof(init), hipMemcpyHostToDevice, st));
     {
         const int grid = (int)std::min<size_t>((nvert + 255) / 256, 2048);
-        hipLaunchKernelGGL(k_bounds, dim3(grid), dim3(256), 0, st, d_verts, nvert, (uint32_t *)b_bounds.p);
+        hipLaunchKernelGGL(k_bounds, dim3(grid), dim3(256), 0, st, d_verts_src, nvert, (uint32_t *)b_bounds.p);
         if (has_tin)
             hipLaunchKernelGGL(k_bounds, dim3(std::min((nvs + 255) / 256, 2048)), dim3(256), 0, st,
                                (const float *)b_vs.p, (size_t)nvs, (uint32_t *)b_bounds.p);
@@ -370,7 +467,7 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     h.pad = (float)(1.0e-6 * std::sqrt(diag2) + 4.0 * FLT_EPSILON * (double)maxabs) + FLT_MIN;
 
     BuildParams bp;
-    bp.verts = d_verts; bp.vs = (const float *)b_vs.p; bp.ts = (const int32_t *)b_ts.p;
+    bp.verts = d_verts_src; bp.vs = (const float *)b_vs.p; bp.ts = (const int32_t *)b_ts.p;
     bp.d0 = d0; bp.d1 = d1; bp.nq1 = d1 - 1;
     bp.n_quads = n_quads; bp.n_tin = n_tin; bp.n_prims = n_prims;
     bp.cx = h.center[0]; bp.cy = h.center[1]; bp.cz = h.center[2]; bp.pad = h.pad;
@@ -383,6 +480,7 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     HZ_HIP(b_k0.alloc((size_t)n_prims * 4)); HZ_HIP(b_k1.alloc((size_t)n_prims * 4));
     HZ_HIP(b_v0.alloc((size_t)n_prims * 4)); HZ_HIP(b_v1.alloc((size_t)n_prims * 4));
     const int gp = (n_prims + 255) / 256;
+    const int gn = (n_bin + 255) / 256;
     hipLaunchKernelGGL(k_morton, dim3(gp), dim3(256), 0, st, bp, (uint32_t *)b_k0.p, (uint32_t *)b_v0.p);
     size_t sort_bytes = 0;
     HZ_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint32_t *)b_k0.p, (uint32_t *)b_k1.p,
@@ -393,54 +491,104 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     const uint32_t *keys = (const uint32_t *)b_k1.p;
     const uint32_t *vals = (const uint32_t *)b_v1.p;
 
-    // ---- 4./5. hierarchy + refit ------------------------------------------------------
-    TempBuf b_child, b_pint, b_pleaf, b_llo, b_lhi, b_nlo, b_nhi, b_cnt, b_perm, b_top, b_intop;
-    HZ_HIP(b_child.alloc((size_t)n_nodes * 8));
-    HZ_HIP(b_pint.alloc((size_t)n_nodes * 4));
+    // ---- 4./5. binary hierarchy + refit -------------------------------------------------
+    TempBuf b_child, b_pint, b_pleaf, b_plen, b_first, b_llo, b_lhi, b_nlo, b_nhi, b_cnt;
+    HZ_HIP(b_child.alloc((size_t)n_bin * 8));
+    HZ_HIP(b_pint.alloc((size_t)n_bin * 4));
     HZ_HIP(b_pleaf.alloc((size_t)n_prims * 4));
+    HZ_HIP(b_plen.alloc((size_t)n_bin));
+    HZ_HIP(b_first.alloc((size_t)n_bin * 4));
     HZ_HIP(b_llo.alloc((size_t)n_prims * 16)); HZ_HIP(b_lhi.alloc((size_t)n_prims * 16));
-    HZ_HIP(b_nlo.alloc((size_t)n_nodes * 16)); HZ_HIP(b_nhi.alloc((size_t)n_nodes * 16));
-    HZ_HIP(b_cnt.alloc((size_t)n_nodes * 4));
-    HZ_HIP(hipMemsetAsync(b_cnt.p, 0, (size_t)n_nodes * 4, st));
-    HZ_HIP(hipMemsetAsync(b_nlo.p, 0, (size_t)n_nodes * 16, st));
+    HZ_HIP(b_nlo.alloc((size_t)n_bin * 16)); HZ_HIP(b_nhi.alloc((size_t)n_bin * 16));
+    HZ_HIP(b_cnt.alloc((size_t)n_bin * 4));
+    HZ_HIP(hipMemsetAsync(b_cnt.p, 0, (size_t)n_bin * 4, st));
+    HZ_HIP(hipMemsetAsync(b_nlo.p, 0, (size_t)n_bin * 16, st));
     if (n_prims > 1)
         hipLaunchKernelGGL(k_karras, dim3((n_prims - 1 + 255) / 256), dim3(256), 0, st, keys, n_prims,
-                           (int2 *)b_child.p, (int *)b_pint.p, (int *)b_pleaf.p);
+                           (int2 *)b_child.p, (int *)b_pint.p, (int *)b_pleaf.p, (uint8_t *)b_plen.p,
+                           (int *)b_first.p);
     hipLaunchKernelGGL(k_refit, dim3(gp), dim3(256), 0, st, bp, vals, (const int2 *)b_child.p,
-                       (const int *)b_pint.p, (const int *)b_pleaf.p, (float4 *)b_llo.p, (float4 *)b_lhi.p,
-                       (float4 *)b_nlo.p, (float4 *)b_nhi.p, (int *)b_cnt.p);
+                       (const int *)b_pint.p, (const int *)b_pleaf.p, (const uint8_t *)b_plen.p,
+                       (float4 *)b_llo.p, (float4 *)b_lhi.p, (float4 *)b_nlo.p, (float4 *)b_nhi.p, (int *)b_cnt.p);
 
-    // ---- 6./7. relabel + emit ------------------------------------------------------------
-    int n_top = 0;
+    // ---- 6. which binary nodes open a 4-wide node; compact indices ------------------------
+    int n4 = 1;
+    TempBuf b_flag, b_idx, b_scan;
     if (n_prims > 1) {
-        n_top = std::min(n_nodes, HZ_MAX_TOP_NODES);
-        HZ_HIP(b_perm.alloc((size_t)n_nodes * 4));
+        HZ_HIP(b_flag.alloc((size_t)n_bin * 4));
+        HZ_HIP(b_idx.alloc((size_t)n_bin * 4));
+        hipLaunchKernelGGL(k_roots, dim3(gn), dim3(256), 0, st, n_bin, (const int *)b_pint.p,
+                           (const uint8_t *)b_plen.p, (uint32_t *)b_flag.p);
+        size_t scan_bytes = 0;
+        HZ_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t *)b_flag.p, (uint32_t *)b_idx.p, 0u,
+                                       (size_t)n_bin, rocprim::plus<uint32_t>(), st));
+        HZ_HIP(b_scan.alloc(scan_bytes));
+        HZ_HIP(rocprim::exclusive_scan(b_scan.p, scan_bytes, (uint32_t *)b_flag.p, (uint32_t *)b_idx.p, 0u,
+                                       (size_t)n_bin, rocprim::plus<uint32_t>(), st));
+        uint32_t last_idx = 0, last_flag = 0;
+        HZ_HIP(hipMemcpyAsync(&last_idx, (uint32_t *)b_idx.p + (n_bin - 1), 4, hipMemcpyDeviceToHost, st));
+        HZ_HIP(hipMemcpyAsync(&last_flag, (uint32_t *)b_flag.p + (n_bin - 1), 4, hipMemcpyDeviceToHost, st));
+        HZ_HIP(hipStreamSynchronize(st));
+        n4 = (int)(last_idx + last_flag);
+    }
+
+    // ---- blob allocation (exact size now known) ------------------------------------------------
+    h.n_nodes = n4;
+    h.off_verts = sizeof(BlobHeader);
+    h.off_nodes = align_up(h.off_verts + nvert * 12, 256);
+    h.off_prims = align_up(h.off_nodes + (size_t)n4 * sizeof(Node), 256);
+    h.total_bytes = align_up(h.off_prims + (size_t)n_prims * sizeof(Prim), 256);
+    HZ_HIP(hipMalloc(&sc->blob, h.total_bytes));
+    sc->owns_blob = true;
+    sc->blob_bytes = h.total_bytes;
+    char *blob = (char *)sc->blob;
+    float *d_verts = (float *)(blob + h.off_verts);
+    Node *d_nodes = (Node *)(blob + h.off_nodes);
+    Prim *d_prims = (Prim *)(blob + h.off_prims);
+    HZ_HIP(hipMemcpyAsync(d_verts, d_verts_src, nvert * 12, hipMemcpyDeviceToDevice, st));
+
+    // ---- 7./8. emit 4-wide nodes, relabel the top breadth first ----------------------------------
+    int n_top = 1;
+    TempBuf b_tmp4, b_perm, b_top, b_intop;
+    if (n_prims > 1) {
+        HZ_HIP(b_tmp4.alloc((size_t)n4 * sizeof(Node)));
+        Emit4 e;
+        e.child = (const int2 *)b_child.p; e.plen = (const uint8_t *)b_plen.p; e.first = (const int *)b_first.p;
+        e.keys = keys; e.flag = (const uint32_t *)b_flag.p; e.idx = (const uint32_t *)b_idx.p;
+        e.leaf_lo = (const float4 *)b_llo.p; e.leaf_hi = (const float4 *)b_lhi.p;
+        e.node_lo = (const float4 *)b_nlo.p; e.node_hi = (const float4 *)b_nhi.p;
+        e.n_nodes = n_bin;
+        hipLaunchKernelGGL(k_emit4, dim3(gn), dim3(256), 0, st, e, (Node *)b_tmp4.p);
+        n_top = std::min(n4, HZ_MAX_TOP_NODES);
+        HZ_HIP(b_perm.alloc((size_t)n4 * 4));
         HZ_HIP(b_top.alloc((size_t)n_top * 4));
         HZ_HIP(b_intop.alloc((size_t)n_top));
         HZ_HIP(hipMemsetAsync(b_intop.p, 0, (size_t)n_top, st));
-        hipLaunchKernelGGL(k_iota, dim3((n_nodes + 255) / 256), dim3(256), 0, st, (int *)b_perm.p, n_nodes);
-        hipLaunchKernelGGL(k_top, dim3(1), dim3(64), 0, st, (const int2 *)b_child.p, n_nodes, n_top,
+        const int g4 = (n4 + 255) / 256;
+        hipLaunchKernelGGL(k_iota, dim3(g4), dim3(256), 0, st, (int *)b_perm.p, n4);
+        hipLaunchKernelGGL(k_top, dim3(1), dim3(64), 0, st, (const Node *)b_tmp4.p, n4, n_top,
                            (int *)b_perm.p, (int *)b_top.p, (uint8_t *)b_intop.p);
-        hipLaunchKernelGGL(k_emit_nodes, dim3((n_nodes + 255) / 256), dim3(256), 0, st, n_nodes,
-                           (const int2 *)b_child.p, (const int *)b_perm.p, (const float4 *)b_llo.p,
-                           (const float4 *)b_lhi.p, (const float4 *)b_nlo.p, (const float4 *)b_nhi.p, d_nodes);
+        hipLaunchKernelGGL(k_permute, dim3(g4), dim3(256), 0, st, n4, (const int *)b_perm.p,
+                           (const Node *)b_tmp4.p, d_nodes);
     } else {
         hipLaunchKernelGGL(k_single_node, dim3(1), dim3(1), 0, st, (const float4 *)b_llo.p,
                            (const float4 *)b_lhi.p, d_nodes);
-        n_top = 1;
     }
+    // ---- 9. leaf records ------------------------------------------------------------------------
     hipLaunchKernelGGL(k_emit_prims, dim3(gp), dim3(256), 0, st, bp, vals, d_prims);
-    // tree height = height stored with the root box
+    // height in 4-wide levels = 1 + levels below the root's digit group (stored with the root box)
     float4 root_lo = make_float4(0, 0, 0, 0);
     if (n_prims > 1) HZ_HIP(hipMemcpyAsync(&root_lo, b_nlo.p, 16, hipMemcpyDeviceToHost, st));
     HZ_HIP(hipStreamSynchronize(st));
     HZ_HIP(hipGetLastError());
-    int height = 1;
-    if (n_prims > 1) memcpy(&height, &root_lo.w, 4);
+    int below = 0;
+    if (n_prims > 1) memcpy(&below, &root_lo.w, 4);
+    const int height = below + 1;
     h.height = height;
     h.n_top = n_top;
-    if (height > HZ_MAX_STACK)
-        return set_error(HZ_ERR_DEPTH, "BVH height %d exceeds the traversal stack (%d)", height, HZ_MAX_STACK);
+    if (3 * height > HZ_MAX_STACK)
+        return set_error(HZ_ERR_DEPTH, "BVH height %d (4-wide levels) exceeds the traversal stack (%d entries)",
+                         height, HZ_MAX_STACK);
     HZ_HIP(hipMemcpyAsync(blob, &h, sizeof(h), hipMemcpyHostToDevice, st));
     HZ_HIP(hipStreamSynchronize(st));
     sc->hdr = h;
@@ -449,7 +597,6 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
         stats->t_bvh_s += bvh_s; stats->t_h2d_s += h2d_s;
         stats->bvh_height = height; stats->scene_bytes = h.total_bytes;
     }
-    (void)t_total;
     return HZ_OK;
 }
 

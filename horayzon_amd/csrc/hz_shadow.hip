@@ -9,7 +9,6 @@
 
 namespace hz {
 
-#define HZ_EMPTY ((int)0x80000000)
 #define HZ_TPB 256
 
 struct ShadowParams {
@@ -22,7 +21,7 @@ struct ShadowParams {
     float fill, dot_prod_min;
     int refrac, which;
     uint8_t *out_u8; float *out_f32;
-    int top_nodes;
+    int top_nodes, stack_bytes;
     unsigned long long *counters;
 };
 
@@ -54,62 +53,29 @@ __device__ __forceinline__ float atmos_refrac(float elev_ang_true, float temp, f
     return (float)((double)refrac_cor * (1.0 / 60.0));
 }
 
-// any-hit traversal to completion; per-lane stack in LDS
-template <int STACK>
+// any-hit traversal to completion (regroup = 0: never suspends)
 __device__ __forceinline__ bool occluded(const SceneView &sv, const float4 *top, int ntop, int *stack, int tid,
                                          float ox, float oy, float oz, float dx, float dy, float dz,
                                          float tfar) {
     const RayBox rb = hz_raybox(ox - sv.cx, oy - sv.cy, oz - sv.cz, dx, dy, dz);
-    int node = 0, sp = 0;
-    for (;;) {
-        while (node >= 0) {
-            float4 n0, n1, n2; int2 ch;
-            if (node < ntop) {
-                const float4 *q = top + 4 * node;
-                n0 = q[0]; n1 = q[1]; n2 = q[2]; ch = *reinterpret_cast<const int2 *>(q + 3);
-            } else {
-                const float4 *q = reinterpret_cast<const float4 *>(sv.nodes + node);
-                n0 = q[0]; n1 = q[1]; n2 = q[2]; ch = *reinterpret_cast<const int2 *>(q + 3);
-            }
-            float ta, tb;
-            const bool ha = hz_box_hit(rb, tfar, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, &ta);
-            const bool hb = hz_box_hit(rb, tfar, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, &tb);
-            if (ha && hb) {
-                const bool sw = tb < ta;
-                stack[sp * HZ_TPB + tid] = sw ? ch.x : ch.y;
-                sp++;
-                node = sw ? ch.y : ch.x;
-            } else if (ha) node = ch.x;
-            else if (hb) node = ch.y;
-            else if (sp > 0) { sp--; node = stack[sp * HZ_TPB + tid]; }
-            else node = HZ_EMPTY;
-        }
-        if (node == HZ_EMPTY) return false;
-        const float4 *q = reinterpret_cast<const float4 *>(sv.prims + (~node));
-        const float4 q0 = q[0], q1 = q[1], q2 = q[2];
-        if (hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x))
-            return true;
-        if ((q2.y == q2.y) &&
-            hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, q0.w, q1.x, q1.y, q2.y, q2.z, q2.w, q1.z, q1.w, q2.x))
-            return true;
-        if (sp > 0) { sp--; node = stack[sp * HZ_TPB + tid]; }
-        else return false;
-    }
+    int node = 0, leaf = HZ_EMPTY, sp = 0;
+    TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.w_nodes = 0; tc.w_leaves = 0;
+    return hz_trace<HZ_TPB, false>(sv.nodes, sv.prims, top, ntop, stack, tid, ox, oy, oz, dx, dy, dz, tfar, rb,
+                                   node, leaf, sp, 0, tc) == 1;
 }
 
-template <int STACK>
 __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *stack = reinterpret_cast<int *>(smem);
-    const float4 *top = reinterpret_cast<const float4 *>(smem + STACK * HZ_TPB * 4);
+    const float4 *top = reinterpret_cast<const float4 *>(smem + p.stack_bytes);
     const int tid = threadIdx.x;
     const int ntop = p.top_nodes;
-    {
-        float4 *dst = reinterpret_cast<float4 *>(smem + STACK * HZ_TPB * 4);
+    if (ntop > 0) {
+        float4 *dst = reinterpret_cast<float4 *>(smem + p.stack_bytes);
         const float4 *src = reinterpret_cast<const float4 *>(p.sv.nodes);
         for (int i = tid; i < ntop * 4; i += HZ_TPB) dst[i] = src[i];
+        __syncthreads();
     }
-    __syncthreads();
     const int b = blockIdx.x;
     const int tile = (b & 7) * p.chunk + (b >> 3);
     const int ti = tile / p.tiles_j, tj = tile - ti * p.tiles_j;
@@ -159,7 +125,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
             if (p.which == 0) {                                    // :451-478
                 if (dot_prod_ts > 0.0f) {
                     rays = 1;
-                    const bool h = occluded<STACK>(p.sv, top, ntop, stack, tid, ox, oy, oz, sun_x, sun_y, sun_z, inf);
+                    const bool h = occluded(p.sv, top, ntop, stack, tid, ox, oy, oz, sun_x, sun_y, sun_z, inf);
                     p.out_u8[cell] = h ? 2 : 0;
                 } else {
                     p.out_u8[cell] = 1;
@@ -167,7 +133,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
             } else {                                               // :561-592
                 if (dot_prod_ts > p.dot_prod_min) {
                     rays = 1;
-                    const bool h = occluded<STACK>(p.sv, top, ntop, stack, tid, ox, oy, oz, sun_x, sun_y, sun_z, inf);
+                    const bool h = occluded(p.sv, top, ntop, stack, tid, ox, oy, oz, sun_x, sun_y, sun_z, inf);
                     if (h) p.out_f32[cell] = 0.0f;
                     else {
                         if (dot_prod_ns < p.dot_prod_min) dot_prod_ns = p.dot_prod_min;
@@ -199,22 +165,16 @@ int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st) {
     p.fill = a.sw_dir_cor_fill; p.dot_prod_min = a.dot_prod_min;
     p.refrac = a.refrac_cor; p.which = a.which;
     p.out_u8 = a.out_u8; p.out_f32 = a.out_f32;
-    const int stack = (sc->hdr.height <= 32) ? 32 : 64;
-    int top = (a.top_nodes < 0) ? 127 : a.top_nodes;
+    p.stack_bytes = 3 * std::max(sc->hdr.height, 1) * HZ_TPB * 4;
+    int top = (a.top_nodes < 0) ? 0 : a.top_nodes;
     top = std::min(top, sc->hdr.n_top);
     p.top_nodes = top;
     p.counters = a.counters;
-    const size_t lds = (size_t)stack * HZ_TPB * 4 + (size_t)top * sizeof(Node);
+    const size_t lds = (size_t)p.stack_bytes + (size_t)top * sizeof(Node);
     const int grid = p.chunk * 8;
-    if (stack == 32) {
-        HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shadow<32>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_shadow<32>, dim3(grid), dim3(HZ_TPB), lds, st, p);
-    } else {
-        HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shadow<64>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_shadow<64>, dim3(grid), dim3(HZ_TPB), lds, st, p);
-    }
+    HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shadow),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(HZ_TPB), lds, st, p);
     HZ_HIP(hipGetLastError());
     return HZ_OK;
 }

@@ -43,7 +43,7 @@ for rep in range(args.reps):
           % (rep, time.time() - t, st["t_kernel_s"], st["num_rays"], st["num_rays"] / (w * w * args.azim),
              st["num_rays"] / st["t_kernel_s"] / 1e6, w * w / st["t_kernel_s"],
              st["nodes_visited"] / max(st["num_rays"], 1), st["tris_tested"] / max(st["num_rays"], 1)), flush=True)
-if args.count:
+if args.count or args.count_all:
     print("SIMT efficiency: node step %.3f  leaf step %.3f  refill %.3f   (wave iters: node %.3g leaf %.3g refill %.3g)"
           % (st["nodes_visited"] / max(64 * st["wave_node_iters"], 1), st["tris_tested"] / 2 / max(64 * st["wave_leaf_iters"], 1),
              st["num_rays"] / max(64 * st["wave_refills"], 1), st["wave_node_iters"], st["wave_leaf_iters"], st["wave_refills"]))
