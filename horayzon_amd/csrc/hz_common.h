@@ -189,15 +189,20 @@ __device__ __forceinline__ void hz_load_prim(const Prim *q, float4 &q0, float4 &
 
 // ---------------------------------------------------------------------------
 // any-hit traversal of one ray, resumable.
-//   state   : node (current link), leaf (one postponed leaf), sp (stack pointer)
-//   stack   : per-lane LDS stack, entry k of lane tid at stack[k * TPB + tid]
-//   top     : LDS copy of the first ntop nodes (may be null / ntop = 0)
-//   regroup : leave when fewer than `regroup` lanes of the wave are still traversing
-// Speculative while-while: a lane that reaches its first leaf postpones it and keeps
-// descending while any other lane of the wave still has none (keeps the node step full).
+//   TravState : node (current link), sp (stack pointer), two queued leaves
+//   stack     : per-lane LDS stack, entry k of lane tid at stack[k * TPB + tid]
+//   top       : LDS copy of the first ntop nodes (may be null / ntop = 0)
+//   regroup   : leave when fewer than `regroup` lanes of the wave are still traversing
+// Scheduling inside the wave: every lane sets leaves aside (up to 2) and keeps descending;
+// each iteration the wave executes ONE kind of step -- the node step or the leaf step --
+// whichever more lanes are ready for (ballot + popcount vote).  This keeps the 64 lanes
+// busy although neighbouring rays reach their leaves at different times.
 // returns 0 = miss, 1 = hit, 2 = suspended (state is valid, call again)
 // ---------------------------------------------------------------------------
 struct TravCounters { unsigned nodes, tris, w_nodes, w_leaves; };
+struct TravState { int node, sp, lq0, lq1; };
+
+__device__ __forceinline__ void hz_trav_reset(TravState &t) { t.node = 0; t.sp = 0; t.lq0 = HZ_EMPTY; t.lq1 = HZ_EMPTY; }
 
 #define HZ_WAVE_TICK(c, lane_) do { const unsigned long long m_ = __ballot(1); if ((lane_) == __ffsll((long long)m_) - 1) (c)++; } while (0)
 
@@ -205,70 +210,77 @@ template <int TPB, bool COUNT>
 __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Prim *__restrict__ prims,
                                         const float4 *top, int ntop, int *stack, int tid,
                                         float ox, float oy, float oz, float dx, float dy, float dz, float tfar,
-                                        const RayBox &rb, int &node, int &leaf, int &sp, int regroup,
+                                        const RayBox &rb, TravState &t, int regroup, int leaf_bias,
                                         TravCounters &cnt) {
     const int lane = tid & 63;
+    int node = t.node, sp = t.sp, lq0 = t.lq0, lq1 = t.lq1;
+    const int n_entry = __popcll(__ballot(1));   // lanes that entered with a ray
 #define HZ_POP() do { if (sp > 0) { sp--; node = stack[sp * TPB + tid]; } else node = HZ_EMPTY; } while (0)
+#define HZ_SAVE() do { t.node = node; t.sp = sp; t.lq0 = lq0; t.lq1 = lq1; } while (0)
     for (;;) {
-        while (node >= 0) {
-            float4 n0; uint4 n1, n2; int4 n3;
-            if (ntop > 0 && __all(node < ntop)) {   // whole wave inside the LDS nodelet
-                const float4 *q = top + 4 * node;
-                n0 = q[0];
-                n1 = *reinterpret_cast<const uint4 *>(q + 1);
-                n2 = *reinterpret_cast<const uint4 *>(q + 2);
-                n3 = *reinterpret_cast<const int4 *>(q + 3);
-            } else {
-                hz_load_node(nodes + node, n0, n1, n2, n3);
+        // set leaves aside while the 2-entry queue has room
+        if (node < 0 && node != HZ_EMPTY && lq0 == HZ_EMPTY) { lq0 = node; HZ_POP(); }
+        if (node < 0 && node != HZ_EMPTY && lq1 == HZ_EMPTY) { lq1 = node; HZ_POP(); }
+        const bool can_node = node >= 0;
+        const bool can_leaf = lq0 != HZ_EMPTY;
+        if (!can_node && !can_leaf) { HZ_SAVE(); return 0; }                  // nothing left: miss
+        const int n_all = __popcll(__ballot(1));
+        // ray compaction: suspend only if some lane finished its ray in this call (it can refill,
+        // so the caller always makes progress)
+        if (n_all < regroup && n_all < n_entry) { HZ_SAVE(); return 2; }
+        const int n_node = __popcll(__ballot(can_node));
+        const int n_leaf = __popcll(__ballot(can_leaf));
+        if (n_node * 16 >= n_leaf * leaf_bias) {
+            // ---------------- node step ------------------------------------------------------
+            if (can_node) {
+                float4 n0; uint4 n1, n2; int4 n3;
+                if (ntop > 0 && __all(node < ntop)) {   // all stepping lanes inside the LDS nodelet
+                    const float4 *q = top + 4 * node;
+                    n0 = q[0];
+                    n1 = *reinterpret_cast<const uint4 *>(q + 1);
+                    n2 = *reinterpret_cast<const uint4 *>(q + 2);
+                    n3 = *reinterpret_cast<const int4 *>(q + 3);
+                } else {
+                    hz_load_node(nodes + node, n0, n1, n2, n3);
+                }
+                if (COUNT) { cnt.nodes++; HZ_WAVE_TICK(cnt.w_nodes, lane); }
+                const NodeRay nr = hz_node_ray(rb, n0.x, n0.y, n0.z, __float_as_uint(n0.w));
+                const bool h0 = hz_qbox_hit(nr, tfar, n1.x, n2.x);
+                const bool h1 = hz_qbox_hit(nr, tfar, n1.y, n2.y);
+                const bool h2 = hz_qbox_hit(nr, tfar, n1.z, n2.z);
+                const bool h3 = hz_qbox_hit(nr, tfar, n1.w, n2.w);
+                // visit order: slot r ^ order for r = 0..3 (front to back in x / y):
+                // bit 0 of `order` swaps neighbours, bit 1 swaps the halves
+                const bool s1 = (rb.order & 1) != 0, s2 = (rb.order & 2) != 0;
+                const int a0 = s1 ? n3.y : n3.x, a1 = s1 ? n3.x : n3.y, a2 = s1 ? n3.w : n3.z, a3 = s1 ? n3.z : n3.w;
+                const bool b0 = s1 ? h1 : h0, b1 = s1 ? h0 : h1, b2 = s1 ? h3 : h2, b3 = s1 ? h2 : h3;
+                const int l0 = s2 ? a2 : a0, l1 = s2 ? a3 : a1, l2 = s2 ? a0 : a2, l3 = s2 ? a1 : a3;
+                const bool g0 = s2 ? b2 : b0, g1 = s2 ? b3 : b1, g2 = s2 ? b0 : b2, g3 = s2 ? b1 : b3;
+                int next = HZ_EMPTY;
+                // r = 3 .. 0: the last hit seen (smallest r) becomes `next`, the previous `next` is pushed
+                if (g3) next = l3;
+                if (g2) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = l2; }
+                if (g1) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = l1; }
+                if (g0) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = l0; }
+                if (next != HZ_EMPTY) node = next; else HZ_POP();
             }
-            if (COUNT) { cnt.nodes++; HZ_WAVE_TICK(cnt.w_nodes, lane); }
-            const NodeRay nr = hz_node_ray(rb, n0.x, n0.y, n0.z, __float_as_uint(n0.w));
-            const bool h0 = hz_qbox_hit(nr, tfar, n1.x, n2.x);
-            const bool h1 = hz_qbox_hit(nr, tfar, n1.y, n2.y);
-            const bool h2 = hz_qbox_hit(nr, tfar, n1.z, n2.z);
-            const bool h3 = hz_qbox_hit(nr, tfar, n1.w, n2.w);
-            // visit order: slot r ^ order for r = 0..3 (front to back in x / y); far ones are pushed first
-            const int o = rb.order;
-            const int l0 = (o == 0) ? n3.x : (o == 1) ? n3.y : (o == 2) ? n3.z : n3.w;
-            const int l1 = (o == 0) ? n3.y : (o == 1) ? n3.x : (o == 2) ? n3.w : n3.z;
-            const int l2 = (o == 0) ? n3.z : (o == 1) ? n3.w : (o == 2) ? n3.x : n3.y;
-            const int l3 = (o == 0) ? n3.w : (o == 1) ? n3.z : (o == 2) ? n3.y : n3.x;
-            const bool g0 = (o == 0) ? h0 : (o == 1) ? h1 : (o == 2) ? h2 : h3;
-            const bool g1 = (o == 0) ? h1 : (o == 1) ? h0 : (o == 2) ? h3 : h2;
-            const bool g2 = (o == 0) ? h2 : (o == 1) ? h3 : (o == 2) ? h0 : h1;
-            const bool g3 = (o == 0) ? h3 : (o == 1) ? h2 : (o == 2) ? h1 : h0;
-            int next = HZ_EMPTY;
-            // r = 3 .. 0: the last hit seen (smallest r) becomes `next`, the previous `next` is pushed
-            if (g3) next = l3;
-            if (g2) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = l2; }
-            if (g1) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = l1; }
-            if (g0) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = l0; }
-            if (next != HZ_EMPTY) node = next; else HZ_POP();
-            if (node < 0 && node != HZ_EMPTY && leaf == HZ_EMPTY) {   // postpone the first leaf
-                leaf = node;
-                HZ_POP();
+        } else {
+            // ---------------- leaf step: the two triangles of a DEM quad (or one TIN triangle) ---
+            if (can_leaf) {
+                float4 q0, q1, q2;
+                hz_load_prim(prims + (~lq0), q0, q1, q2);
+                // a = (q0.x q0.y q0.z) b = (q0.w q1.x q1.y) c = (q1.z q1.w q2.x) d = (q2.y q2.z q2.w)
+                if (COUNT) { cnt.tris += (q2.y == q2.y) ? 2 : 1; HZ_WAVE_TICK(cnt.w_leaves, lane); }
+                bool hit = hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x);
+                if (!hit && (q2.y == q2.y))
+                    hit = hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, q0.w, q1.x, q1.y, q2.y, q2.z, q2.w, q1.z, q1.w, q2.x);
+                if (hit) { HZ_SAVE(); return 1; }
+                lq0 = lq1; lq1 = HZ_EMPTY;
             }
-            if (!__any(leaf == HZ_EMPTY)) break;      // every lane in the loop holds a leaf
         }
-        // leaves: the two triangles of a DEM quad (or one TIN triangle); consecutive leaves chain
-        bool hit = false;
-        while (leaf != HZ_EMPTY) {
-            float4 q0, q1, q2;
-            hz_load_prim(prims + (~leaf), q0, q1, q2);
-            // a = (q0.x q0.y q0.z) b = (q0.w q1.x q1.y) c = (q1.z q1.w q2.x) d = (q2.y q2.z q2.w)
-            if (COUNT) { cnt.tris += (q2.y == q2.y) ? 2 : 1; HZ_WAVE_TICK(cnt.w_leaves, lane); }
-            hit = hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x);
-            if (!hit && (q2.y == q2.y))
-                hit = hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, q0.w, q1.x, q1.y, q2.y, q2.z, q2.w, q1.z, q1.w, q2.x);
-            if (hit) break;
-            leaf = HZ_EMPTY;
-            if (node < 0 && node != HZ_EMPTY) { leaf = node; HZ_POP(); }
-        }
-        if (hit) return 1;
-        if (node == HZ_EMPTY) return 0;
-        if (__popcll(__ballot(1)) < regroup) return 2;   // ray compaction: let idle lanes refill
     }
 #undef HZ_POP
+#undef HZ_SAVE
 }
 
 #endif  // __HIPCC__

@@ -156,7 +156,7 @@ struct HorizonParams {
     int row_begin, row_end;
     int tiles_j, n_tiles, chunk;   // tile grid of the slab; chunk = ceil(n_tiles / 8)
     float dist, hori_fill, ray_org_elev;
-    int top_nodes, regroup, stack_bytes;
+    int top_nodes, regroup, stack_bytes, leaf_bias;
     unsigned long long *counters;
 };
 
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
     bool ray_active = false, last_hit = false;
     float dx = 0, dy = 0, dz = 1;
     RayBox rb = hz_raybox(0, 0, 0, 0, 0, 1);
-    int node = HZ_EMPTY, leaf = HZ_EMPTY, sp = 0;
+    TravState ts; hz_trav_reset(ts);
 
     while (__ballot(!done) != 0ull) {
         // ---- refill: lanes without a ray take the next sample of their search -----------------
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
                 dy = (r10 * rx + r11 * ry) + r12 * rz;
                 dz = (r20 * rx + r21 * ry) + r22 * rz;
                 rb = hz_raybox(ocx, ocy, ocz, dx, dy, dz);
-                node = 0; sp = 0; leaf = HZ_EMPTY;
+                hz_trav_reset(ts);
                 ray_active = true;
                 rays++;
             } else {
@@ -246,7 +246,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
         // ---- traversal (hz_common.h: speculative while-while, one postponed leaf per lane) ------
         if (ray_active) {
             const int r = hz_trace<HZ_TPB, COUNT>(p.sv.nodes, p.sv.prims, top, ntop, stack, tid, ox, oy, oz,
-                                                 dx, dy, dz, tfar, rb, node, leaf, sp, p.regroup, tc);
+                                                 dx, dy, dz, tfar, rb, ts, p.regroup, p.leaf_bias, tc);
             if (r != 2) { ray_active = false; last_hit = (r == 1); }
         }
     }
@@ -312,7 +312,10 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
     int top = (a.top_nodes < 0) ? 0 : a.top_nodes;
     top = std::min(top, sc->hdr.n_top);
     p.top_nodes = top;
-    p.regroup = (a.regroup < 0) ? 0 : std::min(a.regroup, 64);
+    // defaults from the sweep on the 3601^2 tile: refill when fewer than 48 lanes
+    // are traversing; leaf step when 24 n_leaf > 16 n_node.  opts.regroup = threshold | bias << 8.
+    p.regroup = (a.regroup < 0) ? 48 : std::min(a.regroup & 0xff, 64);
+    p.leaf_bias = (a.regroup >= 256) ? (a.regroup >> 8) : 24;
     p.counters = a.counters;
     const size_t lds = (size_t)p.stack_bytes + (size_t)top * sizeof(Node);
     const int grid = p.chunk * 8;

@@ -58,10 +58,10 @@ __device__ __forceinline__ bool occluded(const SceneView &sv, const float4 *top,
                                          float ox, float oy, float oz, float dx, float dy, float dz,
                                          float tfar) {
     const RayBox rb = hz_raybox(ox - sv.cx, oy - sv.cy, oz - sv.cz, dx, dy, dz);
-    int node = 0, leaf = HZ_EMPTY, sp = 0;
+    TravState ts; hz_trav_reset(ts);
     TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.w_nodes = 0; tc.w_leaves = 0;
     return hz_trace<HZ_TPB, false>(sv.nodes, sv.prims, top, ntop, stack, tid, ox, oy, oz, dx, dy, dz, tfar, rb,
-                                   node, leaf, sp, 0, tc) == 1;
+                                   ts, 0, 16, tc) == 1;
 }
 
 __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
