@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--tile", type=int, default=3601)
     ap.add_argument("--azim", type=int, default=360)
     ap.add_argument("--dist-search", type=float, default=50.0)
-    ap.add_argument("--cpu-rows", type=int, default=4, help="rows of the tile the CPU baseline computes")
+    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the tile the CPU baseline computes (0: cores / 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-count", action="store_true", help="skip the counter pass (roofline.achieved becomes I/O only)")
     return ap.parse_args()
@@ -199,7 +199,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "hz::k_horizon<2,false>", "kernel_ms_per_launch": 1e3 * k_launch_s,
                          "alg_bytes_per_launch": b_io + b_trav, "nodes_per_ray": nodes_per_ray,
-                         "tris_per_ray": tris_per_ray, "mray_per_s_kernel": rays_launch / k_launch_s / 1e6},
+                         "tris_per_ray": tris_per_ray, "mray_per_s_kernel": rays_launch / k_launch_s / 1e6,
+                         "svf_kernel_ms_per_launch": 1e3 * stats.t_svf_s / max(args.steps, 1)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g, args, A)
@@ -215,6 +216,8 @@ def cpu_baseline(g, args, A):
     from oracle import oracle as orc
     kw = {k: g[k] for k in ("vert_grid", "dem_dim_0", "dem_dim_1", "vec_norm", "vec_north", "offset_0", "offset_1")}
     in0 = g["vec_norm"].shape[0]
+    if args.cpu_rows <= 0:      # about 10-30 s of CPU work on the host's cores
+        args.cpu_rows = max(4, orc.num_threads() // 4)
     rb = in0 // 2
     _, _, st = orc.horizon_gridded(**kw, dist_search=args.dist_search, azim_num=A, rows=(rb, rb + args.cpu_rows),
                                    slab_only=True, return_stats=True)

@@ -36,7 +36,8 @@ class hz_stats(C.Structure):
                 ("t_d2h_s", C.c_double), ("t_total_s", C.c_double),
                 ("bvh_height", C.c_int32), ("elev_num", C.c_int32),
                 ("scene_bytes", C.c_uint64), ("wave_node_iters", C.c_uint64),
-                ("wave_leaf_iters", C.c_uint64), ("wave_refills", C.c_uint64)]
+                ("wave_leaf_iters", C.c_uint64), ("wave_refills", C.c_uint64),
+                ("t_svf_s", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -277,26 +277,43 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     a.count_work = opts ? opts->count_work : 0;
     a.counters = (unsigned long long *)cnt_dev;
 
-    hipEvent_t e0, e1;
-    HZ_HIP(hipEventCreate(&e0)); HZ_HIP(hipEventCreate(&e1));
-    HZ_HIP(hipEventRecord(e0, st));
+    // HIP events on the kernels' stream: horizon kernel and SVF kernel are timed separately
+    struct Ev { hipEvent_t a = nullptr, b = nullptr, c = nullptr; };
+    std::vector<Ev> evs;
+    auto free_events = [&]() { for (auto &e : evs) { if (e.a) (void)hipEventDestroy(e.a); if (e.b) (void)hipEventDestroy(e.b); if (e.c) (void)hipEventDestroy(e.c); } };
     for (int rb = row_begin; rb < row_end; rb += chunk_rows) {
         const int re = std::min(rb + chunk_rows, row_end);
         // the kernels index hori by global cell: shift the (slab- or chunk-local) buffer back
         float *hori_chunk = skip_hori ? (float *)tmp_hori : d_hori.dev + (size_t)(rb - row_begin) * dim_in_1 * azim_num;
         a.hori = hori_chunk - (size_t)rb * dim_in_1 * azim_num;
         a.row_begin = rb; a.row_end = re;
+        Ev e;
+        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess || hipEventCreate(&e.c) != hipSuccess) {
+            evs.push_back(e); free_events();
+            return set_error(HZ_ERR_HIP, "hipEventCreate failed");
+        }
+        evs.push_back(e);
+        (void)hipEventRecord(e.a, st);
         rc = horizon_launch(sc, a, st);
+        (void)hipEventRecord(e.b, st);
         if (!rc && want_svf)
             rc = svf_launch(d_azim.dev, hori_chunk, d_tilt.dev + 3 * (size_t)rb * dim_in_1, re - rb, dim_in_1,
                             azim_num, d_svf.dev + (size_t)(rb - row_begin) * dim_in_1, st);
-        if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+        (void)hipEventRecord(e.c, st);
+        if (rc) { (void)hipStreamSynchronize(st); free_events(); return rc; }
     }
-    HZ_HIP(hipEventRecord(e1, st));
-    HZ_HIP(hipEventSynchronize(e1));
-    float ms = 0.0f;
-    HZ_HIP(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    {
+        const hipError_t se = hipStreamSynchronize(st);
+        if (se != hipSuccess) { free_events(); return set_error(HZ_ERR_HIP, "horizon kernel failed: %s", hipGetErrorString(se)); }
+    }
+    float ms = 0.0f, ms_svf = 0.0f;
+    for (auto &e : evs) {
+        float m1 = 0.0f, m2 = 0.0f;
+        (void)hipEventElapsedTime(&m1, e.a, e.b);
+        (void)hipEventElapsedTime(&m2, e.b, e.c);
+        ms += m1; ms_svf += m2;
+    }
+    free_events();
     HZ_HIP(hipGetLastError());
 
     Timer t_d2h; t_d2h.start();
@@ -311,7 +328,8 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         stats->num_rays += cnt[0]; stats->guard_events += cnt[1];
         stats->nodes_visited += cnt[2]; stats->tris_tested += cnt[3]; stats->num_cells += cnt[4];
         stats->wave_node_iters += cnt[5]; stats->wave_leaf_iters += cnt[6]; stats->wave_refills += cnt[7];
-        stats->t_h2d_s += h2d_s; stats->t_kernel_s += (double)ms * 1e-3; stats->t_d2h_s += d2h_s;
+        stats->t_h2d_s += h2d_s; stats->t_kernel_s += (double)ms * 1e-3; stats->t_svf_s += (double)ms_svf * 1e-3;
+        stats->t_d2h_s += d2h_s;
         stats->t_total_s += t_total.stop();
         stats->elev_num = tb.elev_num; stats->bvh_height = sc->hdr.height; stats->scene_bytes = sc->hdr.total_bytes;
     }

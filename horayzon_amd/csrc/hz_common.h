@@ -176,6 +176,20 @@ __device__ __forceinline__ void hz_load_node(const Node *n, float4 &n0, uint4 &n
                  : "memory");
 }
 
+// The same node from the LDS nodelet (4 x ds_read_b128, one wait).
+__device__ __forceinline__ void hz_load_node_lds(const float4 *q, float4 &n0, uint4 &n1, uint4 &n2, int4 &n3) {
+    const unsigned addr = (unsigned)(size_t)reinterpret_cast<const __attribute__((address_space(3))) char *>(
+        (const __attribute__((address_space(3))) float4 *)q);
+    asm volatile("ds_read_b128 %0, %4\n\t"
+                 "ds_read_b128 %1, %4 offset:16\n\t"
+                 "ds_read_b128 %2, %4 offset:32\n\t"
+                 "ds_read_b128 %3, %4 offset:48\n\t"
+                 "s_waitcnt lgkmcnt(0)"
+                 : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3)
+                 : "v"(addr)
+                 : "memory");
+}
+
 // One 48 B leaf record = 3 x 16 B global loads, one wait.
 __device__ __forceinline__ void hz_load_prim(const Prim *q, float4 &q0, float4 &q1, float4 &q2) {
     asm volatile("global_load_dwordx4 %0, %3, off\n\t"
@@ -189,38 +203,42 @@ __device__ __forceinline__ void hz_load_prim(const Prim *q, float4 &q0, float4 &
 
 // ---------------------------------------------------------------------------
 // any-hit traversal of one ray, resumable.
-//   TravState : node (current link), sp (stack pointer), two queued leaves
+//   TravState : node (current link), sp (stack pointer), up to 4 queued leaves
 //   stack     : per-lane LDS stack, entry k of lane tid at stack[k * TPB + tid]
 //   top       : LDS copy of the first ntop nodes (may be null / ntop = 0)
 //   regroup   : leave when fewer than `regroup` lanes of the wave are still traversing
-// Scheduling inside the wave: every lane sets leaves aside (up to 2) and keeps descending;
+// Scheduling inside the wave: every lane sets leaves aside (up to QLEN) and keeps descending;
 // each iteration the wave executes ONE kind of step -- the node step or the leaf step --
 // whichever more lanes are ready for (ballot + popcount vote).  This keeps the 64 lanes
 // busy although neighbouring rays reach their leaves at different times.
 // returns 0 = miss, 1 = hit, 2 = suspended (state is valid, call again)
 // ---------------------------------------------------------------------------
 struct TravCounters { unsigned nodes, tris, w_nodes, w_leaves; };
-struct TravState { int node, sp, lq0, lq1; };
+struct TravState { int node, sp, lq0, lq1, lq2, lq3; };
 
-__device__ __forceinline__ void hz_trav_reset(TravState &t) { t.node = 0; t.sp = 0; t.lq0 = HZ_EMPTY; t.lq1 = HZ_EMPTY; }
+__device__ __forceinline__ void hz_trav_reset(TravState &t) {
+    t.node = 0; t.sp = 0; t.lq0 = HZ_EMPTY; t.lq1 = HZ_EMPTY; t.lq2 = HZ_EMPTY; t.lq3 = HZ_EMPTY;
+}
 
 #define HZ_WAVE_TICK(c, lane_) do { const unsigned long long m_ = __ballot(1); if ((lane_) == __ffsll((long long)m_) - 1) (c)++; } while (0)
 
-template <int TPB, bool COUNT>
+template <int TPB, bool COUNT, int QLEN = 2>
 __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Prim *__restrict__ prims,
                                         const float4 *top, int ntop, int *stack, int tid,
                                         float ox, float oy, float oz, float dx, float dy, float dz, float tfar,
                                         const RayBox &rb, TravState &t, int regroup, int leaf_bias,
                                         TravCounters &cnt) {
     const int lane = tid & 63;
-    int node = t.node, sp = t.sp, lq0 = t.lq0, lq1 = t.lq1;
+    int node = t.node, sp = t.sp, lq0 = t.lq0, lq1 = t.lq1, lq2 = t.lq2, lq3 = t.lq3;
     const int n_entry = __popcll(__ballot(1));   // lanes that entered with a ray
 #define HZ_POP() do { if (sp > 0) { sp--; node = stack[sp * TPB + tid]; } else node = HZ_EMPTY; } while (0)
-#define HZ_SAVE() do { t.node = node; t.sp = sp; t.lq0 = lq0; t.lq1 = lq1; } while (0)
+#define HZ_SAVE() do { t.node = node; t.sp = sp; t.lq0 = lq0; t.lq1 = lq1; t.lq2 = lq2; t.lq3 = lq3; } while (0)
     for (;;) {
-        // set leaves aside while the 2-entry queue has room
+        // set leaves aside while the leaf queue (QLEN entries, filled front to back) has room
         if (node < 0 && node != HZ_EMPTY && lq0 == HZ_EMPTY) { lq0 = node; HZ_POP(); }
         if (node < 0 && node != HZ_EMPTY && lq1 == HZ_EMPTY) { lq1 = node; HZ_POP(); }
+        if (QLEN > 2 && node < 0 && node != HZ_EMPTY && lq2 == HZ_EMPTY) { lq2 = node; HZ_POP(); }
+        if (QLEN > 3 && node < 0 && node != HZ_EMPTY && lq3 == HZ_EMPTY) { lq3 = node; HZ_POP(); }
         const bool can_node = node >= 0;
         const bool can_leaf = lq0 != HZ_EMPTY;
         if (!can_node && !can_leaf) { HZ_SAVE(); return 0; }                  // nothing left: miss
@@ -234,15 +252,10 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
             // ---------------- node step ------------------------------------------------------
             if (can_node) {
                 float4 n0; uint4 n1, n2; int4 n3;
-                if (ntop > 0 && __all(node < ntop)) {   // all stepping lanes inside the LDS nodelet
-                    const float4 *q = top + 4 * node;
-                    n0 = q[0];
-                    n1 = *reinterpret_cast<const uint4 *>(q + 1);
-                    n2 = *reinterpret_cast<const uint4 *>(q + 2);
-                    n3 = *reinterpret_cast<const int4 *>(q + 3);
-                } else {
-                    hz_load_node(nodes + node, n0, n1, n2, n3);
-                }
+                // top-of-tree nodelet from LDS, the rest from global memory.  Two separate asm paths:
+                // a per-lane pointer select would be compiled into (slow) flat loads.
+                if (node < ntop) hz_load_node_lds(top + 4 * node, n0, n1, n2, n3);
+                else hz_load_node(nodes + node, n0, n1, n2, n3);
                 if (COUNT) { cnt.nodes++; HZ_WAVE_TICK(cnt.w_nodes, lane); }
                 const NodeRay nr = hz_node_ray(rb, n0.x, n0.y, n0.z, __float_as_uint(n0.w));
                 const bool h0 = hz_qbox_hit(nr, tfar, n1.x, n2.x);
@@ -275,7 +288,7 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
                 if (!hit && (q2.y == q2.y))
                     hit = hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, q0.w, q1.x, q1.y, q2.y, q2.z, q2.w, q1.z, q1.w, q2.x);
                 if (hit) { HZ_SAVE(); return 1; }
-                lq0 = lq1; lq1 = HZ_EMPTY;
+                lq0 = lq1; lq1 = lq2; lq2 = lq3; lq3 = HZ_EMPTY;
             }
         }
     }

@@ -309,7 +309,13 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
     // stack: at most 3 pending siblings per 4-wide level
     const int depth = 3 * std::max(sc->hdr.height, 1);
     p.stack_bytes = depth * HZ_TPB * 4;
-    int top = (a.top_nodes < 0) ? 0 : a.top_nodes;
+    // LDS nodelet: whatever LDS is left at the workgroup residency the stacks allow (160 KiB per CU)
+    int top = a.top_nodes;
+    if (top < 0) {
+        const int lds_cu = 160 * 1024;
+        const int blocks = std::max(1, std::min(8, lds_cu / std::max(p.stack_bytes, 1)));
+        top = std::max(0, (lds_cu / blocks - p.stack_bytes) / (int)sizeof(Node));
+    }
     top = std::min(top, sc->hdr.n_top);
     p.top_nodes = top;
     // defaults from the sweep on the 3601^2 tile: refill when fewer than 48 lanes

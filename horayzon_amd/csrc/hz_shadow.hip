@@ -166,7 +166,13 @@ int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st) {
     p.refrac = a.refrac_cor; p.which = a.which;
     p.out_u8 = a.out_u8; p.out_f32 = a.out_f32;
     p.stack_bytes = 3 * std::max(sc->hdr.height, 1) * HZ_TPB * 4;
-    int top = (a.top_nodes < 0) ? 0 : a.top_nodes;
+    // LDS nodelet: whatever LDS is left at the workgroup residency the stacks allow (160 KiB per CU)
+    int top = a.top_nodes;
+    if (top < 0) {
+        const int lds_cu = 160 * 1024;
+        const int blocks = std::max(1, std::min(8, lds_cu / std::max(p.stack_bytes, 1)));
+        top = std::max(0, (lds_cu / blocks - p.stack_bytes) / (int)sizeof(Node));
+    }
     top = std::min(top, sc->hdr.n_top);
     p.top_nodes = top;
     p.counters = a.counters;

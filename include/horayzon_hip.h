@@ -70,6 +70,7 @@ typedef struct hz_stats {
     uint64_t wave_node_iters; /* count_work: wave-level executions of the node  */
     uint64_t wave_leaf_iters; /*   step / leaf step / ray refill section (SIMT  */
     uint64_t wave_refills;    /*   efficiency = lane count / (64 x wave count)) */
+    double t_svf_s;        /* sky-view-factor kernel (when opts.svf is set)    */
 } hz_stats;
 
 const char *hz_last_error(void);
