@@ -64,8 +64,13 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
-    if world > 1:
+    # HZ_FORCE_DIST=1 runs the multi-rank code path (RCCL broadcast of the scene, gather, all-reduce)
+    # even with a single rank -- used to exercise it on a 1-GPU box
+    use_dist = world > 1 or bool(os.environ.get("HZ_FORCE_DIST"))
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device(dev))
     L = _lib.lib()
 
@@ -78,7 +83,7 @@ def main():
     t_build = time.time() - t0
     scene_stats = scene.stats if scene is not None else None
     t_bcast = 0.0
-    if world > 1:
+    if use_dist:
         torch.cuda.synchronize(); dist.barrier()
         t0 = time.time()
         scene = broadcast_scene(scene, local_rank, src=0)
@@ -121,7 +126,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -145,12 +150,12 @@ def main():
     for s in range(args.steps):
         step(args.warmup + s)
     svf_full = None
-    if world > 1:   # final gather of the per-rank SVF rows touched in the last step (4 B / cell)
+    if use_dist:    # final gather of the per-rank SVF rows touched in the last step (4 B / cell)
         rb = ((args.warmup + args.steps - 1) * world + rank) % n_slabs * rps
         gather_rows(d_svf[rb:rb + rps], [(0, rps)] * world, dst=0)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -205,7 +210,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g, args, A)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
