@@ -47,7 +47,8 @@ class hz_stats(C.Structure):
 SYMBOLS = (
     "hz_last_error", "hz_abi_struct_sizes", "hz_device_count", "hz_device_info",
     "hz_scene_create", "hz_scene_blob", "hz_scene_adopt", "hz_scene_destroy",
-    "hz_horizon_gridded", "hz_horizon_gridded_scene", "hz_horizon_tables",
+    "hz_horizon_gridded", "hz_horizon_gridded_scene", "hz_horizon_locations",
+    "hz_horizon_locations_scene", "hz_horizon_tables",
     "hz_sky_view_factor",
     "hz_terrain_create", "hz_terrain_initialise", "hz_terrain_initialise_scene",
     "hz_terrain_shadow", "hz_terrain_sw_dir_cor", "hz_terrain_shadow_batch",
@@ -105,6 +106,12 @@ def lib():
     L.hz_horizon_gridded_scene.argtypes = [
         vp, vp, vp, ip, ip, vp, ip, ip, ip, C.c_float, C.c_float, C.c_char_p,
         C.c_float, vp, C.c_float, C.c_float, C.POINTER(hz_opts), C.POINTER(hz_stats)]
+    L.hz_horizon_locations.argtypes = [
+        vp, ip, ip, vp, vp, vp, vp, vp, ip, ip, C.c_float, C.c_float, C.c_char_p, C.c_char_p,
+        C.c_float, vp, ip, C.POINTER(hz_opts), C.POINTER(hz_stats)]
+    L.hz_horizon_locations_scene.argtypes = [
+        vp, vp, vp, vp, vp, vp, ip, ip, C.c_float, C.c_float, C.c_char_p, C.c_float, vp, ip,
+        C.POINTER(hz_opts), C.POINTER(hz_stats)]
     L.hz_horizon_tables.argtypes = [ip, C.c_float, C.c_float, vp, vp, ip, vp, vp, vp,
                                     C.POINTER(C.c_int)]
     L.hz_sky_view_factor.argtypes = [vp, vp, vp, ip, ip, ip, vp, ip]

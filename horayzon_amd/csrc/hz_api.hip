@@ -343,6 +343,93 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     return HZ_OK;
 }
 
+static int locations_run(const Scene *sc, const float *coords, const float *vec_norm, const float *vec_north,
+                         float *hori_buffer, float *hori_dist_buffer, int num_loc, int azim_num,
+                         float dist_search, float hori_acc, const char *ray_algorithm, float elev_ang_low_lim,
+                         const float *ray_org_elev, int hori_dist_out, const hz_opts *opts, hz_stats *stats) {
+    int alg = 1;
+    int rc = parse_alg(ray_algorithm, &alg);
+    if (rc) return rc;
+    if (hori_dist_out && alg == 2)
+        return set_error(HZ_ERR_ARG, "horizon detection algorithm 'guess_constant' not implemented for horizon "
+                                     "distance computation");
+    if (!coords || !vec_norm || !vec_north || !ray_org_elev || !hori_buffer) return set_error(HZ_ERR_ARG, "NULL argument");
+    if (hori_dist_out && !hori_dist_buffer) return set_error(HZ_ERR_ARG, "hori_dist_buffer is NULL");
+    if (num_loc <= 0 || azim_num <= 0) return set_error(HZ_ERR_ARG, "num_loc and azim_num must be positive");
+    if (!(hori_acc > 0.0f) || hori_acc > 10.0f) return set_error(HZ_ERR_ARG, "limit of hori_acc (10 degree) is exceeded");
+    HZ_HIP(hipSetDevice(sc->device));
+    hipStream_t st = sc->stream;
+    Timer t_total; t_total.start();
+    HostTables tb;
+    build_tables(azim_num, hori_acc, elev_ang_low_lim, tb);
+    if (tb.elev_num < 2) return set_error(HZ_ERR_ARG, "elevation table is empty (elev_ang_low_lim too high)");
+    Timer t_h2d; t_h2d.start();
+    DevIn<float> d_co, d_norm, d_north, d_roe, d_as, d_ac, d_ea, d_es, d_ec;
+    const size_t n = (size_t)num_loc;
+    if ((rc = d_co.bind(coords, n * 3, st))) return rc;
+    if ((rc = d_norm.bind(vec_norm, n * 3, st))) return rc;
+    if ((rc = d_north.bind(vec_north, n * 3, st))) return rc;
+    if ((rc = d_roe.bind(ray_org_elev, n, st))) return rc;
+    if ((rc = d_as.bind(tb.azim_sin.data(), (size_t)azim_num, st))) return rc;
+    if ((rc = d_ac.bind(tb.azim_cos.data(), (size_t)azim_num, st))) return rc;
+    if ((rc = d_ea.bind(tb.elev_ang.data(), (size_t)tb.elev_num, st))) return rc;
+    if ((rc = d_es.bind(tb.elev_sin.data(), (size_t)tb.elev_num, st))) return rc;
+    if ((rc = d_ec.bind(tb.elev_cos.data(), (size_t)tb.elev_num, st))) return rc;
+    // outputs are read-modify-write (untouched rows keep the caller's NaN): copy them in first
+    DevOut<float> d_hori, d_dist;
+    if ((rc = d_hori.bind(hori_buffer, n * (size_t)azim_num))) return rc;
+    if (d_hori.host) HZ_HIP(hipMemcpyAsync(d_hori.dev, hori_buffer, n * (size_t)azim_num * 4, hipMemcpyHostToDevice, st));
+    if (hori_dist_out) {
+        if ((rc = d_dist.bind(hori_dist_buffer, n * (size_t)azim_num))) return rc;
+        if (d_dist.host) HZ_HIP(hipMemcpyAsync(d_dist.dev, hori_dist_buffer, n * (size_t)azim_num * 4, hipMemcpyHostToDevice, st));
+    }
+    DevIn<unsigned long long> d_cnt;
+    unsigned long long zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void *cnt_dev = nullptr;
+    HZ_HIP(hipMalloc(&cnt_dev, sizeof(zeros)));
+    d_cnt.owned = cnt_dev;
+    HZ_HIP(hipMemcpyAsync(cnt_dev, zeros, sizeof(zeros), hipMemcpyHostToDevice, st));
+    HZ_HIP(hipStreamSynchronize(st));
+    const double h2d_s = t_h2d.stop();
+
+    LocationsArgs a;
+    a.coords = d_co.dev; a.vec_norm = d_norm.dev; a.vec_north = d_north.dev; a.ray_org_elev = d_roe.dev;
+    a.hori = d_hori.dev; a.dist = d_dist.dev;
+    a.num_loc = num_loc; a.azim_num = azim_num; a.elev_num = tb.elev_num; a.alg = alg; a.hori_dist_out = hori_dist_out;
+    a.hori_acc = tb.hori_acc; a.low = tb.low; a.up = tb.up; a.dist_m = (float)((double)dist_search * 1000.0);
+    a.azim_sin = d_as.dev; a.azim_cos = d_ac.dev; a.elev_ang = d_ea.dev; a.elev_sin = d_es.dev; a.elev_cos = d_ec.dev;
+    a.counters = (unsigned long long *)cnt_dev;
+    hipEvent_t e0, e1;
+    HZ_HIP(hipEventCreate(&e0)); HZ_HIP(hipEventCreate(&e1));
+    (void)hipEventRecord(e0, st);
+    rc = locations_launch(sc, a, st);
+    (void)hipEventRecord(e1, st);
+    const hipError_t se = hipStreamSynchronize(st);
+    float ms = 0.0f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (rc) return rc;
+    if (se != hipSuccess) return set_error(HZ_ERR_HIP, "locations kernel failed: %s", hipGetErrorString(se));
+    Timer t_d2h; t_d2h.start();
+    unsigned long long cnt[8];
+    HZ_HIP(hipMemcpyAsync(cnt, cnt_dev, sizeof(cnt), hipMemcpyDeviceToHost, st));
+    if ((rc = d_hori.finish(st))) return rc;
+    if ((rc = d_dist.finish(st))) return rc;
+    HZ_HIP(hipStreamSynchronize(st));
+    if (stats) {
+        stats->num_rays += cnt[0]; stats->guard_events += cnt[1]; stats->num_cells += cnt[4];
+        stats->t_h2d_s += h2d_s; stats->t_kernel_s += (double)ms * 1e-3; stats->t_d2h_s += t_d2h.stop();
+        stats->t_total_s += t_total.stop();
+        stats->elev_num = tb.elev_num; stats->bvh_height = sc->hdr.height; stats->scene_bytes = sc->hdr.total_bytes;
+    }
+    if (opts && opts->verbose) {
+        printf("Number of locations for which horizon is computed: %d \n", num_loc);
+        printf("Ray tracing time: %g s\n", (double)ms * 1e-3);
+        printf("Number of rays shot: %llu\n", cnt[0]);
+    }
+    return HZ_OK;
+}
+
 }  // namespace hz
 
 using namespace hz;
@@ -452,6 +539,39 @@ int hz_horizon_gridded(const float *vert_grid, int dem_dim_0, int dem_dim_1, con
     hz_scene_destroy(scene);   // the reference also releases the scene per call, horizon_comp.cpp:813-814
     local.t_total_s = t.stop();
     if (opts && opts->verbose) printf("Total run time: %g s\n", local.t_total_s);
+    if (stats) *stats = local;
+    return rc;
+}
+
+int hz_horizon_locations_scene(const hz_scene *scene, const float *coords, const float *vec_norm,
+                               const float *vec_north, float *hori_buffer, float *hori_dist_buffer, int num_loc,
+                               int azim_num, float dist_search, float hori_acc, const char *ray_algorithm,
+                               float elev_ang_low_lim, const float *ray_org_elev, int hori_dist_out,
+                               const hz_opts *opts, hz_stats *stats) {
+    if (!scene) return set_error(HZ_ERR_ARG, "scene is NULL");
+    return locations_run(reinterpret_cast<const Scene *>(scene), coords, vec_norm, vec_north, hori_buffer,
+                         hori_dist_buffer, num_loc, azim_num, dist_search, hori_acc, ray_algorithm,
+                         elev_ang_low_lim, ray_org_elev, hori_dist_out, opts, stats);
+}
+
+int hz_horizon_locations(const float *vert_grid, int dem_dim_0, int dem_dim_1, const float *coords,
+                         const float *vec_norm, const float *vec_north, float *hori_buffer,
+                         float *hori_dist_buffer, int num_loc, int azim_num, float dist_search, float hori_acc,
+                         const char *ray_algorithm, const char *geom_type, float elev_ang_low_lim,
+                         const float *ray_org_elev, int hori_dist_out, const hz_opts *opts, hz_stats *stats) {
+    Timer t; t.start();
+    hz_scene *scene = nullptr;
+    hz_stats local;
+    memset(&local, 0, sizeof(local));
+    // no simplified outer mesh for locations: horizon_comp.cpp:848-852
+    int rc = hz_scene_create(vert_grid, dem_dim_0, dem_dim_1, geom_type, nullptr, 0, nullptr, 0,
+                             opts ? opts->device : 0, &scene, &local);
+    if (rc) return rc;
+    rc = hz_horizon_locations_scene(scene, coords, vec_norm, vec_north, hori_buffer, hori_dist_buffer, num_loc,
+                                    azim_num, dist_search, hori_acc, ray_algorithm, elev_ang_low_lim, ray_org_elev,
+                                    hori_dist_out, opts, &local);
+    hz_scene_destroy(scene);
+    local.t_total_s = t.stop();
     if (stats) *stats = local;
     return rc;
 }

@@ -112,6 +112,25 @@ __device__ __forceinline__ bool hz_tri_hit(float ox, float oy, float oz,
     return true;
 }
 
+// closest-hit variant (rtcIntersect1): same acceptance test; t = T / den as one IEEE division
+__device__ __forceinline__ bool hz_tri_hit_t(float ox, float oy, float oz, float dx, float dy, float dz,
+                                             float tfar, float p0x, float p0y, float p0z, float p1x,
+                                             float p1y, float p1z, float p2x, float p2y, float p2z, float *t) {
+    if (!hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, p0x, p0y, p0z, p1x, p1y, p1z, p2x, p2y, p2z)) return false;
+    const float v0x = p0x - ox, v0y = p0y - oy, v0z = p0z - oz;
+    const float v1x = p1x - ox, v1y = p1y - oy, v1z = p1z - oz;
+    const float v2x = p2x - ox, v2y = p2y - oy, v2z = p2z - oz;
+    const float e0x = v2x - v0x, e0y = v2y - v0y, e0z = v2z - v0z;
+    const float e1x = v0x - v1x, e1y = v0y - v1y, e1z = v0z - v1z;
+    const float nx = e1y * e0z - e1z * e0y;
+    const float ny = e1z * e0x - e1x * e0z;
+    const float nz = e1x * e0y - e1y * e0x;
+    const float den = (nx * dx + ny * dy) + nz * dz;
+    const float T = (v0x * nx + v0y * ny) + v0z * nz;
+    *t = T / den;
+    return true;
+}
+
 // ---------------------------------------------------------------------------
 // per-ray constants for the conservative slab test (centred frame)
 // ---------------------------------------------------------------------------
@@ -294,6 +313,51 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
     }
 #undef HZ_POP
 #undef HZ_SAVE
+}
+
+// ---------------------------------------------------------------------------
+// closest hit of one ray (rtcIntersect1 semantics): the minimum t over ALL triangles accepted
+// with the caller's tfar, so the result does not depend on the visiting order; boxes are pruned
+// conservatively against the best t so far.  Plain per-lane loop (used for a handful of rays
+// per location, not the throughput path).  Returns true and *dist when anything was hit.
+// ---------------------------------------------------------------------------
+template <int TPB>
+__device__ __forceinline__ bool hz_closest(const Node *__restrict__ nodes, const Prim *__restrict__ prims,
+                                           int *stack, int tid, float ox, float oy, float oz, float dx,
+                                           float dy, float dz, float tfar, const RayBox &rb, float *dist) {
+    int node = 0, sp = 0;
+    float best = __builtin_inff();
+    bool any = false;
+    while (node != HZ_EMPTY) {
+        if (node >= 0) {
+            float4 n0; uint4 n1, n2; int4 n3;
+            hz_load_node(nodes + node, n0, n1, n2, n3);
+            const float tf = any ? __builtin_fminf(tfar, best * 1.0001f) : tfar;
+            const NodeRay nr = hz_node_ray(rb, n0.x, n0.y, n0.z, __float_as_uint(n0.w));
+            const bool h0 = hz_qbox_hit(nr, tf, n1.x, n2.x), h1 = hz_qbox_hit(nr, tf, n1.y, n2.y);
+            const bool h2 = hz_qbox_hit(nr, tf, n1.z, n2.z), h3 = hz_qbox_hit(nr, tf, n1.w, n2.w);
+            int next = HZ_EMPTY;
+            if (h3) next = n3.w;
+            if (h2) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = n3.z; }
+            if (h1) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = n3.y; }
+            if (h0) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = n3.x; }
+            if (next != HZ_EMPTY) { node = next; continue; }
+        } else {
+            float4 q0, q1, q2;
+            hz_load_prim(prims + (~node), q0, q1, q2);
+            float t;
+            if (hz_tri_hit_t(ox, oy, oz, dx, dy, dz, tfar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, &t)) {
+                any = true; best = __builtin_fminf(best, t);
+            }
+            if ((q2.y == q2.y) &&
+                hz_tri_hit_t(ox, oy, oz, dx, dy, dz, tfar, q0.w, q1.x, q1.y, q2.y, q2.z, q2.w, q1.z, q1.w, q2.x, &t)) {
+                any = true; best = __builtin_fminf(best, t);
+            }
+        }
+        if (sp > 0) { sp--; node = stack[sp * TPB + tid]; } else node = HZ_EMPTY;
+    }
+    if (any) *dist = best;
+    return any;
 }
 
 #endif  // __HIPCC__

@@ -85,6 +85,17 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st);
 int svf_launch(const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
                int len_2, float *svf, hipStream_t st);
 
+// hz_locations.hip
+struct LocationsArgs {
+    const float *coords, *vec_norm, *vec_north, *ray_org_elev;   // device
+    float *hori, *dist;                                           // device; dist may be null
+    int num_loc, azim_num, elev_num, alg, hori_dist_out;
+    float hori_acc, low, up, dist_m;
+    const float *azim_sin, *azim_cos, *elev_ang, *elev_sin, *elev_cos;
+    unsigned long long *counters;
+};
+int locations_launch(const Scene *sc, const LocationsArgs &a, hipStream_t st);
+
 // hz_shadow.hip
 struct ShadowArgs {
     const float *vec_tilt, *vec_norm, *surf_enl_fac, *elevation;   // device

@@ -1,0 +1,133 @@
+// hz_search.h -- the reference's per-cell horizon search algorithms as a resumable per-lane
+// state machine (ray_discrete_sampling / ray_binary_search / ray_guess_const,
+// horizon_comp.cpp:302-498, and the *_hori_dist variants :519-612).  Shared by the gridded
+// and the locations kernels.  The float/double promotion pattern of the reference's index
+// arithmetic is reproduced exactly; tables are built on the host (hz_api.hip) and only read here.
+#pragma once
+#include "hz_internal.h"
+
+namespace hz {
+
+enum { ALG_DISCRETE = 0, ALG_BINARY = 1, ALG_GUESS = 2 };
+enum { PH_NEWAZ = 0, PH_BIN = 1, PH_UP = 2, PH_DOWN = 3 };
+
+struct Tables {
+    const float *azim_sin, *azim_cos, *elev_ang, *elev_sin, *elev_cos;
+    int azim_num, elev_num;
+    float hori_acc, low, up;
+    double step;   // (double)hori_acc / 5.0
+};
+
+struct Search {
+    int k, phase, ind, prev, pazim, count;
+    float lim_up, lim_low, elev_samp;
+};
+
+// (int)roundf((elev_samp - low) / (hori_acc / 5.0)), horizon_comp.cpp:351-352
+__device__ __forceinline__ int ind_of(const Tables &t, float elev_samp) {
+    return (int)__builtin_roundf((float)((double)(elev_samp - t.low) / t.step));
+}
+// (a + b) / 2.0 -> float, horizon_comp.cpp:350, :330, :462, :490
+__device__ __forceinline__ float half_sum(float a, float b) {
+    return (float)((double)(a + b) / 2.0);
+}
+
+// per-cell output sink
+struct Sink {
+    float *hori;         // &hori_buffer[cell * azim_num]
+    float *dist;         // &hori_dist_buffer[cell * azim_num] or null
+    float dist_hit;      // distance of the last hit ray; persists across azimuths (horizon_comp.cpp:526-527)
+};
+
+__device__ __forceinline__ void emit(Sink &s, const Tables &, int k, float h) {
+    s.hori[k] = h;
+    if (s.dist) s.dist[k] = s.dist_hit;   // :552, :608
+}
+
+// Consume the result of the previous ray (if any) and produce the next sample.
+// Returns true with s.ind / s.k identifying the next ray, false when the cell is finished.
+template <int ALG>
+__device__ __forceinline__ bool advance(Search &s, bool hit, const Tables &t, Sink &out,
+                                        unsigned &guards) {
+    const int top = t.elev_num - 1;
+    for (;;) {
+        if (s.phase == PH_NEWAZ) {
+            if (s.k >= t.azim_num) return false;
+            const bool binary = (ALG == ALG_BINARY) || (ALG == ALG_GUESS && s.k == 0);
+            if (binary) {                                   // horizon_comp.cpp:348-354 / :398-404
+                s.lim_up = t.up; s.lim_low = t.low;
+                s.elev_samp = half_sum(s.lim_up, s.lim_low);
+                s.ind = ind_of(t, s.elev_samp);
+                s.phase = PH_BIN;
+                const float e = t.elev_ang[s.ind];
+                if (__builtin_fmaxf(s.lim_up - e, e - s.lim_low) > t.hori_acc) return true;
+                emit(out, t, s.k, s.elev_samp);
+                s.pazim = s.ind; s.k++; s.phase = PH_NEWAZ;
+                continue;
+            }
+            // move upwards: horizon_comp.cpp:311-317 (discrete, from index 0) / :439-446
+            s.ind = (ALG == ALG_DISCRETE) ? 0 : max(s.pazim - 5, 0);
+            s.prev = s.ind;
+            s.ind = min(s.ind + 10, top);
+            s.count = 1;
+            s.phase = PH_UP;
+            return true;
+        }
+        if (s.phase == PH_BIN) {                             // :367-374 / :417-424
+            const float e0 = t.elev_ang[s.ind];
+            if (hit) s.lim_low = e0; else s.lim_up = e0;
+            s.elev_samp = half_sum(s.lim_up, s.lim_low);
+            s.ind = ind_of(t, s.elev_samp);
+            const float e = t.elev_ang[s.ind];
+            if (__builtin_fmaxf(s.lim_up - e, e - s.lim_low) > t.hori_acc) return true;
+            emit(out, t, s.k, s.elev_samp);                  // :376 / :428
+            s.pazim = s.ind; s.k++; s.phase = PH_NEWAZ;
+            continue;
+        }
+        if (s.phase == PH_UP) {
+            const bool guard = hit && (s.ind == top);        // the reference never leaves this loop
+            if (hit && !guard) {
+                s.prev = s.ind;
+                s.ind = min(s.ind + 10, top);
+                s.count++;
+                return true;
+            }
+            if (guard) guards++;
+            if (ALG == ALG_DISCRETE) {                       // :330
+                emit(out, t, s.k, half_sum(t.elev_ang[s.prev], t.elev_ang[s.ind]));
+                s.k++; s.phase = PH_NEWAZ;
+                continue;
+            }
+            if (s.count > 1) {                               // :460-467
+                const float es = half_sum(t.elev_ang[s.prev], t.elev_ang[s.ind]);
+                s.ind = ind_of(t, es);
+                emit(out, t, s.k, t.elev_ang[s.ind]);
+                s.pazim = s.ind; s.k++; s.phase = PH_NEWAZ;
+                continue;
+            }
+            // move downwards: :472-477
+            s.ind = min(s.pazim + 5, top);
+            s.prev = s.ind;
+            s.ind = max(s.ind - 10, 0);
+            s.phase = PH_DOWN;
+            return true;
+        }
+        // PH_DOWN: :474-488
+        {
+            const bool guard = (!hit) && (s.ind == 0);
+            if (!hit && !guard) {
+                s.prev = s.ind;
+                s.ind = max(s.ind - 10, 0);
+                return true;
+            }
+            if (guard) guards++;
+            const float es = half_sum(t.elev_ang[s.prev], t.elev_ang[s.ind]);   // :490-494
+            s.ind = ind_of(t, es);
+            emit(out, t, s.k, t.elev_ang[s.ind]);
+            s.pazim = s.ind; s.k++; s.phase = PH_NEWAZ;
+            continue;
+        }
+    }
+}
+
+}  // namespace hz

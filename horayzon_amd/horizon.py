@@ -166,6 +166,105 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
     return hori_buffer, azim
 
 
+def horizon_locations(vert_grid, dem_dim_0, dem_dim_1, coords, vec_norm, vec_north,
+                      dist_search, azim_num=360, hori_acc=0.25,
+                      ray_algorithm="binary_search", geom_type="grid",
+                      elev_ang_low_lim=-89.98,
+                      ray_org_elev=np.array([0.01], dtype=np.float32),
+                      hori_dist_out=False, *, device=0, verbose=False, scene=None):
+    """Horizon computation for arbitrary locations.
+
+    Parameters, units and return values are those of the reference
+    (horizon.pyx:233-276): returns ``hori_buffer`` float32 (number of locations,
+    azim_num) [radian] and ``azim``; with ``hori_dist_out`` also the distance to the
+    horizon [metre] as second value.  Keyword-only extras: ``device``, ``verbose``, ``scene``."""
+    global last_stats
+    _check_f32(vert_grid, 1, "vert_grid")
+    _check_f32(coords, 2, "coords")
+    _check_f32(vec_norm, 2, "vec_norm")
+    _check_f32(vec_north, 2, "vec_north")
+    _check_f32(ray_org_elev, 1, "ray_org_elev")
+
+    # Check consistency and validity of input arguments (horizon.pyx:279-307)
+    if len(vert_grid) < (dem_dim_0 * dem_dim_1 * 3):
+        raise ValueError("inconsistency between input arguments vert_grid, "
+                         "dem_dim_0 and dem_dim_1")
+    if ((coords.ndim != 2) or (coords.shape[0] != vec_norm.shape[0])
+            or (coords.shape[1] != 3)):
+        raise ValueError("'number of dimensions and/or dimension "
+                         + "length(s) of 'coords' incorrect")
+    if ((vec_norm.ndim != 2) or (vec_north.ndim != 2)
+            or (vec_norm.shape[0] != vec_north.shape[0])
+            or (vec_norm.shape[1] != vec_north.shape[1])):
+        raise ValueError("dimension (lengths) of vec_norm and/or vec_north "
+                         "is/are erroneous")
+    if ray_algorithm not in ("discrete_sampling", "binary_search",
+                             "guess_constant"):
+        raise ValueError("invalid input argument for ray_algorithm")
+    if geom_type not in ("triangle", "quad", "grid"):
+        raise ValueError("invalid input argument for geom_type")
+    if hori_acc > 10.0:
+        raise ValueError("limit of hori_acc (10 degree) is exceeded")
+    if (len(ray_org_elev) != 1) and (len(ray_org_elev) != coords.shape[0]):
+        raise ValueError("length of array 'ray_org_elev' must be either "
+                         + "one or correspond to the number of locations")
+    if ray_org_elev.min() < 0.005:
+        raise TypeError("minimal allowed value for 'ray_org_elev' is 0.005 m")
+    if hori_dist_out and (ray_algorithm == "guess_constant"):
+        raise TypeError("horizon detection algorithm 'guess_constant' not "
+                        + "implemented for horizon distance computation")
+
+    # Check size of input geometries (horizon.pyx:310-312)
+    if (dem_dim_0 > 32767) or (dem_dim_1 > 32767):
+        raise ValueError("maximal allowed input length for dem_dim_0 and "
+                         "dem_dim_1 is 32'767")
+
+    # Repeat array 'ray_org_elev' if necessary (horizon.pyx:315-316)
+    if len(ray_org_elev) != coords.shape[0]:
+        ray_org_elev = np.repeat(ray_org_elev, coords.shape[0])
+
+    vert_grid = np.ascontiguousarray(vert_grid)
+    coords = np.ascontiguousarray(coords)
+    vec_norm = np.ascontiguousarray(vec_norm)
+    vec_north = np.ascontiguousarray(vec_north)
+    ray_org_elev = np.ascontiguousarray(ray_org_elev)
+
+    num_loc = vec_norm.shape[0]
+    hori_buffer = np.empty((num_loc, azim_num), dtype=np.float32)
+    hori_buffer.fill(np.nan)
+    hori_dist_buffer = np.empty((num_loc if hori_dist_out else 1, azim_num), dtype=np.float32)
+    hori_dist_buffer.fill(np.nan)
+
+    opts = hz_opts()
+    opts.device = device if scene is None else scene.device
+    opts.verbose = int(bool(verbose))
+    stats = hz_stats()
+    L = _lib.lib()
+    if scene is None:
+        rc = L.hz_horizon_locations(
+            ptr(vert_grid), dem_dim_0, dem_dim_1, ptr(coords), ptr(vec_norm), ptr(vec_north),
+            ptr(hori_buffer), ptr(hori_dist_buffer) if hori_dist_out else None, num_loc, azim_num,
+            dist_search, hori_acc, ray_algorithm.encode("utf-8"), geom_type.encode("utf-8"),
+            elev_ang_low_lim, ptr(ray_org_elev), int(bool(hori_dist_out)), C.byref(opts), C.byref(stats))
+    else:
+        rc = L.hz_horizon_locations_scene(
+            scene._h, ptr(coords), ptr(vec_norm), ptr(vec_north), ptr(hori_buffer),
+            ptr(hori_dist_buffer) if hori_dist_out else None, num_loc, azim_num, dist_search, hori_acc,
+            ray_algorithm.encode("utf-8"), elev_ang_low_lim, ptr(ray_org_elev), int(bool(hori_dist_out)),
+            C.byref(opts), C.byref(stats))
+    _lib.check(rc)
+    last_stats = stats.as_dict()
+
+    azim = np.empty(azim_num, dtype=np.float32)
+    for i in range(azim_num):
+        azim[i] = ((2 * np.pi) / azim_num * i)
+
+    if hori_dist_out:
+        return hori_buffer, hori_dist_buffer, azim
+    else:
+        return hori_buffer, azim
+
+
 def horizon_tables(azim_num, hori_acc, elev_ang_low_lim):
     """The trig tables the library builds on the host (for bit-for-bit checks)."""
     L = _lib.lib()

@@ -130,6 +130,27 @@ int hz_horizon_gridded_scene(const hz_scene *scene,
                              float hori_fill, float ray_org_elev,
                              const hz_opts *opts, hz_stats *stats);
 
+/* Horizon (and optionally distance to the horizon) for arbitrary locations; argument list     */
+/* mirrors horizon_locations_comp (horizon_comp.h:22-34, horizon_comp.cpp:828-1094).           */
+/* coords f32[num_loc][3], vec_norm / vec_north f32[num_loc][3], ray_org_elev f32[num_loc],    */
+/* hori_buffer f32[num_loc][azim_num]; hori_dist_buffer f32[num_loc][azim_num] is only written */
+/* when hori_dist_out != 0 (may be NULL otherwise).  Locations whose normal never meets the    */
+/* mesh keep the caller's values (the reference pre-fills NaN, horizon.pyx:331-341).           */
+int hz_horizon_locations(const float *vert_grid, int dem_dim_0, int dem_dim_1,
+                         const float *coords, const float *vec_norm, const float *vec_north,
+                         float *hori_buffer, float *hori_dist_buffer, int num_loc,
+                         int azim_num, float dist_search, float hori_acc,
+                         const char *ray_algorithm, const char *geom_type,
+                         float elev_ang_low_lim, const float *ray_org_elev, int hori_dist_out,
+                         const hz_opts *opts, hz_stats *stats);
+int hz_horizon_locations_scene(const hz_scene *scene,
+                               const float *coords, const float *vec_norm, const float *vec_north,
+                               float *hori_buffer, float *hori_dist_buffer, int num_loc,
+                               int azim_num, float dist_search, float hori_acc,
+                               const char *ray_algorithm, float elev_ang_low_lim,
+                               const float *ray_org_elev, int hori_dist_out,
+                               const hz_opts *opts, hz_stats *stats);
+
 /* Trig tables exactly as horizon_comp.cpp:711-731 builds them (host side;     */
 /* exported so tests can compare them bit for bit with the oracle).            */
 /* Returns elev_num through *elev_num; arrays may be NULL to query the size.   */

@@ -156,6 +156,25 @@ static inline int tri_hit_f(const float *o, const float *d, float tfar,
     return 1;
 }
 
+/* closest-hit variant (rtcIntersect1, horizon_comp.cpp:268-292): same acceptance test, and the
+ * hit distance t = T / den as one IEEE float division.  Returns 1 and *t when accepted.           */
+static inline int tri_hit_t_f(const float *o, const float *d, float tfar,
+                              const float *p0, const float *p1, const float *p2, float *t) {
+    const float v0x = p0[0] - o[0], v0y = p0[1] - o[1], v0z = p0[2] - o[2];
+    const float v1x = p1[0] - o[0], v1y = p1[1] - o[1], v1z = p1[2] - o[2];
+    const float v2x = p2[0] - o[0], v2y = p2[1] - o[1], v2z = p2[2] - o[2];
+    const float e0x = v2x - v0x, e0y = v2y - v0y, e0z = v2z - v0z;
+    const float e1x = v0x - v1x, e1y = v0y - v1y, e1z = v0z - v1z;
+    const float nx = e1y * e0z - e1z * e0y;
+    const float ny = e1z * e0x - e1x * e0z;
+    const float nz = e1x * e0y - e1y * e0x;
+    if (!tri_hit_f(o, d, tfar, p0, p1, p2)) return 0;
+    const float den = (nx * d[0] + ny * d[1]) + nz * d[2];
+    const float T = (v0x * nx + v0y * ny) + v0z * nz;
+    *t = T / den;
+    return 1;
+}
+
 /* same algebra in double, zero tolerance: geometric reference for diagnostics */
 static inline int tri_hit_d(const float *of, const float *df, float tfarf,
                             const float *p0, const float *p1, const float *p2) {
@@ -409,6 +428,66 @@ static int occluded(const orc_scene *s, const float *o, const float *d, float tf
     return 0;
 }
 
+/* closest hit: the minimum t over ALL triangles accepted with the caller's tfar (the result does
+ * not depend on the visiting order); mode 0 = BVH, 1 = brute force.  Returns 1 when hit.        */
+static int closest(const orc_scene *s, const float *o, const float *d, float tfar, int mode, float *dist) {
+    float best = INFINITY; int any = 0; float t;
+#define TRY_QUAD(i, j) do { \
+        const float *a = vtx(s, (i), (j)), *b = vtx(s, (i), (j) + 1); \
+        const float *c = vtx(s, (i) + 1, (j)), *e = vtx(s, (i) + 1, (j) + 1); \
+        if (tri_hit_t_f(o, d, tfar, a, b, c, &t)) { any = 1; if (t < best) best = t; } \
+        if (tri_hit_t_f(o, d, tfar, b, e, c, &t)) { any = 1; if (t < best) best = t; } } while (0)
+#define TRY_TIN(tt) do { \
+        const float *p0 = s->vs + 3 * (size_t)s->ts[3 * (tt) + 0], *p1 = s->vs + 3 * (size_t)s->ts[3 * (tt) + 1]; \
+        const float *p2 = s->vs + 3 * (size_t)s->ts[3 * (tt) + 2]; \
+        if (tri_hit_t_f(o, d, tfar, p0, p1, p2, &t)) { any = 1; if (t < best) best = t; } } while (0)
+    if (mode == 0) {
+        ray_t r; ray_init(&r, o, d, tfar);
+        int stack[128]; int sp = 0;
+        if (s->n_gn > 0) {
+            stack[sp++] = 0;
+            while (sp > 0) {
+                const gnode *n = &s->gn[stack[--sp]];
+                r.tfar = (best < tfar) ? best * 1.0001f : tfar;      /* prune, conservatively */
+                if (!box_hit(&r, n->lo, n->hi)) continue;
+                if (n->left < 0) {
+                    for (int i = n->i0; i < n->i0 + n->ni; i++)
+                        for (int j = n->j0; j < n->j0 + n->nj; j++) TRY_QUAD(i, j);
+                } else { stack[sp++] = n->right; stack[sp++] = n->left; }
+            }
+        }
+        if (s->n_tn > 0) {
+            sp = 0; stack[sp++] = 0;
+            while (sp > 0) {
+                const tnode *n = &s->tn[stack[--sp]];
+                r.tfar = (best < tfar) ? best * 1.0001f : tfar;
+                if (!box_hit(&r, n->lo, n->hi)) continue;
+                if (n->left < 0) {
+                    for (int q = n->first; q < n->first + n->count; q++) TRY_TIN(s->tri_order[q]);
+                } else { stack[sp++] = n->right; stack[sp++] = n->left; }
+            }
+        }
+    } else {
+        for (int i = 0; i < s->d0 - 1; i++)
+            for (int j = 0; j < s->d1 - 1; j++) TRY_QUAD(i, j);
+        for (int tt = 0; tt < s->nts; tt++) TRY_TIN(tt);
+    }
+#undef TRY_QUAD
+#undef TRY_TIN
+    if (any) *dist = best;
+    return any;
+}
+
+void orc_closest_batch(const orc_scene *s, int64_t n, const float *org, const float *dir,
+                       const float *tfar, int mode, uint8_t *hit, float *dist) {
+#pragma omp parallel for schedule(dynamic, 64)
+    for (int64_t q = 0; q < n; q++) {
+        float t = NAN;
+        hit[q] = (uint8_t)closest(s, org + 3 * q, dir + 3 * q, tfar[q], mode, &t);
+        dist[q] = t;
+    }
+}
+
 void orc_occluded_batch(const orc_scene *s, int64_t n, const float *org,
                         const float *dir, const float *tfar, int mode,
                         uint8_t *out) {
@@ -484,6 +563,8 @@ typedef struct {
     const orc_scene *s; const tables_t *t; int mode;
     float o[3]; float rot[3][3];
     uint64_t rays, guards; orc_counters *cnt;
+    int want_dist;            /* closest-hit queries (the *_hori_dist variants, :519-612)  */
+    float dist, dist_hit;     /* persist across azimuths exactly as there (:526-527)       */
 } cell_t;
 
 /* direction for (elevation index, azimuth index) + occlusion query          */
@@ -497,6 +578,11 @@ static inline int shoot(cell_t *c, int ie, int k) {
     for (int a = 0; a < 3; a++)
         rr[a] = (c->rot[a][0] * ray[0] + c->rot[a][1] * ray[1]) + c->rot[a][2] * ray[2];
     c->rays++;
+    if (c->want_dist) {                            /* castRay_intersect1, :268-292 */
+        const int hit = closest(c->s, c->o, rr, t->dist, c->mode, &c->dist);
+        if (hit) c->dist_hit = c->dist;            /* :545-547 / :589-591 */
+        return hit;
+    }
     return occluded(c->s, c->o, rr, t->dist, c->mode, c->cnt);
 }
 
@@ -505,7 +591,7 @@ static inline int ind_of(const tables_t *t, float elev_samp) {
     return (int)roundf((float)((double)(elev_samp - t->low) / ((double)t->hori_acc / 5.0)));
 }
 
-static void ray_discrete_sampling(cell_t *c, float *hori) {      /* :302-333  */
+static void ray_discrete_sampling(cell_t *c, float *hori, float *dist_out) {   /* :302-333, :519-555 */
     const tables_t *t = c->t;
     for (int k = 0; k < t->azim_num; k++) {
         int ind_elev = 0, ind_elev_prev = 0, hit = 1;
@@ -518,6 +604,7 @@ static void ray_discrete_sampling(cell_t *c, float *hori) {      /* :302-333  */
             }
         }
         hori[k] = (float)((double)(t->elev_ang[ind_elev_prev] + t->elev_ang[ind_elev]) / 2.0);
+        if (dist_out) dist_out[k] = c->dist_hit;
     }
 }
 
@@ -536,8 +623,11 @@ static int binary_azim(cell_t *c, int k, float *out) {            /* :346-375  *
     return ind_elev;
 }
 
-static void ray_binary_search(cell_t *c, float *hori) {           /* :339-381  */
-    for (int k = 0; k < c->t->azim_num; k++) binary_azim(c, k, &hori[k]);
+static void ray_binary_search(cell_t *c, float *hori, float *dist_out) {   /* :339-381, :561-612 */
+    for (int k = 0; k < c->t->azim_num; k++) {
+        binary_azim(c, k, &hori[k]);
+        if (dist_out) dist_out[k] = c->dist_hit;
+    }
 }
 
 static void ray_guess_const(cell_t *c, float *hori) {             /* :387-498  */
@@ -623,6 +713,7 @@ int orc_horizon_gridded(const float *vert_grid, int dem_dim_0, int dem_dim_1,
                 const float *p = vert_grid + 3 * ((size_t)(i + offset_0) * (size_t)dem_dim_1
                                                   + (size_t)(j + offset_1));
                 cell_t c; c.s = s; c.t = &t; c.mode = mode; c.rays = 0; c.guards = 0;
+                c.want_dist = 0; c.dist = 0.0f; c.dist_hit = 0.0f;
                 orc_counters cn = {0, 0}; c.cnt = count_work ? &cn : NULL;
                 c.o[0] = p[0] + norm_x * ray_org_elev;            /* :763-770  */
                 c.o[1] = p[1] + norm_y * ray_org_elev;
@@ -634,8 +725,8 @@ int orc_horizon_gridded(const float *vert_grid, int dem_dim_0, int dem_dim_1,
                 c.rot[0][0] = east_x; c.rot[0][1] = north_x; c.rot[0][2] = norm_x;
                 c.rot[1][0] = east_y; c.rot[1][1] = north_y; c.rot[1][2] = norm_y;
                 c.rot[2][0] = east_z; c.rot[2][1] = north_z; c.rot[2][2] = norm_z;
-                if (alg == 0) ray_discrete_sampling(&c, hori);
-                else if (alg == 1) ray_binary_search(&c, hori);
+                if (alg == 0) ray_discrete_sampling(&c, hori, NULL);
+                else if (alg == 1) ray_binary_search(&c, hori, NULL);
                 else ray_guess_const(&c, hori);
                 rays += c.rays; guards += c.guards; nodes += cn.nodes; tris += cn.tris;
             } else {
@@ -648,6 +739,67 @@ int orc_horizon_gridded(const float *vert_grid, int dem_dim_0, int dem_dim_1,
         stats[4] = (uint64_t)((t_built - t_start) * 1e9);      /* scene build [ns]  */
         stats[5] = (uint64_t)((now_s() - t_built) * 1e9);      /* ray loop [ns]     */
     }
+    tables_free(&t);
+    orc_scene_destroy(s);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* locations driver (horizon_comp.cpp:828-1094)                               */
+/* stats[0] = search rays (as the reference counts), stats[1] = guard events, */
+/* stats[2] = locations that found the surface along +/- normal               */
+/* ------------------------------------------------------------------------- */
+int orc_horizon_locations(const float *vert_grid, int dem_dim_0, int dem_dim_1,
+                          const float *coords, const float *vec_norm, const float *vec_north,
+                          float *hori_buffer, float *hori_dist_buffer, int num_loc,
+                          int azim_num, float dist_search, float hori_acc,
+                          const char *ray_algorithm, const char *geom_type,
+                          float elev_ang_low_lim, const float *ray_org_elev,
+                          int hori_dist_out, int mode, uint64_t *stats) {
+    (void)geom_type;
+    int alg;
+    if (strcmp(ray_algorithm, "discrete_sampling") == 0) alg = 0;
+    else if (strcmp(ray_algorithm, "binary_search") == 0) alg = 1;
+    else if (strcmp(ray_algorithm, "guess_constant") == 0) alg = 2;
+    else return 1;
+    if (hori_dist_out && alg == 2) return 2;       /* horizon.pyx: not implemented */
+    /* no simplified outer mesh for locations (:848-852) */
+    orc_scene *s = orc_scene_create(vert_grid, dem_dim_0, dem_dim_1, NULL, 0, NULL, 0);
+    tables_t t; tables_build(&t, azim_num, hori_acc, elev_ang_low_lim, dist_search);
+    uint64_t rays = 0, guards = 0, found = 0;
+#pragma omp parallel for schedule(dynamic, 4) reduction(+ : rays, guards, found)
+    for (int i = 0; i < num_loc; i++) {
+        const float norm_x = vec_norm[3 * i], norm_y = vec_norm[3 * i + 1], norm_z = vec_norm[3 * i + 2];
+        const float north_x = vec_north[3 * i], north_y = vec_north[3 * i + 1], north_z = vec_north[3 * i + 2];
+        const float ini[3] = {coords[3 * i], coords[3 * i + 1], coords[3 * i + 2]};
+        float dist = 0.0f;                                         /* :947-957 */
+        const float up[3] = {norm_x, norm_y, norm_z}, down[3] = {-norm_x, -norm_y, -norm_z};
+        int hit = closest(s, ini, up, 100000.0f, mode, &dist);
+        if (!hit) {
+            hit = closest(s, ini, down, 100000.0f, mode, &dist);
+            dist = (float)((double)dist * -1.0);
+        }
+        if (!hit) continue;
+        found++;
+        cell_t c; c.s = s; c.t = &t; c.mode = mode; c.rays = 0; c.guards = 0; c.cnt = NULL;
+        c.want_dist = hori_dist_out ? 1 : 0; c.dist = 0.0f; c.dist_hit = 0.0f;
+        c.o[0] = ini[0] + norm_x * (dist + ray_org_elev[i]);       /* :961-963 */
+        c.o[1] = ini[1] + norm_y * (dist + ray_org_elev[i]);
+        c.o[2] = ini[2] + norm_z * (dist + ray_org_elev[i]);
+        const float east_x = north_y * norm_z - north_z * norm_y;
+        const float east_y = north_z * norm_x - north_x * norm_z;
+        const float east_z = north_x * norm_y - north_y * norm_x;
+        c.rot[0][0] = east_x; c.rot[0][1] = north_x; c.rot[0][2] = norm_x;
+        c.rot[1][0] = east_y; c.rot[1][1] = north_y; c.rot[1][2] = norm_y;
+        c.rot[2][0] = east_z; c.rot[2][1] = north_z; c.rot[2][2] = norm_z;
+        float *hori = hori_buffer + (size_t)i * (size_t)azim_num;
+        float *dout = hori_dist_out ? hori_dist_buffer + (size_t)i * (size_t)azim_num : NULL;
+        if (alg == 0) ray_discrete_sampling(&c, hori, dout);
+        else if (alg == 1) ray_binary_search(&c, hori, dout);
+        else ray_guess_const(&c, hori);
+        rays += c.rays; guards += c.guards;
+    }
+    if (stats) { stats[0] = rays; stats[1] = guards; stats[2] = found; }
     tables_free(&t);
     orc_scene_destroy(s);
     return 0;

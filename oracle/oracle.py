@@ -50,6 +50,11 @@ def lib():
             C.c_int, C.c_float, C.c_float, C.c_char_p, C.c_char_p, fp, C.c_int,
             i32p, C.c_int, C.c_float, u8p, C.c_float, C.c_float,
             C.c_int, C.c_int, C.c_int, C.c_int, u64p]
+        L.orc_closest_batch.argtypes = [C.c_void_p, C.c_int64, fp, fp, fp, C.c_int, u8p, fp]
+        L.orc_horizon_locations.restype = C.c_int
+        L.orc_horizon_locations.argtypes = [
+            fp, C.c_int, C.c_int, fp, fp, fp, fp, fp, C.c_int, C.c_int, C.c_float, C.c_float,
+            C.c_char_p, C.c_char_p, C.c_float, fp, C.c_int, C.c_int, u64p]
         L.orc_terrain_create.restype = C.c_void_p
         L.orc_terrain_create.argtypes = [fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp,
                                          C.c_int, C.c_int, fp, fp, u8p, C.c_float,
@@ -120,10 +125,56 @@ class Scene:
         lib().orc_occluded_batch(self._h, n, _f(org), _f(dirs), _f(tf), mode, _u8(out))
         return out.astype(bool)
 
+    def closest(self, org, dirs, tfar, mode=MODE_BVH):
+        """(hit, distance) of the closest accepted triangle (rtcIntersect1 semantics)."""
+        org = np.ascontiguousarray(org, np.float32).reshape(-1, 3)
+        dirs = np.ascontiguousarray(dirs, np.float32).reshape(-1, 3)
+        n = org.shape[0]
+        tf = np.ascontiguousarray(np.broadcast_to(np.asarray(tfar, np.float32), (n,)))
+        hit = np.empty(n, np.uint8)
+        dist = np.empty(n, np.float32)
+        lib().orc_closest_batch(self._h, n, _f(org), _f(dirs), _f(tf), mode, _u8(hit), _f(dist))
+        return hit.astype(bool), dist
+
     def __del__(self):
         if getattr(self, "_h", None):
             lib().orc_scene_destroy(self._h)
             self._h = None
+
+
+def horizon_locations(vert_grid, dem_dim_0, dem_dim_1, coords, vec_norm, vec_north,
+                      dist_search, azim_num=360, hori_acc=0.25, ray_algorithm="binary_search",
+                      geom_type="grid", elev_ang_low_lim=-89.98,
+                      ray_org_elev=np.array([0.01], dtype=np.float32), hori_dist_out=False,
+                      *, mode=MODE_BVH, return_stats=False):
+    """CPU restatement of horayzon.horizon.horizon_locations (horizon.pyx:218-370)."""
+    vert_grid = np.ascontiguousarray(vert_grid, np.float32)
+    coords = np.ascontiguousarray(coords, np.float32)
+    vec_norm = np.ascontiguousarray(vec_norm, np.float32)
+    vec_north = np.ascontiguousarray(vec_north, np.float32)
+    n = coords.shape[0]
+    roe = np.ascontiguousarray(ray_org_elev, np.float32)
+    if len(roe) != n:
+        roe = np.repeat(roe, n)
+    hori = np.full((n, azim_num), np.nan, np.float32)
+    dist = np.full((n if hori_dist_out else 1, azim_num), np.nan, np.float32)
+    stats = np.zeros(4, np.uint64)
+    rc = lib().orc_horizon_locations(
+        _f(vert_grid), dem_dim_0, dem_dim_1, _f(coords), _f(vec_norm), _f(vec_north), _f(hori), _f(dist),
+        n, azim_num, dist_search, hori_acc, ray_algorithm.encode(), geom_type.encode(), elev_ang_low_lim,
+        _f(roe), int(bool(hori_dist_out)), mode, stats.ctypes.data_as(C.POINTER(C.c_uint64)))
+    if rc == 1:
+        raise ValueError("invalid input argument for ray_algorithm")
+    if rc == 2:
+        raise TypeError("horizon detection algorithm 'guess_constant' not implemented for horizon "
+                        "distance computation")
+    azim = np.empty(azim_num, np.float32)
+    for i in range(azim_num):
+        azim[i] = ((2 * np.pi) / azim_num * i)
+    out = (hori, dist, azim) if hori_dist_out else (hori, azim)
+    if return_stats:
+        return out + (dict(rays=int(stats[0]), guards=int(stats[1]), found=int(stats[2])),)
+    return out
 
 
 def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,

@@ -128,6 +128,46 @@ def test_horizon_validation_errors():
         call(vec_norm=kw["vec_norm"][0])
 
 
+def test_locations_validation_errors():
+    """horizon.pyx:279-312."""
+    g = cases.rough_terrain(20, 24, seed=2, offset=0)
+    n = 6
+    coords = np.zeros((n, 3), np.float32); vn = np.zeros((n, 3), np.float32); vn[:, 2] = 1
+    vo = np.zeros((n, 3), np.float32); vo[:, 1] = 1
+    f = horayzon_amd.horizon.horizon_locations
+
+    def call(**over):
+        a = dict(vert_grid=g["vert_grid"], dem_dim_0=20, dem_dim_1=24, coords=coords, vec_norm=vn, vec_north=vo,
+                 dist_search=1.0, azim_num=8)
+        a.update(over)
+        return f(**a)
+    with pytest.raises(ValueError, match="vert_grid"):
+        call(vert_grid=g["vert_grid"][:30])
+    with pytest.raises(ValueError, match="coords"):
+        call(coords=coords[:4])
+    with pytest.raises(ValueError, match="vec_norm and/or vec_north"):
+        call(vec_north=vo[:3])
+    with pytest.raises(ValueError, match="ray_algorithm"):
+        call(ray_algorithm="x")
+    with pytest.raises(ValueError, match="geom_type"):
+        call(geom_type="x")
+    with pytest.raises(ValueError, match="hori_acc"):
+        call(hori_acc=20.0)
+    with pytest.raises(ValueError, match="ray_org_elev"):
+        call(ray_org_elev=np.full(3, 0.01, np.float32))
+    with pytest.raises(TypeError, match="ray_org_elev"):
+        call(ray_org_elev=np.array([0.001], np.float32))
+    with pytest.raises(TypeError, match="guess_constant"):
+        call(ray_algorithm="guess_constant", hori_dist_out=True)
+    import inspect
+    names = [p for p in inspect.signature(f).parameters]
+    assert names[:14] == ["vert_grid", "dem_dim_0", "dem_dim_1", "coords", "vec_norm", "vec_north", "dist_search",
+                          "azim_num", "hori_acc", "ray_algorithm", "geom_type", "elev_ang_low_lim", "ray_org_elev",
+                          "hori_dist_out"]                                  # horizon.pyx:218-231
+    d = {k: v.default for k, v in inspect.signature(f).parameters.items()}
+    assert d["ray_algorithm"] == "binary_search" and d["elev_ang_low_lim"] == -89.98 and d["hori_dist_out"] is False
+
+
 def test_terrain_validation_errors(monkeypatch):
     """shadow.pyx:87-133; the handle is never touched because validation raises first."""
     g = cases.rough_terrain(20, 24, seed=2, offset=3)

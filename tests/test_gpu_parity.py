@@ -144,6 +144,56 @@ def test_persistent_scene_and_blob_adopt(hip, orc):
     del src
 
 
+def _locations(seed, n=300, tilt=False):
+    g = cases.rough_terrain(70, 80, seed=seed, offset=0, relief=700.0)
+    rng = np.random.default_rng(seed + 1)
+    ci = rng.integers(3, 67, n); cj = rng.integers(3, 77, n)
+    coords = np.stack([g["x"][cj] + rng.uniform(-12, 12, n), g["y"][ci] + rng.uniform(-12, 12, n),
+                       g["z"][ci, cj] + rng.uniform(-150, 300, n)], axis=1).astype(np.float32)
+    coords[:5, 0] += 1.0e5          # far outside the DEM: the normal never meets the mesh -> NaN rows
+    vn = np.zeros((n, 3), np.float32); vn[:, 2] = 1.0
+    vo = np.zeros((n, 3), np.float32); vo[:, 1] = 1.0
+    if tilt:
+        a = rng.uniform(-0.05, 0.05, n); b = rng.uniform(-0.05, 0.05, n)
+        nrm = np.stack([np.sin(b), -np.sin(a) * np.cos(b), np.cos(a) * np.cos(b)], axis=1)
+        north = np.array([0.0, 1.0, 0.0])[None, :] - nrm[:, 1:2] * nrm
+        north /= np.linalg.norm(north, axis=1, keepdims=True)
+        vn, vo = nrm.astype(np.float32), north.astype(np.float32)
+    return g, coords, vn, vo
+
+
+@pytest.mark.parametrize("alg", ALGS)
+def test_horizon_locations(hip, orc, alg):
+    """horizon_locations (horizon_comp.cpp:828-1094): snap onto the mesh along +/- normal, then search."""
+    g, coords, vn, vo = _locations(51, tilt=True)
+    roe = np.linspace(0.01, 2.0, coords.shape[0]).astype(np.float32)
+    h_gpu, a_gpu = hip.horizon.horizon_locations(g["vert_grid"], 70, 80, coords, vn, vo, 2.0, azim_num=24,
+                                                 ray_algorithm=alg, ray_org_elev=roe)
+    st = hip.horizon.last_stats
+    h_cpu, a_cpu, so = orc.horizon_locations(g["vert_grid"], 70, 80, coords, vn, vo, 2.0, azim_num=24,
+                                             ray_algorithm=alg, ray_org_elev=roe, return_stats=True)
+    assert np.array_equal(a_gpu, a_cpu)
+    assert np.isnan(h_gpu[:5]).all() and not np.isnan(h_gpu[5:]).any()
+    assert np.array_equal(h_gpu, h_cpu, equal_nan=True)
+    assert st["num_rays"] == so["rays"] and st["num_cells"] == so["found"] == coords.shape[0] - 5
+
+
+@pytest.mark.parametrize("alg", ("binary_search", "discrete_sampling"))
+def test_horizon_locations_distance(hip, orc, alg):
+    """Distance to the horizon (closest hit, the *_hori_dist variants :519-612)."""
+    g, coords, vn, vo = _locations(57)
+    out_g = hip.horizon.horizon_locations(g["vert_grid"], 70, 80, coords, vn, vo, 2.5, azim_num=16,
+                                          ray_algorithm=alg, hori_dist_out=True, elev_ang_low_lim=-60.0)
+    out_c = orc.horizon_locations(g["vert_grid"], 70, 80, coords, vn, vo, 2.5, azim_num=16,
+                                  ray_algorithm=alg, hori_dist_out=True, elev_ang_low_lim=-60.0)
+    assert np.array_equal(out_g[0], out_c[0], equal_nan=True)          # horizon
+    assert np.array_equal(out_g[1], out_c[1], equal_nan=True)          # distance: the same float division
+    assert np.nanmax(out_g[1]) <= 2500.0 * 1.0001 and np.nanmin(out_g[1]) >= 0.0
+    with pytest.raises(TypeError, match="guess_constant"):
+        hip.horizon.horizon_locations(g["vert_grid"], 70, 80, coords, vn, vo, 2.5, ray_algorithm="guess_constant",
+                                      hori_dist_out=True)
+
+
 def test_svf_fused_and_standalone(hip, orc):
     g = cases.rough_terrain(72, 72, seed=23, offset=4)
     kw = cases.grid_kwargs(g)

@@ -148,6 +148,39 @@ def test_horizon_bvh_equals_brute_force_and_tin(orc):
     assert np.array_equal(c, d)
 
 
+def test_closest_hit_and_locations(orc):
+    """Closest hit: BVH == brute force (the minimum over all accepted triangles is order
+    independent); a vertical ray from above returns the height above ground."""
+    g = cases.rough_terrain(40, 44, seed=5, offset=0, relief=600.0)
+    sc = orc.Scene(g["vert_grid"], 40, 44)
+    rng = np.random.default_rng(2)
+    n = 20000
+    ci = rng.integers(1, 39, n); cj = rng.integers(1, 43, n)
+    org = np.stack([g["x"][cj], g["y"][ci], g["z"][ci, cj] + np.float32(0.01)], axis=1).astype(np.float32)
+    az = rng.uniform(0, 2 * np.pi, n); el = np.deg2rad(rng.uniform(-40.0, 30.0, n))
+    d = np.stack([np.cos(el) * np.sin(az), np.cos(el) * np.cos(az), np.sin(el)], axis=1).astype(np.float32)
+    h0, t0 = sc.closest(org, d, 2500.0, orc.MODE_BVH)
+    h1, t1 = sc.closest(org, d, 2500.0, orc.MODE_BRUTE)
+    assert np.array_equal(h0, h1) and np.array_equal(t0[h0], t1[h1])
+    assert np.array_equal(h0, sc.occluded(org, d, 2500.0))            # same acceptance as any-hit
+    assert (t0[h0] >= 0).all() and (t0[h0] <= 2500.0 * 1.0001).all()
+    up = np.zeros((50, 3), np.float32); up[:, 2] = -1.0
+    o2 = np.stack([g["x"][cj[:50]], g["y"][ci[:50]], g["z"][ci[:50], cj[:50]] + np.float32(123.0)], axis=1).astype(np.float32)
+    h2, t2 = sc.closest(o2, up, 1.0e5)
+    assert h2.all() and np.abs(t2 - 123.0).max() < 1e-2
+    # locations driver: points above / below the surface are snapped, far away ones stay NaN
+    vn = np.zeros((50, 3), np.float32); vn[:, 2] = 1.0
+    vo = np.zeros((50, 3), np.float32); vo[:, 1] = 1.0
+    o2[:25, 2] -= 200.0
+    o2[0, 0] += 1.0e6
+    h, azim, st = orc.horizon_locations(g["vert_grid"], 40, 44, o2, vn, vo, 1.0, azim_num=8, return_stats=True)
+    assert st["found"] == 49 and np.isnan(h[0]).all() and not np.isnan(h[1:]).any()
+    hg, _ = orc.horizon_gridded(g["vert_grid"], 40, 44, np.repeat(vn[:1], 1, 0).reshape(1, 1, 3),
+                                np.repeat(vo[:1], 1, 0).reshape(1, 1, 3), int(ci[1]), int(cj[1]), 1.0, azim_num=8,
+                                ray_algorithm="binary_search", elev_ang_low_lim=-89.98)
+    assert np.abs(h[1] - hg[0, 0]).max() <= np.deg2rad(0.25) + 1e-6     # same cell via the gridded driver
+
+
 def test_curved_dem_fixture(orc):
     """ENU vertices / normals / north vectors produced by the REFERENCE's transform and
     direction modules (tests/golden/make_fixtures.py): non axis-aligned frames."""
