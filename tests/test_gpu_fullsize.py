@@ -1,0 +1,86 @@
+"""GPU checks at BASELINE.json's full size (config 3: 3601 x 3601 tile, 360 azimuths, 50 km):
+a slab of rows bit-identical to the oracle, plus size-independent properties."""
+import numpy as np
+import pytest
+
+from horayzon_amd import synth
+from tests import cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tile():
+    g = synth.fractal_tile(n=3601, offset=16)
+    return g
+
+
+def test_c3_rows_bit_identical_and_properties(hip, orc, tile):
+    kw = cases.grid_kwargs(tile)
+    rows = (1777, 1781)
+    sc = hip.Scene.create(kw["vert_grid"], 3601, 3601)
+    assert sc.stats["bvh_height"] <= 16
+    vec_tilt, enl = synth.tilt_from_planar_dem(tile["x"], tile["y"], tile["z"], 16)
+    # product: full boundary call restricted to a slab (the rest of hori stays NaN)
+    import ctypes as C
+    from horayzon_amd import _lib
+    in0 = in1 = 3569
+    A = 360
+    nrow = rows[1] - rows[0]
+    res = {}
+    for alg in ("guess_constant", "binary_search"):
+        hori = np.full((nrow, in1, A), np.nan, np.float32)
+        svf = np.full((in0, in1), np.nan, np.float32)
+        opts = _lib.hz_opts(); opts.device = 0; opts.top_nodes = -1; opts.regroup = -1
+        opts.row_begin, opts.row_end = rows
+        opts.svf = svf.ctypes.data; opts.vec_tilt = vec_tilt.ctypes.data
+        st = _lib.hz_stats()
+        mask = np.ones((in0, in1), np.uint8)
+        shifted = hori.ctypes.data - 4 * rows[0] * in1 * A          # library indexes by global cell
+        _lib.check(_lib.lib().hz_horizon_gridded_scene(
+            sc._h, kw["vec_norm"].ctypes.data, kw["vec_north"].ctypes.data, 16, 16, shifted, in0, in1, A, 50.0,
+            0.25, alg.encode(), -15.0, mask.ctypes.data, 0.0, 0.01, C.byref(opts), C.byref(st)))
+        ref, azim, so = orc.horizon_gridded(**kw, dist_search=50.0, azim_num=A, ray_algorithm=alg, rows=rows,
+                                            slab_only=True, return_stats=True)
+        assert not np.isnan(hori).any()
+        assert np.array_equal(hori, ref), alg                     # bit-identical at full size
+        assert st.num_rays == so["rays"] and st.guard_events == so["guards"] == 0
+        assert st.num_cells == nrow * in1
+        svf_ref = orc.sky_view_factor(azim, ref, np.ascontiguousarray(vec_tilt[rows[0]:rows[1]]))
+        assert np.abs(svf[rows[0]:rows[1]] - svf_ref).max() <= 1.0e-5
+        assert np.isnan(svf[:rows[0]]).all() and np.isnan(svf[rows[1]:]).all()
+        assert 0.0 < svf_ref.min() and svf_ref.max() <= 1.0 + 1e-5
+        res[alg] = hori
+    # the two search algorithms agree within their accuracy (max error = hori_acc)
+    assert np.abs(res["guess_constant"] - res["binary_search"]).max() <= np.deg2rad(0.25) * 2.5
+    # rays per (cell, azimuth): 2-3 for guess_constant on real-looking terrain (horizon_comp.cpp:809-810)
+    g_rays = st.num_rays  # binary: ~9 rays
+    assert 8.0 <= g_rays / (nrow * in1 * A) <= 11.0
+
+
+def test_c3_shadow_matches_horizon(hip, orc, tile):
+    """Full-size consistency of the two hot paths: a cell is terrain-shaded exactly when the sun is
+    below the horizon the horizon kernel found at the sun's azimuth (both with ray_org_elev 0.05)."""
+    kw = cases.grid_kwargs(tile)
+    sc = hip.Scene.create(kw["vert_grid"], 3601, 3601)
+    rows = (900, 916)
+    h, azim = hip.horizon.horizon_gridded(**{**kw, "vec_norm": kw["vec_norm"][rows[0]:rows[1]].copy(),
+                                             "vec_north": kw["vec_north"][rows[0]:rows[1]].copy(),
+                                             "offset_0": 16 + rows[0]},
+                                          dist_search=200.0, azim_num=8, ray_algorithm="binary_search",
+                                          hori_acc=0.1, elev_ang_low_lim=-15.0, ray_org_elev=0.05, scene=sc)
+    in1 = 3569
+    vec_norm = kw["vec_norm"][rows[0]:rows[1]].copy()
+    ones = np.ones((rows[1] - rows[0], in1), np.float32)
+    t = hip.shadow.Terrain()
+    t.initialise(kw["vert_grid"], 3601, 3601, 16 + rows[0], 16, vec_norm.copy(), vec_norm, ones, ones,
+                 np.ones(ones.shape, np.uint8), scene=sc)
+    k, sun_el = 2, np.deg2rad(9.0)                              # azimuth 90 deg = east
+    far = np.float32(2.0e10)                                     # effectively parallel rays
+    sun = np.array([far * np.cos(sun_el), 0.0, far * np.sin(sun_el)], np.float32)
+    sh = np.empty(ones.shape, np.uint8)
+    t.shadow(sun, sh)
+    clear = np.abs(h[:, :, k] - sun_el) > np.deg2rad(0.25)      # outside the search accuracy band
+    assert clear.mean() > 0.9
+    assert np.array_equal(sh[clear] == 2, h[:, :, k][clear] > sun_el)
+    assert 0.02 < (sh == 2).mean() < 0.98
