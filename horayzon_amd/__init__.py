@@ -8,6 +8,8 @@ NumPy out, same signatures; the computation runs in hand-written HIP kernels
 from . import horizon      # noqa: F401
 from . import shadow       # noqa: F401
 from . import topo_param   # noqa: F401
+from . import transform    # noqa: F401
+from . import direction    # noqa: F401
 from . import synth        # noqa: F401
 from ._lib import HorayzonHipError, Scene, device_count, device_info   # noqa: F401
 

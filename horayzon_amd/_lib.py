@@ -50,6 +50,8 @@ SYMBOLS = (
     "hz_horizon_gridded", "hz_horizon_gridded_scene", "hz_horizon_locations",
     "hz_horizon_locations_scene", "hz_horizon_tables",
     "hz_sky_view_factor",
+    "hz_slope_plane_meth", "hz_slope_vector_meth", "hz_lonlat2ecef", "hz_ecef2enu",
+    "hz_ecef2enu_vector", "hz_surf_norm", "hz_north_dir",
     "hz_terrain_create", "hz_terrain_initialise", "hz_terrain_initialise_scene",
     "hz_terrain_shadow", "hz_terrain_sw_dir_cor", "hz_terrain_shadow_batch",
     "hz_terrain_sw_dir_cor_batch", "hz_terrain_destroy",
@@ -115,6 +117,13 @@ def lib():
     L.hz_horizon_tables.argtypes = [ip, C.c_float, C.c_float, vp, vp, ip, vp, vp, vp,
                                     C.POINTER(C.c_int)]
     L.hz_sky_view_factor.argtypes = [vp, vp, vp, ip, ip, ip, vp, ip]
+    L.hz_slope_plane_meth.argtypes = [vp, vp, vp, ip, ip, vp, ip, vp, ip]
+    L.hz_slope_vector_meth.argtypes = [vp, vp, vp, ip, ip, vp, ip, vp, ip]
+    L.hz_lonlat2ecef.argtypes = [vp, vp, vp, C.c_size_t, ip, vp, vp, vp, ip]
+    L.hz_ecef2enu.argtypes = [vp, vp, vp, C.c_size_t, C.c_double, C.c_double, ip, vp, vp, vp, ip]
+    L.hz_ecef2enu_vector.argtypes = [vp, C.c_size_t, C.c_double, C.c_double, ip, vp, ip]
+    L.hz_surf_norm.argtypes = [vp, vp, C.c_size_t, vp, ip]
+    L.hz_north_dir.argtypes = [vp, vp, vp, vp, C.c_size_t, ip, vp, ip]
     L.hz_terrain_create.argtypes = [ip, C.POINTER(vp)]
     L.hz_terrain_initialise.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, ip, ip, vp, vp, vp,
                                         C.c_char_p, C.c_float, C.c_float, ip, C.POINTER(hz_stats)]

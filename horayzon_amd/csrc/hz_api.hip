@@ -614,6 +614,123 @@ int hz_sky_view_factor(const float *azim, const float *hori, const float *vec_ti
 }
 
 // ---------------------------------------------------------------------------------------
+// slope and input preparation (hz_prep.hip)
+// ---------------------------------------------------------------------------------------
+static int slope_api(int which, const float *x, const float *y, const float *z, int len_0, int len_1,
+                     const float *rot_mat, int output_rot, float *vec_tilt, int device) {
+    if (!x || !y || !z || !vec_tilt) return set_error(HZ_ERR_ARG, "NULL argument");
+    if (len_0 <= 0 || len_1 <= 0) return set_error(HZ_ERR_ARG, "Inconsistent shapes / number of dimensions of input arrays");
+    if (which == 1 && output_rot && !rot_mat) return set_error(HZ_ERR_ARG, "'rot_mat' must be provided for 'output_rot = True'");
+    int rc = select_device(device);
+    if (rc) return rc;
+    hipStream_t st = nullptr;
+    const size_t n = (size_t)len_0 * len_1;
+    DevIn<float> dx, dy, dz, dr;
+    DevOut<float> dt;
+    if ((rc = dx.bind(x, n, st))) return rc;
+    if ((rc = dy.bind(y, n, st))) return rc;
+    if ((rc = dz.bind(z, n, st))) return rc;
+    if ((rc = dr.bind(rot_mat, rot_mat ? n * 9 : 0, st))) return rc;
+    if ((rc = dt.bind(vec_tilt, n * 3))) return rc;
+    if ((rc = prep_slope(which, dx.dev, dy.dev, dz.dev, len_0, len_1, dr.dev, output_rot, dt.dev, st))) return rc;
+    if ((rc = dt.finish(st))) return rc;
+    HZ_HIP(hipStreamSynchronize(st));
+    return HZ_OK;
+}
+
+int hz_slope_plane_meth(const float *x, const float *y, const float *z, int len_0, int len_1,
+                        const float *rot_mat, int output_rot, float *vec_tilt, int device) {
+    return slope_api(0, x, y, z, len_0, len_1, rot_mat, output_rot, vec_tilt, device);
+}
+int hz_slope_vector_meth(const float *x, const float *y, const float *z, int len_0, int len_1,
+                         const float *rot_mat, int output_rot, float *vec_tilt, int device) {
+    return slope_api(1, x, y, z, len_0, len_1, rot_mat, output_rot, vec_tilt, device);
+}
+
+static int check_ellps(int ellps) {
+    if (ellps < 0 || ellps > 2) return set_error(HZ_ERR_ARG, "Unknown value for 'ellps'");
+    return HZ_OK;
+}
+
+int hz_lonlat2ecef(const double *lon, const double *lat, const float *h, size_t n, int ellps, double *x_ecef,
+                   double *y_ecef, double *z_ecef, int device) {
+    if (!lon || !lat || !h || !x_ecef || !y_ecef || !z_ecef) return set_error(HZ_ERR_ARG, "NULL argument");
+    int rc = check_ellps(ellps);
+    if (rc) return rc;
+    if ((rc = select_device(device))) return rc;
+    hipStream_t st = nullptr;
+    DevIn<double> dlon, dlat; DevIn<float> dh; DevOut<double> ox, oy, oz;
+    if ((rc = dlon.bind(lon, n, st)) || (rc = dlat.bind(lat, n, st)) || (rc = dh.bind(h, n, st))) return rc;
+    if ((rc = ox.bind(x_ecef, n)) || (rc = oy.bind(y_ecef, n)) || (rc = oz.bind(z_ecef, n))) return rc;
+    if ((rc = prep_lonlat2ecef(ellps, dlon.dev, dlat.dev, dh.dev, n, ox.dev, oy.dev, oz.dev, st))) return rc;
+    if ((rc = ox.finish(st)) || (rc = oy.finish(st)) || (rc = oz.finish(st))) return rc;
+    HZ_HIP(hipStreamSynchronize(st));
+    return HZ_OK;
+}
+
+int hz_ecef2enu(const double *x_ecef, const double *y_ecef, const double *z_ecef, size_t n, double lon_or,
+                double lat_or, int ellps, float *x_enu, float *y_enu, float *z_enu, int device) {
+    if (!x_ecef || !y_ecef || !z_ecef || !x_enu || !y_enu || !z_enu) return set_error(HZ_ERR_ARG, "NULL argument");
+    if (lon_or < -180.0 || lon_or > 180.0) return set_error(HZ_ERR_ARG, "Value for 'lon_or' is outside of valid range");
+    if (lat_or < -90.0 || lat_or > 90.0) return set_error(HZ_ERR_ARG, "Value for 'lat_or' is outside of valid range");
+    int rc = check_ellps(ellps);
+    if (rc) return rc;
+    if ((rc = select_device(device))) return rc;
+    hipStream_t st = nullptr;
+    DevIn<double> dx, dy, dz; DevOut<float> ox, oy, oz;
+    if ((rc = dx.bind(x_ecef, n, st)) || (rc = dy.bind(y_ecef, n, st)) || (rc = dz.bind(z_ecef, n, st))) return rc;
+    if ((rc = ox.bind(x_enu, n)) || (rc = oy.bind(y_enu, n)) || (rc = oz.bind(z_enu, n))) return rc;
+    if ((rc = prep_ecef2enu(ellps, lon_or, lat_or, dx.dev, dy.dev, dz.dev, n, ox.dev, oy.dev, oz.dev, st))) return rc;
+    if ((rc = ox.finish(st)) || (rc = oy.finish(st)) || (rc = oz.finish(st))) return rc;
+    HZ_HIP(hipStreamSynchronize(st));
+    return HZ_OK;
+}
+
+int hz_ecef2enu_vector(const float *vec_ecef, size_t n, double lon_or, double lat_or, int ellps, float *vec_enu,
+                       int device) {
+    if (!vec_ecef || !vec_enu) return set_error(HZ_ERR_ARG, "NULL argument");
+    int rc = check_ellps(ellps);
+    if (rc) return rc;
+    if ((rc = select_device(device))) return rc;
+    hipStream_t st = nullptr;
+    DevIn<float> dv; DevOut<float> dout;
+    if ((rc = dv.bind(vec_ecef, n * 3, st)) || (rc = dout.bind(vec_enu, n * 3))) return rc;
+    if ((rc = prep_ecef2enu_vector(ellps, lon_or, lat_or, dv.dev, n, dout.dev, st))) return rc;
+    if ((rc = dout.finish(st))) return rc;
+    HZ_HIP(hipStreamSynchronize(st));
+    return HZ_OK;
+}
+
+int hz_surf_norm(const double *lon, const double *lat, size_t n, float *vec_norm_ecef, int device) {
+    if (!lon || !lat || !vec_norm_ecef) return set_error(HZ_ERR_ARG, "NULL argument");
+    int rc = select_device(device);
+    if (rc) return rc;
+    hipStream_t st = nullptr;
+    DevIn<double> dlon, dlat; DevOut<float> dout;
+    if ((rc = dlon.bind(lon, n, st)) || (rc = dlat.bind(lat, n, st)) || (rc = dout.bind(vec_norm_ecef, n * 3))) return rc;
+    if ((rc = prep_surf_norm(dlon.dev, dlat.dev, n, dout.dev, st))) return rc;
+    if ((rc = dout.finish(st))) return rc;
+    HZ_HIP(hipStreamSynchronize(st));
+    return HZ_OK;
+}
+
+int hz_north_dir(const double *x_ecef, const double *y_ecef, const double *z_ecef, const float *vec_norm_ecef,
+                 size_t n, int ellps, float *vec_north_ecef, int device) {
+    if (!x_ecef || !y_ecef || !z_ecef || !vec_norm_ecef || !vec_north_ecef) return set_error(HZ_ERR_ARG, "NULL argument");
+    int rc = check_ellps(ellps);
+    if (rc) return rc;
+    if ((rc = select_device(device))) return rc;
+    hipStream_t st = nullptr;
+    DevIn<double> dx, dy, dz; DevIn<float> dn; DevOut<float> dout;
+    if ((rc = dx.bind(x_ecef, n, st)) || (rc = dy.bind(y_ecef, n, st)) || (rc = dz.bind(z_ecef, n, st))) return rc;
+    if ((rc = dn.bind(vec_norm_ecef, n * 3, st)) || (rc = dout.bind(vec_north_ecef, n * 3))) return rc;
+    if ((rc = prep_north_dir(ellps, dx.dev, dy.dev, dz.dev, dn.dev, n, dout.dev, st))) return rc;
+    if ((rc = dout.finish(st))) return rc;
+    HZ_HIP(hipStreamSynchronize(st));
+    return HZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------
 // Terrain (shadow_comp.h:4-39)
 // ---------------------------------------------------------------------------------------
 

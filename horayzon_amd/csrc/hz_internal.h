@@ -111,4 +111,16 @@ struct ShadowArgs {
 };
 int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st);
 
+// hz_prep.hip (device pointers)
+int prep_slope(int which, const float *x, const float *y, const float *z, int len_0, int len_1,
+               const float *rot_mat, int output_rot, float *vec_tilt, hipStream_t st);
+int prep_lonlat2ecef(int ellps, const double *lon, const double *lat, const float *h, size_t n, double *X,
+                     double *Y, double *Z, hipStream_t st);
+int prep_ecef2enu(int ellps, double lon_or, double lat_or, const double *X, const double *Y, const double *Z,
+                  size_t n, float *xe, float *ye, float *ze, hipStream_t st);
+int prep_ecef2enu_vector(int ellps, double lon_or, double lat_or, const float *v, size_t n, float *o, hipStream_t st);
+int prep_surf_norm(const double *lon, const double *lat, size_t n, float *o, hipStream_t st);
+int prep_north_dir(int ellps, const double *X, const double *Y, const double *Z, const float *vn, size_t n,
+                   float *o, hipStream_t st);
+
 }  // namespace hz

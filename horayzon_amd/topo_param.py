@@ -27,3 +27,46 @@ def sky_view_factor(azim, hori, vec_tilt, *, device=0):
                                              hori.shape[0], hori.shape[1], hori.shape[2],
                                              ptr(svf), device))
     return svf
+
+
+def _slope(which, x, y, z, rot_mat, output_rot, device):
+    # Check arguments (topo_param.pyx:59-72 / :262-277)
+    if (x.shape != y.shape) or (y.shape != z.shape):
+        raise ValueError("Inconsistent shapes / number of dimensions of "
+                         + "input arrays")
+    if ((x.dtype != "float32") or (y.dtype != "float32")
+            or (z.dtype != "float32")):
+        raise ValueError("Input array(s) has/have incorrect data type(s)")
+    if which == 1 and output_rot and (rot_mat is None):
+        raise ValueError("'rot_mat' must be provided for 'output_rot = True'")
+    if rot_mat is not None:
+        if ((x.shape[0] != rot_mat.shape[0])
+                or (x.shape[1] != rot_mat.shape[1])):
+            raise ValueError("Inconsistent shapes / number of dimensions of "
+                             + "input arrays")
+        if rot_mat.dtype != "float32":
+            raise ValueError("'rot mat' has incorrect data type")
+        rot_mat = np.ascontiguousarray(rot_mat)
+    x = np.ascontiguousarray(x)
+    y = np.ascontiguousarray(y)
+    z = np.ascontiguousarray(z)
+    vec_tilt = np.empty(x.shape + (3,), dtype=np.float32)
+    L = _lib.lib()
+    fn = L.hz_slope_plane_meth if which == 0 else L.hz_slope_vector_meth
+    _lib.check(fn(ptr(x), ptr(y), ptr(z), x.shape[0], x.shape[1], ptr(rot_mat), int(bool(output_rot)),
+                  ptr(vec_tilt), device))
+    return vec_tilt
+
+
+def slope_plane_meth(x, y, z, rot_mat=None, output_rot=False, *, device=0):
+    """Plane-based slope computation (surface normal of the least-squares plane through the
+    centre and its 8 neighbours).  Arguments and result as the reference
+    (topo_param.pyx:16-82): x, y, z float32 (y, x); optional rot_mat float32 (y, x, 3, 3);
+    returns vec_tilt float32 (y, x, 3) with NaN on the outermost ring."""
+    return _slope(0, x, y, z, rot_mat, output_rot, device)
+
+
+def slope_vector_meth(x, y, z, rot_mat=None, output_rot=False, *, device=0):
+    """Vector-based slope computation (average normal of the 4 adjacent triangles,
+    Corripio 2003).  Arguments and result as the reference (topo_param.pyx:230-281)."""
+    return _slope(1, x, y, z, rot_mat, output_rot, device)

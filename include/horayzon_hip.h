@@ -165,6 +165,34 @@ int hz_sky_view_factor(const float *azim, const float *hori, const float *vec_ti
                        int len_0, int len_1, int len_2, float *svf, int device);
 
 /* ------------------------------------------------------------------------- */
+/* Steps next to the path: slope and input preparation */
+/* ------------------------------------------------------------------------- */
+
+/* _slope_plane_meth_cy / _slope_vector_meth_cy, topo_param.pyx:84-225, :284-372.               */
+/* x, y, z f32[len_0][len_1]; rot_mat f32[len_0][len_1][3][3] or NULL; vec_tilt f32[..][3]      */
+/* (border cells NaN).                                                                          */
+int hz_slope_plane_meth(const float *x, const float *y, const float *z, int len_0, int len_1,
+                        const float *rot_mat, int output_rot, float *vec_tilt, int device);
+int hz_slope_vector_meth(const float *x, const float *y, const float *z, int len_0, int len_1,
+                         const float *rot_mat, int output_rot, float *vec_tilt, int device);
+/* ellps: 0 "sphere", 1 "GRS80", 2 "WGS84".                                                     */
+/* _lonlat2ecef_1d, transform.pyx:60-103: lon, lat f64[n] [degree], h f32[n] -> f64[n] x 3      */
+int hz_lonlat2ecef(const double *lon, const double *lat, const float *h, size_t n, int ellps,
+                   double *x_ecef, double *y_ecef, double *z_ecef, int device);
+/* _ecef2enu_1d with TransformerEcef2enu(lon_or, lat_or, ellps), transform.pyx:152-189, 438-487 */
+int hz_ecef2enu(const double *x_ecef, const double *y_ecef, const double *z_ecef, size_t n,
+                double lon_or, double lat_or, int ellps, float *x_enu, float *y_enu, float *z_enu,
+                int device);
+/* _ecef2enu_vector_1d, transform.pyx:231-261: f32[n][3] -> f32[n][3]                           */
+int hz_ecef2enu_vector(const float *vec_ecef, size_t n, double lon_or, double lat_or, int ellps,
+                       float *vec_enu, int device);
+/* _surf_norm_1d, direction.pyx:48-70                                                           */
+int hz_surf_norm(const double *lon, const double *lat, size_t n, float *vec_norm_ecef, int device);
+/* _north_dir_1d, direction.pyx:125-178                                                         */
+int hz_north_dir(const double *x_ecef, const double *y_ecef, const double *z_ecef,
+                 const float *vec_norm_ecef, size_t n, int ellps, float *vec_north_ecef, int device);
+
+/* ------------------------------------------------------------------------- */
 /* Shadow: handle API mirroring class CppTerrain (shadow_comp.h:4-39)          */
 /* ------------------------------------------------------------------------- */
 typedef struct hz_terrain hz_terrain;

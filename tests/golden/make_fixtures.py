@@ -82,3 +82,41 @@ np.savez_compressed(os.path.join(here, "curved_dem_reference.npz"),
                     x_enu=x_enu.astype(np.float32), y_enu=y_enu.astype(np.float32), z_enu=z_enu.astype(np.float32),
                     vec_norm=vec_norm_enu, vec_north=vec_north_enu, offset=np.int32(off))
 print("curved fixture:", x_enu.shape, vec_norm_enu.shape, float(np.abs(z_enu).max()))
+
+# ---- slope (plane / vector method) and the input-preparation chain, all three ellipsoids -----
+out = {}
+rng = np.random.default_rng(11)
+# planar DEM, no rotation matrices
+xp = (np.arange(26) * 40.0).astype(np.float32); yp = ((22 - np.arange(23)) * 35.0).astype(np.float32)
+xx, yy = np.meshgrid(xp, yp)
+zz = (800.0 + 300.0 * np.sin(xx / 400.0) * np.cos(yy / 300.0) + 15.0 * rng.standard_normal(xx.shape)).astype(np.float32)
+out["pl_x"], out["pl_y"], out["pl_z"] = xx, yy, zz
+import io, contextlib   # the reference prints when no rot_mat is given
+with contextlib.redirect_stdout(io.StringIO()):
+    out["pl_tilt_plane"] = topo_param.slope_plane_meth(xx, yy, zz)
+out["pl_tilt_vector"] = topo_param.slope_vector_meth(xx, yy, zz)
+for ellps in ("sphere", "GRS80", "WGS84"):
+    lon = np.linspace(10.0, 10.4, 30); lat = np.linspace(-33.1, -33.4, 26)
+    lon2, lat2 = np.meshgrid(lon, lat)
+    h = (500.0 + 2500.0 * rng.random(lon2.shape)).astype(np.float32)
+    X, Y, Z = transform.lonlat2ecef(lon2, lat2, h, ellps=ellps)
+    tr = transform.TransformerEcef2enu(lon_or=lon.mean(), lat_or=lat.mean(), ellps=ellps)
+    xe, ye, ze = transform.ecef2enu(X, Y, Z, tr)
+    vn = direction.surf_norm(lon2, lat2)
+    vno = direction.north_dir(X, Y, Z, vn, ellps=ellps)
+    vn_enu = transform.ecef2enu_vector(vn, tr)
+    vno_enu = transform.ecef2enu_vector(vno, tr)
+    rot = transform.rotation_matrix_glob2loc(vno_enu[1:-1, 1:-1], vn_enu[1:-1, 1:-1])
+    with contextlib.redirect_stdout(io.StringIO()):
+        t_plane = topo_param.slope_plane_meth(xe, ye, ze, rot_mat=rot, output_rot=False)
+        t_plane_rot = topo_param.slope_plane_meth(xe, ye, ze, rot_mat=rot, output_rot=True)
+        t_vec_rot = topo_param.slope_vector_meth(xe, ye, ze, rot_mat=rot, output_rot=True)
+    t_vec = topo_param.slope_vector_meth(xe, ye, ze)
+    k = ellps + "_"
+    out.update({k + "lon": lon2, k + "lat": lat2, k + "h": h, k + "X": X, k + "Y": Y, k + "Z": Z,
+                k + "origin": np.array([tr.lon_or, tr.lat_or, tr.x_ecef_or, tr.y_ecef_or, tr.z_ecef_or]),
+                k + "x_enu": xe, k + "y_enu": ye, k + "z_enu": ze, k + "norm_ecef": vn, k + "north_ecef": vno,
+                k + "norm_enu": vn_enu, k + "north_enu": vno_enu, k + "rot": rot, k + "tilt_plane": t_plane,
+                k + "tilt_plane_rot": t_plane_rot, k + "tilt_vector": t_vec, k + "tilt_vector_rot": t_vec_rot})
+np.savez_compressed(os.path.join(here, "prep_reference.npz"), **{k: np.asarray(v) for k, v in out.items()})
+print("prep fixtures:", len(out), "arrays")

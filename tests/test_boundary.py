@@ -215,6 +215,37 @@ def test_svf_validation_errors():
         f(azim, hori.astype(np.float64), tilt)
 
 
+def test_prep_host_side_matches_reference_fixture():
+    """Host-only pieces of the input-preparation chain against the reference-made fixture."""
+    import os as _os
+    d = np.load(_os.path.join(ROOT, "tests", "golden", "prep_reference.npz"))
+    T = horayzon_amd.transform
+    for ellps in ("sphere", "GRS80", "WGS84"):
+        org = d[ellps + "_origin"]
+        tr = T.TransformerEcef2enu(lon_or=org[0], lat_or=org[1], ellps=ellps)
+        assert np.allclose([tr.x_ecef_or, tr.y_ecef_or, tr.z_ecef_or], org[2:], rtol=1e-15, atol=1e-8)
+        rot = T.rotation_matrix_glob2loc(d[ellps + "_north_enu"][1:-1, 1:-1], d[ellps + "_norm_enu"][1:-1, 1:-1])
+        assert np.array_equal(np.isnan(rot), np.isnan(d[ellps + "_rot"]))
+        assert np.nanmax(np.abs(rot - d[ellps + "_rot"])) <= 1e-7
+    with pytest.raises(ValueError, match="lon_or"):
+        T.TransformerEcef2enu(200.0, 0.0, "WGS84")
+    with pytest.raises(ValueError, match="ellps"):
+        T.TransformerEcef2enu(0.0, 0.0, "mars")
+    z = np.zeros((3, 3), np.float32)
+    with pytest.raises(ValueError, match="data type"):
+        horayzon_amd.topo_param.slope_plane_meth(z.astype(np.float64), z, z)
+    with pytest.raises(ValueError, match="rot_mat"):
+        horayzon_amd.topo_param.slope_vector_meth(z, z, z, output_rot=True)
+    with pytest.raises(ValueError, match="data type"):
+        T.lonlat2ecef(z, z, z, "WGS84")
+    with pytest.raises(ValueError, match="ellps"):
+        T.lonlat2ecef(z.astype(np.float64), z.astype(np.float64), z, "mars")
+    with pytest.raises(ValueError, match="TransformerEcef2enu"):
+        T.ecef2enu(z.astype(np.float64), z.astype(np.float64), z.astype(np.float64), object())
+    with pytest.raises(ValueError, match="data type"):
+        horayzon_amd.direction.surf_norm(z, z)
+
+
 def test_pack_vertices_layout():
     """vert_grid layout defined by reference auxiliary.py:49-95: interleaved xyz, row-major,
     >= 16 trailing zeros, byte size divisible by 16."""
