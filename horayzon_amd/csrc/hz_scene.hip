@@ -9,7 +9,7 @@
 //                    centroid (x, y); primitive = DEM quad (2 triangles) or TIN triangle
 //   3. rocprim radix sort of (key, primitive id)
 //   4. k_karras      binary radix tree over the sorted keys (Karras 2012)
-//   5. k_refit       leaf AABBs + bottom-up union with one atomic counter per node
+//   5. k_leaf_boxes / k_refit_pass  leaf AABBs; bottom-up union in level-synchronous passes
 //   6. k_roots/scan  collapse along the 2-bit Morton digits: a binary node starts a 4-wide
 //                    node when its common-prefix length enters a new digit (quadtree level)
 //   7. k_emit4       64 B nodes with conservatively quantised child AABBs (8 bit x/y, 16 bit z)
@@ -163,14 +163,9 @@ __global__ __launch_bounds__(256) void k_karras(const uint32_t *__restrict__ key
 }
 
 // --- leaf boxes + bottom-up refit ---------------------------------------------
-// box arrays: lo/hi as float4 (w of lo = height as int bits for internal nodes)
-__global__ __launch_bounds__(256) void k_refit(BuildParams b, const uint32_t *__restrict__ vals,
-                                              const int2 *__restrict__ child,
-                                              const int *__restrict__ parent_int,
-                                              const int *__restrict__ parent_leaf,
-                                              const uint8_t *__restrict__ plen,
-                                              float4 *leaf_lo, float4 *leaf_hi,
-                                              float4 *node_lo, float4 *node_hi, int *counter) {
+// box arrays: lo/hi as float4 (w of lo = 4-wide levels below the node's digit group, as int bits)
+__global__ __launch_bounds__(256) void k_leaf_boxes(BuildParams b, const uint32_t *__restrict__ vals,
+                                                   float4 *__restrict__ leaf_lo, float4 *__restrict__ leaf_hi) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= b.n_prims) return;
     float a[3], bb[3], c[3], d[3];
@@ -184,31 +179,42 @@ __global__ __launch_bounds__(256) void k_refit(BuildParams b, const uint32_t *__
     }
     leaf_lo[s] = make_float4(lo[0], lo[1], lo[2], 0.0f);
     leaf_hi[s] = make_float4(hi[0], hi[1], hi[2], 0.0f);
-    if (b.n_prims == 1) return;
-    int height = 0;
-    int node = parent_leaf[s];
-    __threadfence();
-    while (node >= 0) {
-        if (atomicAdd(&counter[node], 1) == 0) return;   // first arrival: sibling not ready
-        __threadfence();
-        const int2 ch = child[node];
-        // children boxes were published (store -> fence -> counter) before the first arrival
-        const float4 l0 = (ch.x >= 0) ? node_lo[ch.x] : leaf_lo[~ch.x];
-        const float4 h0 = (ch.x >= 0) ? node_hi[ch.x] : leaf_hi[~ch.x];
-        const float4 l1 = (ch.y >= 0) ? node_lo[ch.y] : leaf_lo[~ch.y];
-        const float4 h1 = (ch.y >= 0) ? node_hi[ch.y] : leaf_hi[~ch.y];
-        // 4-wide levels strictly below this node's digit group (see k_roots)
-        const int dg = plen[node] >> 1;
-        const int hgt0 = (ch.x >= 0) ? __float_as_int(l0.w) + (((plen[ch.x] >> 1) != dg) ? 1 : 0) : 0;
-        const int hgt1 = (ch.y >= 0) ? __float_as_int(l1.w) + (((plen[ch.y] >> 1) != dg) ? 1 : 0) : 0;
-        height = max(hgt0, hgt1);
-        float4 nl = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), __int_as_float(height));
-        float4 nh = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 0.0f);
-        node_lo[node] = nl;
-        node_hi[node] = nh;
-        __threadfence();
-        node = parent_int[node];
+}
+
+// One refit pass: a node whose children were finished in EARLIER passes (done[child] < pass) takes
+// the union of their boxes.  Kernel boundaries give the ordering, so no fences or atomics on the
+// data path (an in-kernel atomic-counter refit spent 97 % of the build in cache write-backs on the
+// 8-XCD part).  The host repeats the pass until every node is done (= binary tree height passes;
+// late passes only stream one byte per node).
+__global__ __launch_bounds__(256) void k_refit_pass(int n_nodes, int pass, const int2 *__restrict__ child,
+                                                   const uint8_t *__restrict__ plen,
+                                                   const float4 *__restrict__ leaf_lo,
+                                                   const float4 *__restrict__ leaf_hi, float4 *node_lo,
+                                                   float4 *node_hi, uint8_t *done, unsigned int *n_done) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool fin = false;
+    if (i < n_nodes && done[i] == 0) {
+        const int2 ch = child[i];
+        const bool r0 = (ch.x < 0) || (done[ch.x] != 0 && done[ch.x] < pass);
+        const bool r1 = (ch.y < 0) || (done[ch.y] != 0 && done[ch.y] < pass);
+        if (r0 && r1) {
+            const float4 l0 = (ch.x >= 0) ? node_lo[ch.x] : leaf_lo[~ch.x];
+            const float4 h0 = (ch.x >= 0) ? node_hi[ch.x] : leaf_hi[~ch.x];
+            const float4 l1 = (ch.y >= 0) ? node_lo[ch.y] : leaf_lo[~ch.y];
+            const float4 h1 = (ch.y >= 0) ? node_hi[ch.y] : leaf_hi[~ch.y];
+            // 4-wide levels strictly below this node's digit group (see k_roots)
+            const int dg = plen[i] >> 1;
+            const int hgt0 = (ch.x >= 0) ? __float_as_int(l0.w) + (((plen[ch.x] >> 1) != dg) ? 1 : 0) : 0;
+            const int hgt1 = (ch.y >= 0) ? __float_as_int(l1.w) + (((plen[ch.y] >> 1) != dg) ? 1 : 0) : 0;
+            node_lo[i] = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z),
+                                     __int_as_float(max(hgt0, hgt1)));
+            node_hi[i] = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 0.0f);
+            done[i] = (uint8_t)pass;
+            fin = true;
+        }
     }
+    const unsigned long long m = __ballot(fin);
+    if (m != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(n_done, (unsigned)__popcll(m));
 }
 
 // --- collapse to 4-wide nodes --------------------------------------------------------
@@ -500,16 +506,32 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     HZ_HIP(b_first.alloc((size_t)n_bin * 4));
     HZ_HIP(b_llo.alloc((size_t)n_prims * 16)); HZ_HIP(b_lhi.alloc((size_t)n_prims * 16));
     HZ_HIP(b_nlo.alloc((size_t)n_bin * 16)); HZ_HIP(b_nhi.alloc((size_t)n_bin * 16));
-    HZ_HIP(b_cnt.alloc((size_t)n_bin * 4));
-    HZ_HIP(hipMemsetAsync(b_cnt.p, 0, (size_t)n_bin * 4, st));
+    HZ_HIP(b_cnt.alloc((size_t)n_bin + 16));                       // done[] (pass index per node) + counter
+    HZ_HIP(hipMemsetAsync(b_cnt.p, 0, (size_t)n_bin + 16, st));
     HZ_HIP(hipMemsetAsync(b_nlo.p, 0, (size_t)n_bin * 16, st));
     if (n_prims > 1)
         hipLaunchKernelGGL(k_karras, dim3((n_prims - 1 + 255) / 256), dim3(256), 0, st, keys, n_prims,
                            (int2 *)b_child.p, (int *)b_pint.p, (int *)b_pleaf.p, (uint8_t *)b_plen.p,
                            (int *)b_first.p);
-    hipLaunchKernelGGL(k_refit, dim3(gp), dim3(256), 0, st, bp, vals, (const int2 *)b_child.p,
-                       (const int *)b_pint.p, (const int *)b_pleaf.p, (const uint8_t *)b_plen.p,
-                       (float4 *)b_llo.p, (float4 *)b_lhi.p, (float4 *)b_nlo.p, (float4 *)b_nhi.p, (int *)b_cnt.p);
+    hipLaunchKernelGGL(k_leaf_boxes, dim3(gp), dim3(256), 0, st, bp, vals, (float4 *)b_llo.p, (float4 *)b_lhi.p);
+    if (n_prims > 1) {
+        uint8_t *done = (uint8_t *)b_cnt.p;
+        unsigned int *n_done = (unsigned int *)((char *)b_cnt.p + (((size_t)n_bin + 3) & ~(size_t)3));
+        unsigned int finished = 0;
+        for (int pass = 1; pass < 250 && finished < (unsigned)n_bin; pass++) {
+            hipLaunchKernelGGL(k_refit_pass, dim3(gn), dim3(256), 0, st, n_bin, pass, (const int2 *)b_child.p,
+                               (const uint8_t *)b_plen.p, (const float4 *)b_llo.p, (const float4 *)b_lhi.p,
+                               (float4 *)b_nlo.p, (float4 *)b_nhi.p, done, n_done);
+            if (pass >= 8 && (pass & 3) == 0) {                       // poll the progress counter every 4th pass
+                HZ_HIP(hipMemcpyAsync(&finished, n_done, 4, hipMemcpyDeviceToHost, st));
+                HZ_HIP(hipStreamSynchronize(st));
+            }
+        }
+        HZ_HIP(hipMemcpyAsync(&finished, n_done, 4, hipMemcpyDeviceToHost, st));
+        HZ_HIP(hipStreamSynchronize(st));
+        if (finished != (unsigned)n_bin)
+            return set_error(HZ_ERR_DEPTH, "BVH refit did not converge (%u of %d nodes)", finished, n_bin);
+    }
 
     // ---- 6. which binary nodes open a 4-wide node; compact indices ------------------------
     int n4 = 1;
