@@ -23,6 +23,7 @@
 // The float/double promotion pattern of the reference's index arithmetic is
 // reproduced exactly (hard part 2); tables are built on the
 // host with the reference's expressions (hz_api.cpp) and only read here.
+#include <cstdlib>
 #include "hz_search.h"
 
 namespace hz {
@@ -39,20 +40,20 @@ struct HorizonParams {
     int row_begin, row_end;
     int tiles_j, n_tiles, chunk;   // tile grid of the slab; chunk = ceil(n_tiles / 8)
     float dist, hori_fill, ray_org_elev;
-    int top_nodes, regroup, stack_bytes, leaf_bias;
+    int top_nodes, regroup, stack_bytes, leaf_bias, stage_bytes;
     unsigned long long *counters;
 };
 
-// LDS: [ per-lane stacks int[depth][256] | top-of-tree nodelet Node[top_nodes] ]
-template <int ALG, bool COUNT>
+// LDS: [ per-lane stacks int[depth][256] | output staging float[4][256] | top-of-tree nodelet Node[top_nodes] ]
+template <int ALG, bool COUNT, bool STAGE>
 __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *stack = reinterpret_cast<int *>(smem);
-    const float4 *top = reinterpret_cast<const float4 *>(smem + p.stack_bytes);
+    const float4 *top = reinterpret_cast<const float4 *>(smem + p.stack_bytes + p.stage_bytes);
     const int tid = threadIdx.x;
     const int ntop = p.top_nodes;
     if (ntop > 0) {   // stage the breadth-first top of the tree in LDS (coalesced 16 B per lane)
-        float4 *dst = reinterpret_cast<float4 *>(smem + p.stack_bytes);
+        float4 *dst = reinterpret_cast<float4 *>(smem + p.stack_bytes + p.stage_bytes);
         const float4 *src = reinterpret_cast<const float4 *>(p.sv.nodes);
         for (int i = tid; i < ntop * 4; i += HZ_TPB) dst[i] = src[i];
         __syncthreads();
@@ -73,6 +74,8 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
     Sink out;
     out.hori = p.hori + cell * (size_t)t.azim_num;
     out.dist = nullptr; out.dist_hit = 0.0f;
+    out.stage = reinterpret_cast<float *>(smem + p.stack_bytes) + tid;   // only touched when STAGE
+    out.stride = HZ_TPB;
     float ox = 0, oy = 0, oz = 0;
     float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
     if (in_dom) {
@@ -99,7 +102,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
 
     Search s;
     s.k = 0; s.phase = PH_NEWAZ; s.ind = 0; s.prev = 0; s.pazim = 0; s.count = 0;
-    s.lim_up = 0; s.lim_low = 0; s.elev_samp = 0;
+    s.lim_up = 0; s.lim_low = 0; s.elev_samp = 0; s.ev = 0;
     unsigned rays = 0, guards = 0, w_adv = 0;
     TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.w_nodes = 0; tc.w_leaves = 0;   // COUNT only
     const unsigned cells_cnt = (in_dom && !done) ? 1u : 0u;
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
         // ---- refill: lanes without a ray take the next sample of their search -----------------
         if (!done && !ray_active) {
             if (COUNT) HZ_WAVE_TICK(w_adv, lane);
-            if (advance<ALG>(s, last_hit, t, out, guards)) {
+            if (advance<ALG, STAGE>(s, last_hit, t, out, guards)) {
                 // local direction (east, north, up) and rotation: horizon_comp.cpp:357-361, :55-62
                 const float ec = t.elev_cos[s.ind], es = t.elev_sin[s.ind];
                 const float rx = ec * t.azim_sin[s.k], ry = ec * t.azim_cos[s.k], rz = es;
@@ -156,19 +159,20 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
     }
 }
 
-template <int ALG>
-static int launch_alg(const HorizonParams &p, int grid, size_t lds, bool count, hipStream_t st) {
-    if (count) {
-        HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_horizon<ALG, true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_horizon<ALG, true>), dim3(grid), dim3(HZ_TPB), lds, st, p);
-    } else {
-        HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_horizon<ALG, false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_horizon<ALG, false>), dim3(grid), dim3(HZ_TPB), lds, st, p);
-    }
+template <int ALG, bool COUNT, bool STAGE>
+static int launch_one(const HorizonParams &p, int grid, size_t lds, hipStream_t st) {
+    HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_horizon<ALG, COUNT, STAGE>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_horizon<ALG, COUNT, STAGE>), dim3(grid), dim3(HZ_TPB), lds, st, p);
     HZ_HIP(hipGetLastError());
     return HZ_OK;
+}
+
+template <int ALG>
+static int launch_alg(const HorizonParams &p, int grid, size_t lds, bool count, hipStream_t st) {
+    const bool stage = p.stage_bytes != 0;
+    if (count) return stage ? launch_one<ALG, true, true>(p, grid, lds, st) : launch_one<ALG, true, false>(p, grid, lds, st);
+    return stage ? launch_one<ALG, false, true>(p, grid, lds, st) : launch_one<ALG, false, false>(p, grid, lds, st);
 }
 
 int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
@@ -193,12 +197,16 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
     // stack: at most 3 pending siblings per 4-wide level
     const int depth = 3 * std::max(sc->hdr.height, 1);
     p.stack_bytes = depth * HZ_TPB * 4;
+    // output staging (4 azimuths per lane) when the 16 B stores are aligned: azim_num % 4 == 0
+    p.stage_bytes = ((a.azim_num & 3) == 0 && (reinterpret_cast<size_t>(a.hori) & 15) == 0) ? 4 * HZ_TPB * 4 : 0;
+    if (getenv("HZ_NO_STAGE")) p.stage_bytes = 0;   // A/B switch for measurements
     // LDS nodelet: whatever LDS is left at the workgroup residency the stacks allow (160 KiB per CU)
     int top = a.top_nodes;
     if (top < 0) {
         const int lds_cu = 160 * 1024;
-        const int blocks = std::max(1, std::min(8, lds_cu / std::max(p.stack_bytes, 1)));
-        top = std::max(0, (lds_cu / blocks - p.stack_bytes) / (int)sizeof(Node));
+        const int fixed = p.stack_bytes + p.stage_bytes;
+        const int blocks = std::max(1, std::min(8, lds_cu / std::max(fixed, 1)));
+        top = std::max(0, (lds_cu / blocks - fixed) / (int)sizeof(Node));
     }
     top = std::min(top, sc->hdr.n_top);
     p.top_nodes = top;
@@ -207,7 +215,7 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
     p.regroup = (a.regroup < 0) ? 48 : std::min(a.regroup & 0xff, 64);
     p.leaf_bias = (a.regroup >= 256) ? (a.regroup >> 8) : 24;
     p.counters = a.counters;
-    const size_t lds = (size_t)p.stack_bytes + (size_t)top * sizeof(Node);
+    const size_t lds = (size_t)p.stack_bytes + (size_t)p.stage_bytes + (size_t)top * sizeof(Node);
     const int grid = p.chunk * 8;
     const bool count = a.count_work != 0;
     switch (a.alg) {

@@ -68,9 +68,10 @@ __global__ __launch_bounds__(HZ_TPB) void k_locations(LocParams p) {
     out.hori = p.hori + ii * (size_t)t.azim_num;
     out.dist = DIST ? p.dist + ii * (size_t)t.azim_num : nullptr;
     out.dist_hit = 0.0f;
+    out.stage = nullptr; out.stride = 0;
     Search s;
     s.k = 0; s.phase = PH_NEWAZ; s.ind = 0; s.prev = 0; s.pazim = 0; s.count = 0;
-    s.lim_up = 0; s.lim_low = 0; s.elev_samp = 0;
+    s.lim_up = 0; s.lim_low = 0; s.elev_samp = 0; s.ev = 0;
     unsigned rays = 0, guards = 0;
     bool last_hit = false;
     TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.w_nodes = 0; tc.w_leaves = 0;
@@ -78,7 +79,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_locations(LocParams p) {
         bool have_ray = false;
         float dx = 0, dy = 0, dz = 1;
         if (!done) {
-            if (advance<ALG>(s, last_hit, t, out, guards)) {
+            if (advance<ALG, false>(s, last_hit, t, out, guards)) {
                 const float ec = t.elev_cos[s.ind], es = t.elev_sin[s.ind];
                 const float rx = ec * t.azim_sin[s.k], ry = ec * t.azim_cos[s.k], rz = es;
                 dx = (r00 * rx + r01 * ry) + r02 * rz;

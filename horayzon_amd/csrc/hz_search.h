@@ -9,7 +9,7 @@
 namespace hz {
 
 enum { ALG_DISCRETE = 0, ALG_BINARY = 1, ALG_GUESS = 2 };
-enum { PH_NEWAZ = 0, PH_BIN = 1, PH_UP = 2, PH_DOWN = 3 };
+enum { PH_NEWAZ = 0, PH_BIN = 1, PH_UP = 2, PH_DOWN = 3, PH_EMIT = 4 };
 
 struct Tables {
     const float *azim_sin, *azim_cos, *elev_ang, *elev_sin, *elev_cos;
@@ -21,6 +21,7 @@ struct Tables {
 struct Search {
     int k, phase, ind, prev, pazim, count;
     float lim_up, lim_low, elev_samp;
+    float ev;   // value to emit for azimuth k (phase PH_EMIT): one emit site keeps the code small
 };
 
 // (int)roundf((elev_samp - low) / (hori_acc / 5.0)), horizon_comp.cpp:351-352
@@ -37,20 +38,40 @@ struct Sink {
     float *hori;         // &hori_buffer[cell * azim_num]
     float *dist;         // &hori_dist_buffer[cell * azim_num] or null
     float dist_hit;      // distance of the last hit ray; persists across azimuths (horizon_comp.cpp:526-527)
+    float *stage;        // LDS staging of 4 consecutive azimuths of this lane (stage[j * stride]) or null
+    int stride;
 };
 
+// A lane produces its azimuths one at a time; a 4 B store per lane at stride 4*A bytes costs a
+// 32 B memory sector each (8x write amplification measured).  With STAGE, four consecutive
+// values of a lane are collected in LDS and leave as one 16 B store (requires azim_num % 4 == 0
+// and a 16 B aligned buffer; checked by the launcher).
+template <bool STAGE>
 __device__ __forceinline__ void emit(Sink &s, const Tables &, int k, float h) {
-    s.hori[k] = h;
+    if (STAGE) {
+        if ((k & 3) == 3) {
+            const float4 v = make_float4(s.stage[0], s.stage[s.stride], s.stage[2 * s.stride], h);
+            *reinterpret_cast<float4 *>(s.hori + (k - 3)) = v;
+        } else {
+            s.stage[(k & 3) * s.stride] = h;
+        }
+    } else {
+        s.hori[k] = h;
+    }
     if (s.dist) s.dist[k] = s.dist_hit;   // :552, :608
 }
 
 // Consume the result of the previous ray (if any) and produce the next sample.
 // Returns true with s.ind / s.k identifying the next ray, false when the cell is finished.
-template <int ALG>
+template <int ALG, bool STAGE>
 __device__ __forceinline__ bool advance(Search &s, bool hit, const Tables &t, Sink &out,
                                         unsigned &guards) {
     const int top = t.elev_num - 1;
     for (;;) {
+        if (s.phase == PH_EMIT) {                              // the only place that writes output
+            emit<STAGE>(out, t, s.k, s.ev);
+            s.k++; s.phase = PH_NEWAZ;
+        }
         if (s.phase == PH_NEWAZ) {
             if (s.k >= t.azim_num) return false;
             const bool binary = (ALG == ALG_BINARY) || (ALG == ALG_GUESS && s.k == 0);
@@ -61,8 +82,7 @@ __device__ __forceinline__ bool advance(Search &s, bool hit, const Tables &t, Si
                 s.phase = PH_BIN;
                 const float e = t.elev_ang[s.ind];
                 if (__builtin_fmaxf(s.lim_up - e, e - s.lim_low) > t.hori_acc) return true;
-                emit(out, t, s.k, s.elev_samp);
-                s.pazim = s.ind; s.k++; s.phase = PH_NEWAZ;
+                s.ev = s.elev_samp; s.pazim = s.ind; s.phase = PH_EMIT;
                 continue;
             }
             // move upwards: horizon_comp.cpp:311-317 (discrete, from index 0) / :439-446
@@ -80,8 +100,7 @@ __device__ __forceinline__ bool advance(Search &s, bool hit, const Tables &t, Si
             s.ind = ind_of(t, s.elev_samp);
             const float e = t.elev_ang[s.ind];
             if (__builtin_fmaxf(s.lim_up - e, e - s.lim_low) > t.hori_acc) return true;
-            emit(out, t, s.k, s.elev_samp);                  // :376 / :428
-            s.pazim = s.ind; s.k++; s.phase = PH_NEWAZ;
+            s.ev = s.elev_samp; s.pazim = s.ind; s.phase = PH_EMIT;   // :376 / :428
             continue;
         }
         if (s.phase == PH_UP) {
@@ -94,15 +113,13 @@ __device__ __forceinline__ bool advance(Search &s, bool hit, const Tables &t, Si
             }
             if (guard) guards++;
             if (ALG == ALG_DISCRETE) {                       // :330
-                emit(out, t, s.k, half_sum(t.elev_ang[s.prev], t.elev_ang[s.ind]));
-                s.k++; s.phase = PH_NEWAZ;
+                s.ev = half_sum(t.elev_ang[s.prev], t.elev_ang[s.ind]); s.phase = PH_EMIT;
                 continue;
             }
             if (s.count > 1) {                               // :460-467
                 const float es = half_sum(t.elev_ang[s.prev], t.elev_ang[s.ind]);
                 s.ind = ind_of(t, es);
-                emit(out, t, s.k, t.elev_ang[s.ind]);
-                s.pazim = s.ind; s.k++; s.phase = PH_NEWAZ;
+                s.ev = t.elev_ang[s.ind]; s.pazim = s.ind; s.phase = PH_EMIT;
                 continue;
             }
             // move downwards: :472-477
@@ -123,8 +140,7 @@ __device__ __forceinline__ bool advance(Search &s, bool hit, const Tables &t, Si
             if (guard) guards++;
             const float es = half_sum(t.elev_ang[s.prev], t.elev_ang[s.ind]);   // :490-494
             s.ind = ind_of(t, es);
-            emit(out, t, s.k, t.elev_ang[s.ind]);
-            s.pazim = s.ind; s.k++; s.phase = PH_NEWAZ;
+            s.ev = t.elev_ang[s.ind]; s.pazim = s.ind; s.phase = PH_EMIT;
             continue;
         }
     }
