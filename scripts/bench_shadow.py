@@ -17,7 +17,6 @@ from horayzon_amd import _lib, synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--n", type=int, default=3601)
 ap.add_argument("--suns", type=int, default=144)
-ap.add_argument("--cpu-suns", type=int, default=0, help="also time the CPU oracle on this many sun positions")
 args = ap.parse_args()
 
 n, off = args.n, 16
@@ -55,18 +54,4 @@ for refrac in (0, 1):
             res[key]["frac_codes_0123"] = [float((o == c).mean()) for c in range(4)]
         del out
     L.hz_terrain_destroy(th)
-if args.cpu_suns > 0:
-    from oracle import oracle as orc
-    t = orc.Terrain()
-    t0 = time.time()
-    t.initialise(g["vert_grid"], n, n, off, off, vec_tilt, vec_norm, enl, elev, mask, refrac_cor=False)
-    tb = time.time() - t0
-    buf = np.empty((in0, in1), np.uint8)
-    day = np.argsort(-alt)[:args.cpu_suns]
-    t0 = time.time(); rays = 0
-    for s in day:
-        t.shadow(suns[s], buf); rays += t.rays
-    dt = time.time() - t0
-    res["cpu_oracle_shadow"] = {"suns": int(args.cpu_suns), "threads": orc.num_threads(), "build_s": tb, "s": dt,
-                                "cells_per_s": args.cpu_suns * in0 * in1 / dt, "mray_per_s": rays / dt / 1e6}
 print(json.dumps(res))
