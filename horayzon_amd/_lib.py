@@ -11,7 +11,7 @@ import sys
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhorayzon_hip.so")
+LIB_PATH = os.environ.get("HORAYZON_HIP_LIB") or os.path.join(_HERE, "libhorayzon_hip.so")
 _lib = None
 
 
@@ -49,7 +49,7 @@ SYMBOLS = (
     "hz_scene_create", "hz_scene_blob", "hz_scene_adopt", "hz_scene_destroy",
     "hz_horizon_gridded", "hz_horizon_gridded_scene", "hz_horizon_locations",
     "hz_horizon_locations_scene", "hz_horizon_tables",
-    "hz_sky_view_factor",
+    "hz_sky_view_factor", "hz_visible_sky_fraction", "hz_topographic_openness",
     "hz_slope_plane_meth", "hz_slope_vector_meth", "hz_lonlat2ecef", "hz_ecef2enu",
     "hz_ecef2enu_vector", "hz_surf_norm", "hz_north_dir",
     "hz_terrain_create", "hz_terrain_initialise", "hz_terrain_initialise_scene",
@@ -117,6 +117,8 @@ def lib():
     L.hz_horizon_tables.argtypes = [ip, C.c_float, C.c_float, vp, vp, ip, vp, vp, vp,
                                     C.POINTER(C.c_int)]
     L.hz_sky_view_factor.argtypes = [vp, vp, vp, ip, ip, ip, vp, ip]
+    L.hz_visible_sky_fraction.argtypes = [vp, vp, vp, ip, ip, ip, vp, ip]
+    L.hz_topographic_openness.argtypes = [vp, vp, ip, ip, ip, vp, ip]
     L.hz_slope_plane_meth.argtypes = [vp, vp, vp, ip, ip, vp, ip, vp, ip]
     L.hz_slope_vector_meth.argtypes = [vp, vp, vp, ip, ip, vp, ip, vp, ip]
     L.hz_lonlat2ecef.argtypes = [vp, vp, vp, C.c_size_t, ip, vp, vp, vp, ip]

@@ -593,24 +593,37 @@ int hz_horizon_tables(int azim_num, float hori_acc, float elev_ang_low_lim, floa
     return HZ_OK;
 }
 
-int hz_sky_view_factor(const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
-                       int len_2, float *svf, int device) {
-    if (!azim || !hori || !vec_tilt || !svf) return set_error(HZ_ERR_ARG, "NULL argument");
+static int topo_api(int kind, const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
+                    int len_2, float *out, int device) {
+    if (!azim || !hori || !out || (kind != 2 && !vec_tilt)) return set_error(HZ_ERR_ARG, "NULL argument");
     if (len_0 <= 0 || len_1 <= 0 || len_2 < 2) return set_error(HZ_ERR_ARG, "Inconsistent/incorrect shapes of input arrays");
     int rc = select_device(device);
     if (rc) return rc;
     hipStream_t st = nullptr;
     const size_t ncell = (size_t)len_0 * len_1;
     DevIn<float> d_azim, d_hori, d_tilt;
-    DevOut<float> d_svf;
+    DevOut<float> d_out;
     if ((rc = d_azim.bind(azim, (size_t)len_2, st))) return rc;
     if ((rc = d_hori.bind(hori, ncell * (size_t)len_2, st))) return rc;
-    if ((rc = d_tilt.bind(vec_tilt, ncell * 3, st))) return rc;
-    if ((rc = d_svf.bind(svf, ncell))) return rc;
-    if ((rc = svf_launch(d_azim.dev, d_hori.dev, d_tilt.dev, len_0, len_1, len_2, d_svf.dev, st))) return rc;
-    if ((rc = d_svf.finish(st))) return rc;
+    if (kind != 2) if ((rc = d_tilt.bind(vec_tilt, ncell * 3, st))) return rc;
+    if ((rc = d_out.bind(out, ncell))) return rc;
+    if ((rc = topo_launch(kind, d_azim.dev, d_hori.dev, d_tilt.dev, len_0, len_1, len_2, d_out.dev, st))) return rc;
+    if ((rc = d_out.finish(st))) return rc;
     HZ_HIP(hipStreamSynchronize(st));
     return HZ_OK;
+}
+
+int hz_sky_view_factor(const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
+                       int len_2, float *svf, int device) {
+    return topo_api(0, azim, hori, vec_tilt, len_0, len_1, len_2, svf, device);
+}
+int hz_visible_sky_fraction(const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
+                            int len_2, float *vsf, int device) {
+    return topo_api(1, azim, hori, vec_tilt, len_0, len_1, len_2, vsf, device);
+}
+int hz_topographic_openness(const float *azim, const float *hori, int len_0, int len_1, int len_2, float *top,
+                            int device) {
+    return topo_api(2, azim, hori, nullptr, len_0, len_1, len_2, top, device);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -226,40 +226,61 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
 }
 
 // ---------------------------------------------------------------------------------------
-// stand-alone sky view factor from a horizon array (topo_param.pyx:412-460).
-// One lane per cell; the 4*A bytes of a cell are read by consecutive k, so a wave streams
-// 64 rows of A floats (HBM bound: 4*A + 12 B in, 4 B out per cell).
+// reductions over the azimuth axis of a horizon array (topo_param.pyx):
+//   KIND 0  sky view factor        _sky_view_factor_cy        :412-460
+//   KIND 1  visible sky fraction   _visible_sky_fraction_cy   :499-543
+//   KIND 2  topographic openness   _topographic_openness_cy   :577-603
+// One lane per cell, float32 accumulator and float64 libm calls as the Cython code has them
+// (HBM bound: 4*A (+12) B in, 4 B out per cell).
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_svf(const float *__restrict__ azim, const float *__restrict__ hori,
-                                            const float *__restrict__ vec_tilt, size_t ncell, int A,
-                                            float *__restrict__ svf) {
+template <int KIND>
+__global__ __launch_bounds__(256) void k_topo(const float *__restrict__ azim, const float *__restrict__ hori,
+                                             const float *__restrict__ vec_tilt, size_t ncell, int A,
+                                             float *__restrict__ out) {
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncell) return;
-    const float tx = vec_tilt[3 * c], ty = vec_tilt[3 * c + 1], tz = vec_tilt[3 * c + 2];
+    float tx = 0.0f, ty = 0.0f, tz = 1.0f;
+    if (KIND != 2) { tx = vec_tilt[3 * c]; ty = vec_tilt[3 * c + 1]; tz = vec_tilt[3 * c + 2]; }
     const float *h = hori + c * (size_t)A;
     float agg = 0.0f;
     for (int k = 0; k < A; k++) {
+        const float hv = h[k];
+        if (KIND == 2) {
+            agg = (float)(((double)agg + (3.14159265358979323846 / 2.0)) - (double)hv);     // :599
+            continue;
+        }
         const float as = (float)sin((double)azim[k]), ac = (float)cos((double)azim[k]);
         const float hori_plane = (float)atan((double)(-as * tx / tz - ac * ty / tz));
-        const float hv = h[k];
         const float he = (hv >= hori_plane) ? hv : hori_plane;
-        const double ce = cos((double)he);
-        agg = (float)((double)agg + ((double)(tx * as + ty * ac)
-                      * ((3.14159265358979323846 / 2.0) - (double)he - (sin(2.0 * (double)he) / 2.0))
-                      + (double)tz * (ce * ce)));
+        if (KIND == 0) {
+            const double ce = cos((double)he);
+            agg = (float)((double)agg + ((double)(tx * as + ty * ac)
+                          * ((3.14159265358979323846 / 2.0) - (double)he - (sin(2.0 * (double)he) / 2.0))
+                          + (double)tz * (ce * ce)));
+        } else {
+            agg = (float)((double)agg + (1.0 - cos((3.14159265358979323846 / 2.0) - (double)he)));   // :540
+        }
     }
+    if (KIND == 2) { out[c] = agg / (float)A; return; }                                     // :601
     const float azim_spac = azim[1] - azim[0];
-    svf[c] = (float)(((double)azim_spac / (2.0 * 3.14159265358979323846)) * (double)agg);
+    out[c] = (float)(((double)azim_spac / (2.0 * 3.14159265358979323846)) * (double)agg);
+}
+
+int topo_launch(int kind, const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
+                int len_2, float *out, hipStream_t st) {
+    const size_t ncell = (size_t)len_0 * len_1;
+    if (ncell == 0) return HZ_OK;
+    const dim3 grid((unsigned)((ncell + 255) / 256)), block(256);
+    if (kind == 0) hipLaunchKernelGGL(k_topo<0>, grid, block, 0, st, azim, hori, vec_tilt, ncell, len_2, out);
+    else if (kind == 1) hipLaunchKernelGGL(k_topo<1>, grid, block, 0, st, azim, hori, vec_tilt, ncell, len_2, out);
+    else hipLaunchKernelGGL(k_topo<2>, grid, block, 0, st, azim, hori, vec_tilt, ncell, len_2, out);
+    HZ_HIP(hipGetLastError());
+    return HZ_OK;
 }
 
 int svf_launch(const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
                int len_2, float *svf, hipStream_t st) {
-    const size_t ncell = (size_t)len_0 * len_1;
-    if (ncell == 0) return HZ_OK;
-    hipLaunchKernelGGL(k_svf, dim3((unsigned)((ncell + 255) / 256)), dim3(256), 0, st, azim, hori, vec_tilt,
-                       ncell, len_2, svf);
-    HZ_HIP(hipGetLastError());
-    return HZ_OK;
+    return topo_launch(0, azim, hori, vec_tilt, len_0, len_1, len_2, svf, st);
 }
 
 }  // namespace hz

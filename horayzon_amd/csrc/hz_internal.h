@@ -82,6 +82,8 @@ struct HorizonArgs {
     unsigned long long *counters;        // device u64[8]: [0] rays, [1] guards, [2] nodes, [3] tris, [4] cells
 };
 int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st);
+int topo_launch(int kind, const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
+                int len_2, float *out, hipStream_t st);
 int svf_launch(const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
                int len_2, float *svf, hipStream_t st);
 

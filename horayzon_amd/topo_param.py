@@ -29,6 +29,39 @@ def sky_view_factor(azim, hori, vec_tilt, *, device=0):
     return svf
 
 
+def visible_sky_fraction(azim, hori, vec_tilt, *, device=0):
+    """Visible sky fraction (solid angle of the visible sky); arguments, checks and result as the
+    reference (topo_param.pyx:465-496)."""
+    if (len(azim) != hori.shape[2]) or (hori.shape[:2] != vec_tilt.shape[:2])\
+            or (vec_tilt.shape[2] != 3):
+        raise ValueError("Inconsistent/incorrect shapes of input arrays")
+    if ((azim.dtype != "float32") or (hori.dtype != "float32")
+            or (vec_tilt.dtype != "float32")):
+        raise ValueError("Input array(s) has/have incorrect data type(s)")
+    azim = np.ascontiguousarray(azim)
+    hori = np.ascontiguousarray(hori)
+    vec_tilt = np.ascontiguousarray(vec_tilt)
+    vsf = np.empty(hori.shape[:2], dtype=np.float32)
+    _lib.check(_lib.lib().hz_visible_sky_fraction(ptr(azim), ptr(hori), ptr(vec_tilt), hori.shape[0],
+                                                  hori.shape[1], hori.shape[2], ptr(vsf), device))
+    return vsf
+
+
+def topographic_openness(azim, hori, *, device=0):
+    """Positive topographic openness (Yokoyama et al. 2002) [radian]; arguments, checks and result as
+    the reference (topo_param.pyx:548-574)."""
+    if len(azim) != hori.shape[2]:
+        raise ValueError("Inconsistent/incorrect shapes of input arrays")
+    if (azim.dtype != "float32") or (hori.dtype != "float32"):
+        raise ValueError("Input array(s) has/have incorrect data type(s)")
+    azim = np.ascontiguousarray(azim)
+    hori = np.ascontiguousarray(hori)
+    top = np.empty(hori.shape[:2], dtype=np.float32)
+    _lib.check(_lib.lib().hz_topographic_openness(ptr(azim), ptr(hori), hori.shape[0], hori.shape[1],
+                                                  hori.shape[2], ptr(top), device))
+    return top
+
+
 def _slope(which, x, y, z, rot_mat, output_rot, device):
     # Check arguments (topo_param.pyx:59-72 / :262-277)
     if (x.shape != y.shape) or (y.shape != z.shape):

@@ -163,6 +163,12 @@ int hz_horizon_tables(int azim_num, float hori_acc, float elev_ang_low_lim,
 /* topo_param.pyx:412-460.                                                     */
 int hz_sky_view_factor(const float *azim, const float *hori, const float *vec_tilt,
                        int len_0, int len_1, int len_2, float *svf, int device);
+/* _visible_sky_fraction_cy (topo_param.pyx:499-543) and _topographic_openness_cy (:577-603):   */
+/* the other two reductions of the same horizon array.                                          */
+int hz_visible_sky_fraction(const float *azim, const float *hori, const float *vec_tilt,
+                            int len_0, int len_1, int len_2, float *vsf, int device);
+int hz_topographic_openness(const float *azim, const float *hori, int len_0, int len_1, int len_2,
+                            float *top, int device);
 
 /* ------------------------------------------------------------------------- */
 /* Steps next to the path: slope and input preparation */

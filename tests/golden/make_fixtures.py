@@ -50,6 +50,8 @@ for name, (ny, nx, na, hmax, smax) in {"a": (16, 16, 36, 40.0, 35.0),
     out["hori_" + name] = hori
     out["tilt_" + name] = tilt
     out["svf_" + name] = np.asarray(svf, np.float32)
+    out["vsf_" + name] = np.asarray(topo_param.visible_sky_fraction(azim, hori, tilt), np.float32)
+    out["top_" + name] = np.asarray(topo_param.topographic_openness(azim, hori), np.float32)
 # closed forms: flat horizon & flat tilt -> 1; uniform 30 deg horizon -> cos^2(30 deg)
 azim = out["azim_a"]
 flat = np.zeros((2, 2, 36), np.float32)

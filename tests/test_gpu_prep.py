@@ -17,6 +17,17 @@ def _close(a, b, tol):
     assert np.abs(a[m].astype(np.float64) - b[m].astype(np.float64)).max() <= tol
 
 
+def test_visible_sky_fraction_and_openness(hip):
+    d = np.load(os.path.join(os.path.dirname(GOLD), "svf_reference.npz"))
+    for n in "abc":
+        vsf = hip.topo_param.visible_sky_fraction(d["azim_" + n], d["hori_" + n], d["tilt_" + n])
+        top = hip.topo_param.topographic_openness(d["azim_" + n], d["hori_" + n])
+        svf = hip.topo_param.sky_view_factor(d["azim_" + n], d["hori_" + n], d["tilt_" + n])
+        assert np.abs(vsf - d["vsf_" + n]).max() <= 1e-5
+        assert np.abs(top - d["top_" + n]).max() <= 1e-5
+        assert np.abs(svf - d["svf_" + n]).max() <= 1e-5
+
+
 def test_slope_planar(hip):
     d = np.load(GOLD)
     tp = hip.topo_param.slope_plane_meth(d["pl_x"], d["pl_y"], d["pl_z"])
