@@ -60,6 +60,34 @@ struct __attribute__((aligned(16))) Prim {
 };
 static_assert(sizeof(Prim) == 48, "Prim must be 48 bytes");
 
+// XCD-aware block -> tile mapping (device + host).  Workgroup b runs on XCD b % 8 (observed
+// dispatch order; used for L2 affinity only).  The tile grid is cut into sr x sc = 8 compact
+// regions, one per XCD; inside a region tiles are walked in column groups of `gw` tiles so that
+// the workgroups resident at the same time on one XCD cover a compact patch of the DEM (their
+// rays share BVH nodes in that XCD's L2).
+struct TileMap {
+    int tiles_i, tiles_j;   // tile grid
+    int sr, sc;             // regions: sr rows x sc columns (sr * sc == 8)
+    int ri, rj;             // tiles per region (rows, columns; last regions may be cut)
+    int gw;                 // column-group width inside a region
+    int per_xcd;            // ri * rj: workgroups launched per XCD
+};
+
+#ifdef __HIPCC__
+__device__ __forceinline__ bool hz_tile_of_block(const TileMap &m, int b, int *ti, int *tj) {
+    const int x = b & 7, t = b >> 3;
+    const int i0 = (x / m.sc) * m.ri, j0 = (x % m.sc) * m.rj;
+    const int rows = min(m.ri, m.tiles_i - i0), cols = min(m.rj, m.tiles_j - j0);
+    if (rows <= 0 || cols <= 0 || t >= rows * cols) return false;
+    const int per_group = m.gw * rows;
+    const int g = t / per_group, r = t - g * per_group;
+    const int w = min(m.gw, cols - g * m.gw);          // width of this (possibly last, narrower) group
+    *ti = i0 + r / w;
+    *tj = j0 + g * m.gw + (r - (r / w) * w);
+    return true;
+}
+#endif
+
 #ifdef __HIPCC__
 
 // ---------------------------------------------------------------------------

@@ -38,7 +38,7 @@ struct HorizonParams {
     float *hori;
     int offset_0, offset_1, dim_in_1;
     int row_begin, row_end;
-    int tiles_j, n_tiles, chunk;   // tile grid of the slab; chunk = ceil(n_tiles / 8)
+    TileMap tm;                    // tile grid of the slab -> workgroups (XCD aware)
     float dist, hori_fill, ray_org_elev;
     int top_nodes, regroup, stack_bytes, leaf_bias, stage_bytes;
     unsigned long long *counters;
@@ -59,14 +59,12 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
         __syncthreads();
     }
 
-    // XCD-aware block -> tile mapping: block b runs on XCD b % 8; give XCD x the tile band [x*chunk, (x+1)*chunk)
-    const int b = blockIdx.x;
-    const int tile = (b & 7) * p.chunk + (b >> 3);
-    const int ti = tile / p.tiles_j, tj = tile - ti * p.tiles_j;
+    int ti = 0, tj = 0;
+    const bool has_tile = hz_tile_of_block(p.tm, blockIdx.x, &ti, &tj);
     const int wave = tid >> 6, lane = tid & 63;
     const int i = p.row_begin + ti * 16 + (wave >> 1) * 8 + (lane >> 3);
     const int j = tj * 16 + (wave & 1) * 8 + (lane & 7);
-    const bool in_dom = (tile < p.n_tiles) && (i < p.row_end) && (j < p.dim_in_1);
+    const bool in_dom = has_tile && (i < p.row_end) && (j < p.dim_in_1);
 
     const Tables &t = p.tb;
     const size_t cell = in_dom ? ((size_t)i * p.dim_in_1 + j) : 0;
@@ -190,9 +188,7 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
     const int rows = a.row_end - a.row_begin;
     if (rows <= 0 || a.dim_in_1 <= 0) return HZ_OK;
     const int tiles_i = (rows + 15) / 16;
-    p.tiles_j = (a.dim_in_1 + 15) / 16;
-    p.n_tiles = tiles_i * p.tiles_j;
-    p.chunk = (p.n_tiles + 7) / 8;
+    p.tm = make_tile_map(tiles_i, (a.dim_in_1 + 15) / 16, getenv("HZ_GW") ? atoi(getenv("HZ_GW")) : 8);
     p.dist = a.dist; p.hori_fill = a.hori_fill; p.ray_org_elev = a.ray_org_elev;
     // stack: at most 3 pending siblings per 4-wide level
     const int depth = 3 * std::max(sc->hdr.height, 1);
@@ -216,7 +212,7 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
     p.leaf_bias = (a.regroup >= 256) ? (a.regroup >> 8) : 24;
     p.counters = a.counters;
     const size_t lds = (size_t)p.stack_bytes + (size_t)p.stage_bytes + (size_t)top * sizeof(Node);
-    const int grid = p.chunk * 8;
+    const int grid = p.tm.per_xcd * 8;
     const bool count = a.count_work != 0;
     switch (a.alg) {
         case ALG_DISCRETE: return launch_alg<ALG_DISCRETE>(p, grid, lds, count, st);

@@ -1,6 +1,7 @@
 // hz_internal.h -- host-side internals of libhorayzon_hip (not part of the ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -62,6 +63,25 @@ inline SceneView scene_view(const Scene *sc) {
     v.d1 = sc->hdr.d1; v.n_top = sc->hdr.n_top;
     v.cx = sc->hdr.center[0]; v.cy = sc->hdr.center[1]; v.cz = sc->hdr.center[2];
     return v;
+}
+
+inline TileMap make_tile_map(int tiles_i, int tiles_j, int gw = 8) {
+    TileMap m;
+    m.tiles_i = tiles_i; m.tiles_j = tiles_j; m.gw = gw;
+    double best = 1e300;
+    m.sr = 8; m.sc = 1;
+    for (int sr = 1; sr <= 8; sr *= 2) {
+        const int sc = 8 / sr;
+        const int ri = (tiles_i + sr - 1) / sr, rj = (tiles_j + sc - 1) / sc;
+        // prefer square regions; penalise splits that leave XCDs without tiles
+        const int used = ((tiles_i + ri - 1) / ri) * ((tiles_j + rj - 1) / rj);
+        const double aspect = (double)std::max(ri, rj) / (double)std::max(1, std::min(ri, rj));
+        const double cost = aspect + 100.0 * (8 - used);
+        if (cost < best) { best = cost; m.sr = sr; m.sc = sc; }
+    }
+    m.ri = (tiles_i + m.sr - 1) / m.sr; m.rj = (tiles_j + m.sc - 1) / m.sc;
+    m.per_xcd = m.ri * m.rj;
+    return m;
 }
 
 // true if p points to device memory (HBM); false for host memory

@@ -16,7 +16,7 @@ struct ShadowParams {
     const float *vec_tilt, *vec_norm, *surf_enl_fac, *elevation;
     const uint8_t *mask;
     int offset_0, offset_1, dim_in_0, dim_in_1;
-    int tiles_j, n_tiles, chunk;
+    TileMap tm;
     float sun_x, sun_y, sun_z;
     float fill, dot_prod_min;
     int refrac, which;
@@ -76,13 +76,12 @@ __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
         for (int i = tid; i < ntop * 4; i += HZ_TPB) dst[i] = src[i];
         __syncthreads();
     }
-    const int b = blockIdx.x;
-    const int tile = (b & 7) * p.chunk + (b >> 3);
-    const int ti = tile / p.tiles_j, tj = tile - ti * p.tiles_j;
+    int ti = 0, tj = 0;
+    const bool has_tile = hz_tile_of_block(p.tm, blockIdx.x, &ti, &tj);
     const int wave = tid >> 6, lane = tid & 63;
     const int i = ti * 16 + (wave >> 1) * 8 + (lane >> 3);
     const int j = tj * 16 + (wave & 1) * 8 + (lane & 7);
-    const bool in_dom = (tile < p.n_tiles) && (i < p.dim_in_0) && (j < p.dim_in_1);
+    const bool in_dom = has_tile && (i < p.dim_in_0) && (j < p.dim_in_1);
     const size_t cell = in_dom ? ((size_t)i * p.dim_in_1 + j) : 0;
     unsigned rays = 0;
     if (in_dom) {
@@ -158,9 +157,7 @@ int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st) {
     p.offset_0 = a.offset_0; p.offset_1 = a.offset_1; p.dim_in_0 = a.dim_in_0; p.dim_in_1 = a.dim_in_1;
     if (a.dim_in_0 <= 0 || a.dim_in_1 <= 0) return HZ_OK;
     const int tiles_i = (a.dim_in_0 + 15) / 16;
-    p.tiles_j = (a.dim_in_1 + 15) / 16;
-    p.n_tiles = tiles_i * p.tiles_j;
-    p.chunk = (p.n_tiles + 7) / 8;
+    p.tm = make_tile_map(tiles_i, (a.dim_in_1 + 15) / 16);
     p.sun_x = a.sun[0]; p.sun_y = a.sun[1]; p.sun_z = a.sun[2];
     p.fill = a.sw_dir_cor_fill; p.dot_prod_min = a.dot_prod_min;
     p.refrac = a.refrac_cor; p.which = a.which;
@@ -177,7 +174,7 @@ int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st) {
     p.top_nodes = top;
     p.counters = a.counters;
     const size_t lds = (size_t)p.stack_bytes + (size_t)top * sizeof(Node);
-    const int grid = p.chunk * 8;
+    const int grid = p.tm.per_xcd * 8;
     HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shadow),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(HZ_TPB), lds, st, p);
