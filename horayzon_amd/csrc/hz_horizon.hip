@@ -233,6 +233,16 @@ template <int KIND>
 __global__ __launch_bounds__(256) void k_topo(const float *__restrict__ azim, const float *__restrict__ hori,
                                              const float *__restrict__ vec_tilt, size_t ncell, int A,
                                              float *__restrict__ out) {
+    // sin / cos of the azimuths once per workgroup (float32 of the float64 value, topo_param.pyx:425-426)
+    extern __shared__ float az_tab[];                 // [2 * A] when it fits, else unused
+    const bool tab = (KIND != 2) && (2 * (size_t)A * sizeof(float) <= 48 * 1024);
+    if (tab) {
+        for (int k = threadIdx.x; k < A; k += blockDim.x) {
+            az_tab[k] = (float)sin((double)azim[k]);
+            az_tab[A + k] = (float)cos((double)azim[k]);
+        }
+        __syncthreads();
+    }
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncell) return;
     float tx = 0.0f, ty = 0.0f, tz = 1.0f;
@@ -245,7 +255,8 @@ __global__ __launch_bounds__(256) void k_topo(const float *__restrict__ azim, co
             agg = (float)(((double)agg + (3.14159265358979323846 / 2.0)) - (double)hv);     // :599
             continue;
         }
-        const float as = (float)sin((double)azim[k]), ac = (float)cos((double)azim[k]);
+        const float as = tab ? az_tab[k] : (float)sin((double)azim[k]);
+        const float ac = tab ? az_tab[A + k] : (float)cos((double)azim[k]);
         const float hori_plane = (float)atan((double)(-as * tx / tz - ac * ty / tz));
         const float he = (hv >= hori_plane) ? hv : hori_plane;
         if (KIND == 0) {
@@ -267,9 +278,11 @@ int topo_launch(int kind, const float *azim, const float *hori, const float *vec
     const size_t ncell = (size_t)len_0 * len_1;
     if (ncell == 0) return HZ_OK;
     const dim3 grid((unsigned)((ncell + 255) / 256)), block(256);
-    if (kind == 0) hipLaunchKernelGGL(k_topo<0>, grid, block, 0, st, azim, hori, vec_tilt, ncell, len_2, out);
-    else if (kind == 1) hipLaunchKernelGGL(k_topo<1>, grid, block, 0, st, azim, hori, vec_tilt, ncell, len_2, out);
-    else hipLaunchKernelGGL(k_topo<2>, grid, block, 0, st, azim, hori, vec_tilt, ncell, len_2, out);
+    const size_t tab_bytes = 2 * (size_t)len_2 * sizeof(float);
+    const size_t lds = (kind != 2 && tab_bytes <= 48 * 1024) ? tab_bytes : 0;
+    if (kind == 0) hipLaunchKernelGGL(k_topo<0>, grid, block, lds, st, azim, hori, vec_tilt, ncell, len_2, out);
+    else if (kind == 1) hipLaunchKernelGGL(k_topo<1>, grid, block, lds, st, azim, hori, vec_tilt, ncell, len_2, out);
+    else hipLaunchKernelGGL(k_topo<2>, grid, block, lds, st, azim, hori, vec_tilt, ncell, len_2, out);
     HZ_HIP(hipGetLastError());
     return HZ_OK;
 }
