@@ -117,7 +117,9 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
     dim_in_0, dim_in_1 = vec_norm.shape[0], vec_norm.shape[1]
     # Allocate horizon array (horizon.pyx:170-173)
     hori_buffer = np.empty((dim_in_0, dim_in_1, azim_num), dtype=np.float32)
-    hori_buffer.fill(np.nan)
+    if rows is not None:
+        hori_buffer.fill(np.nan)   # only a slab is written; every cell is written otherwise
+                                   # (masked ones get hori_fill), so the 18 GB pre-fill is skipped
 
     opts = hz_opts()
     opts.device = device
