@@ -140,6 +140,66 @@ __device__ __forceinline__ bool hz_tri_hit(float ox, float oy, float oz,
     return true;
 }
 
+// The two triangles (a, b, c) and (b, d, c) of a DEM quad in one go.  Bitwise the same decisions as
+// two hz_tri_hit calls: the second triangle's first edge function runs over the shared diagonal
+// c - b = -(b - c), and every step of that edge function is an exact negation of the first
+// triangle's third one (IEEE rounding is sign symmetric), so U1 = -W0 is reused instead of
+// recomputed.  `second` = false for a TIN triangle (only a, b, c are tested).
+__device__ __forceinline__ bool hz_quad_hit(float ox, float oy, float oz, float dx, float dy, float dz, float tfar,
+                                            float ax, float ay, float az, float bx, float by, float bz,
+                                            float cx, float cy, float cz, float qx, float qy, float qz,
+                                            bool second) {
+    const float v0x = ax - ox, v0y = ay - oy, v0z = az - oz;      // a
+    const float v1x = bx - ox, v1y = by - oy, v1z = bz - oz;      // b
+    const float v2x = cx - ox, v2y = cy - oy, v2z = cz - oz;      // c
+    const float e0x = v2x - v0x, e0y = v2y - v0y, e0z = v2z - v0z;
+    const float e1x = v0x - v1x, e1y = v0y - v1y, e1z = v0z - v1z;
+    const float e2x = v1x - v2x, e2y = v1y - v2y, e2z = v1z - v2z;
+    const float s0x = v2x + v0x, s0y = v2y + v0y, s0z = v2z + v0z;
+    const float s1x = v0x + v1x, s1y = v0y + v1y, s1z = v0z + v1z;
+    const float s2x = v1x + v2x, s2y = v1y + v2y, s2z = v1z + v2z;
+    const float U = ((e0y * s0z - e0z * s0y) * dx + (e0z * s0x - e0x * s0z) * dy) + (e0x * s0y - e0y * s0x) * dz;
+    const float V = ((e1y * s1z - e1z * s1y) * dx + (e1z * s1x - e1x * s1z) * dy) + (e1x * s1y - e1y * s1x) * dz;
+    const float W = ((e2y * s2z - e2z * s2y) * dx + (e2z * s2x - e2x * s2z) * dy) + (e2x * s2y - e2y * s2x) * dz;
+    {
+        const float UVW = (U + V) + W;
+        const float eps = 1.1920928955078125e-7f * __builtin_fabsf(UVW);
+        const float mn = __builtin_fminf(U, __builtin_fminf(V, W));
+        const float mx = __builtin_fmaxf(U, __builtin_fmaxf(V, W));
+        if ((mn >= -eps) || (mx <= eps)) {
+            const float nx = e1y * e0z - e1z * e0y, ny = e1z * e0x - e1x * e0z, nz = e1x * e0y - e1y * e0x;
+            const float den = (nx * dx + ny * dy) + nz * dz;
+            const float T = (v0x * nx + v0y * ny) + v0z * nz;
+            const float Ts = (den < 0.0f) ? -T : T;
+            if (den != 0.0f && Ts >= 0.0f && Ts <= tfar * __builtin_fabsf(den)) return true;
+        }
+    }
+    if (!second) return false;
+    // triangle (b, d, c): v0' = b, v1' = d, v2' = c
+    const float w1x = qx - ox, w1y = qy - oy, w1z = qz - oz;      // d
+    const float f0x = -e2x, f0y = -e2y, f0z = -e2z;               // e0' = c - b
+    const float f1x = v1x - w1x, f1y = v1y - w1y, f1z = v1z - w1z;   // e1' = b - d
+    const float f2x = w1x - v2x, f2y = w1y - v2y, f2z = w1z - v2z;   // e2' = d - c
+    const float t1x = v1x + w1x, t1y = v1y + w1y, t1z = v1z + w1z;
+    const float t2x = w1x + v2x, t2y = w1y + v2y, t2z = w1z + v2z;
+    const float U1 = -W;
+    const float V1 = ((f1y * t1z - f1z * t1y) * dx + (f1z * t1x - f1x * t1z) * dy) + (f1x * t1y - f1y * t1x) * dz;
+    const float W1 = ((f2y * t2z - f2z * t2y) * dx + (f2z * t2x - f2x * t2z) * dy) + (f2x * t2y - f2y * t2x) * dz;
+    const float UVW = (U1 + V1) + W1;
+    const float eps = 1.1920928955078125e-7f * __builtin_fabsf(UVW);
+    const float mn = __builtin_fminf(U1, __builtin_fminf(V1, W1));
+    const float mx = __builtin_fmaxf(U1, __builtin_fmaxf(V1, W1));
+    if (!((mn >= -eps) || (mx <= eps))) return false;
+    const float nx = f1y * f0z - f1z * f0y, ny = f1z * f0x - f1x * f0z, nz = f1x * f0y - f1y * f0x;
+    const float den = (nx * dx + ny * dy) + nz * dz;
+    const float T = (v1x * nx + v1y * ny) + v1z * nz;
+    if (den == 0.0f) return false;
+    const float Ts = (den < 0.0f) ? -T : T;
+    if (!(Ts >= 0.0f)) return false;
+    if (!(Ts <= tfar * __builtin_fabsf(den))) return false;
+    return true;
+}
+
 // closest-hit variant (rtcIntersect1): same acceptance test; t = T / den as one IEEE division
 __device__ __forceinline__ bool hz_tri_hit_t(float ox, float oy, float oz, float dx, float dy, float dz,
                                              float tfar, float p0x, float p0y, float p0z, float p1x,
@@ -166,6 +226,8 @@ struct RayBox {
     float rdx, rdy, rdz;     // 1 / d (clamped away from inf)
     float ordx, ordy, ordz;  // (o - center) * rd
     int order;               // (dy < 0 ? 2 : 0) | (dx < 0 ? 1 : 0): slot visited r-th = r ^ order
+    uint32_t sel_xy, sel_z;  // v_perm selectors that put the NEAR bound first: (x_near, x_far, y_near, y_far)
+                             // and (z_near, z_far); near = lo when 1/d > 0, hi otherwise
 };
 
 __device__ __forceinline__ float hz_safe_rcp(float d) {
@@ -178,6 +240,9 @@ __device__ __forceinline__ RayBox hz_raybox(float ocx, float ocy, float ocz,
     r.rdx = hz_safe_rcp(dx); r.rdy = hz_safe_rcp(dy); r.rdz = hz_safe_rcp(dz);
     r.ordx = ocx * r.rdx; r.ordy = ocy * r.rdy; r.ordz = ocz * r.rdz;
     r.order = ((dy < 0.0f) ? 2 : 0) | ((dx < 0.0f) ? 1 : 0);
+    // selector bytes 0..3 pick bytes 0..3 of the second v_perm operand
+    r.sel_xy = ((r.rdy < 0.0f) ? 0x02030000u : 0x03020000u) | ((r.rdx < 0.0f) ? 0x00000001u : 0x00000100u);
+    r.sel_z = (r.rdz < 0.0f) ? 0x01000302u : 0x03020100u;
     return r;
 }
 
@@ -195,18 +260,20 @@ __device__ __forceinline__ NodeRay hz_node_ray(const RayBox &r, float ox, float 
     return n;
 }
 
-// does [0, tfar] overlap the quantised child box (qxy, qz)?
-__device__ __forceinline__ bool hz_qbox_hit(const NodeRay &n, float tfar, uint32_t qxy, uint32_t qz) {
-    const float xl = (float)(qxy & 0xffu), xh = (float)((qxy >> 8) & 0xffu);
-    const float yl = (float)((qxy >> 16) & 0xffu), yh = (float)(qxy >> 24);
-    const float zl = (float)(qz & 0xffffu), zh = (float)(qz >> 16);
-    const float t0x = __builtin_fmaf(xl, n.ax, n.bx), t1x = __builtin_fmaf(xh, n.ax, n.bx);
-    const float t0y = __builtin_fmaf(yl, n.ay, n.by), t1y = __builtin_fmaf(yh, n.ay, n.by);
-    const float t0z = __builtin_fmaf(zl, n.az, n.bz), t1z = __builtin_fmaf(zh, n.az, n.bz);
-    const float tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(t0x, t1x), __builtin_fminf(t0y, t1y)),
-                                       __builtin_fmaxf(__builtin_fminf(t0z, t1z), 0.0f));
-    const float tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(t0x, t1x), __builtin_fmaxf(t0y, t1y)),
-                                       __builtin_fminf(__builtin_fmaxf(t0z, t1z), tfar));
+// does [0, tfar] overlap the quantised child box (qxy, qz)?  The ray's direction signs say which
+// bound of each slab is entered first, so the bounds are byte-permuted once (v_perm_b32) instead
+// of being sorted with min / max per axis.
+__device__ __forceinline__ bool hz_qbox_hit(const NodeRay &n, const RayBox &r, float tfar, uint32_t qxy, uint32_t qz) {
+    const uint32_t pxy = __builtin_amdgcn_perm(0u, qxy, r.sel_xy);
+    const uint32_t pz = __builtin_amdgcn_perm(0u, qz, r.sel_z);
+    const float xn = (float)(pxy & 0xffu), xf = (float)((pxy >> 8) & 0xffu);
+    const float yn = (float)((pxy >> 16) & 0xffu), yf = (float)(pxy >> 24);
+    const float zn = (float)(pz & 0xffffu), zf = (float)(pz >> 16);
+    const float tnx = __builtin_fmaf(xn, n.ax, n.bx), tfx = __builtin_fmaf(xf, n.ax, n.bx);
+    const float tny = __builtin_fmaf(yn, n.ay, n.by), tfy = __builtin_fmaf(yf, n.ay, n.by);
+    const float tnz = __builtin_fmaf(zn, n.az, n.bz), tfz = __builtin_fmaf(zf, n.az, n.bz);
+    const float tmin = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));
+    const float tmax = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tfar));
     return tmin <= tmax * 1.000001f;
 }
 
@@ -305,10 +372,10 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
                 else hz_load_node(nodes + node, n0, n1, n2, n3);
                 if (COUNT) { cnt.nodes++; HZ_WAVE_TICK(cnt.w_nodes, lane); }
                 const NodeRay nr = hz_node_ray(rb, n0.x, n0.y, n0.z, __float_as_uint(n0.w));
-                const bool h0 = hz_qbox_hit(nr, tfar, n1.x, n2.x);
-                const bool h1 = hz_qbox_hit(nr, tfar, n1.y, n2.y);
-                const bool h2 = hz_qbox_hit(nr, tfar, n1.z, n2.z);
-                const bool h3 = hz_qbox_hit(nr, tfar, n1.w, n2.w);
+                const bool h0 = hz_qbox_hit(nr, rb, tfar, n1.x, n2.x);
+                const bool h1 = hz_qbox_hit(nr, rb, tfar, n1.y, n2.y);
+                const bool h2 = hz_qbox_hit(nr, rb, tfar, n1.z, n2.z);
+                const bool h3 = hz_qbox_hit(nr, rb, tfar, n1.w, n2.w);
                 // visit order: slot r ^ order for r = 0..3 (front to back in x / y):
                 // bit 0 of `order` swaps neighbours, bit 1 swaps the halves
                 const bool s1 = (rb.order & 1) != 0, s2 = (rb.order & 2) != 0;
@@ -331,9 +398,8 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
                 hz_load_prim(prims + (~lq0), q0, q1, q2);
                 // a = (q0.x q0.y q0.z) b = (q0.w q1.x q1.y) c = (q1.z q1.w q2.x) d = (q2.y q2.z q2.w)
                 if (COUNT) { cnt.tris += (q2.y == q2.y) ? 2 : 1; HZ_WAVE_TICK(cnt.w_leaves, lane); }
-                bool hit = hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x);
-                if (!hit && (q2.y == q2.y))
-                    hit = hz_tri_hit(ox, oy, oz, dx, dy, dz, tfar, q0.w, q1.x, q1.y, q2.y, q2.z, q2.w, q1.z, q1.w, q2.x);
+                const bool hit = hz_quad_hit(ox, oy, oz, dx, dy, dz, tfar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
+                                             q2.x, q2.y, q2.z, q2.w, q2.y == q2.y);
                 if (hit) { HZ_SAVE(); return 1; }
                 lq0 = lq1; lq1 = lq2; lq2 = lq3; lq3 = HZ_EMPTY;
             }
@@ -362,8 +428,8 @@ __device__ __forceinline__ bool hz_closest(const Node *__restrict__ nodes, const
             hz_load_node(nodes + node, n0, n1, n2, n3);
             const float tf = any ? __builtin_fminf(tfar, best * 1.0001f) : tfar;
             const NodeRay nr = hz_node_ray(rb, n0.x, n0.y, n0.z, __float_as_uint(n0.w));
-            const bool h0 = hz_qbox_hit(nr, tf, n1.x, n2.x), h1 = hz_qbox_hit(nr, tf, n1.y, n2.y);
-            const bool h2 = hz_qbox_hit(nr, tf, n1.z, n2.z), h3 = hz_qbox_hit(nr, tf, n1.w, n2.w);
+            const bool h0 = hz_qbox_hit(nr, rb, tf, n1.x, n2.x), h1 = hz_qbox_hit(nr, rb, tf, n1.y, n2.y);
+            const bool h2 = hz_qbox_hit(nr, rb, tf, n1.z, n2.z), h3 = hz_qbox_hit(nr, rb, tf, n1.w, n2.w);
             int next = HZ_EMPTY;
             if (h3) next = n3.w;
             if (h2) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = n3.z; }
