@@ -231,7 +231,8 @@ struct RayBox {
 };
 
 __device__ __forceinline__ float hz_safe_rcp(float d) {
-    return (__builtin_fabsf(d) > 1e-30f) ? 1.0f / d : __builtin_copysignf(1e30f, d);
+    // v_rcp_f32 (1 ulp) is enough: these constants only feed the conservative box test
+    return (__builtin_fabsf(d) > 1e-30f) ? __builtin_amdgcn_rcpf(d) : __builtin_copysignf(1e30f, d);
 }
 
 __device__ __forceinline__ RayBox hz_raybox(float ocx, float ocy, float ocz,
