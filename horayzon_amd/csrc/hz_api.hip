@@ -86,6 +86,7 @@ static inline float deg2rad_f(float ang) { return (float)(((double)ang / 180.0) 
 
 struct HostTables {
     std::vector<float> azim_sin, azim_cos, elev_ang, elev_sin, elev_cos;
+    std::vector<int> mid_idx;   // index nearest to the midpoint of entries i and i + 10 (horizon_comp.cpp:462-464)
     int elev_num = 0;
     float hori_acc = 0, low = 0, up = 0;
 };
@@ -112,6 +113,12 @@ static void build_tables(int azim_num, float hori_acc_deg, float low_deg, HostTa
         t.elev_ang[(size_t)(t.elev_num - i - 1)] = ang;
         t.elev_sin[(size_t)(t.elev_num - i - 1)] = sinf(ang);
         t.elev_cos[(size_t)(t.elev_num - i - 1)] = cosf(ang);
+    }
+    // elev_samp = (elev_ang[prev] + elev_ang[ind]) / 2.0; ind = (int)roundf((elev_samp - low) / (hori_acc / 5.0))
+    t.mid_idx.assign(n > 0 ? n : 1, 0);
+    for (int i = 0; i + 10 < t.elev_num; i++) {
+        const float es = (float)((double)(t.elev_ang[(size_t)i] + t.elev_ang[(size_t)i + 10]) / 2.0);
+        t.mid_idx[(size_t)i] = (int)roundf((float)((double)(es - t.low) / step));
     }
 }
 
@@ -220,6 +227,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     const size_t slab_cells = (size_t)(row_end - row_begin) * dim_in_1;
     Timer t_h2d; t_h2d.start();
     DevIn<float> d_norm, d_north, d_tilt, d_as, d_ac, d_ea, d_es, d_ec;
+    DevIn<int> d_mid;
     DevIn<uint8_t> d_mask;
     if ((rc = d_norm.bind(vec_norm, ncell * 3, st))) return rc;
     if ((rc = d_north.bind(vec_north, ncell * 3, st))) return rc;
@@ -230,6 +238,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     if ((rc = d_ea.bind(tb.elev_ang.data(), (size_t)tb.elev_num, st))) return rc;
     if ((rc = d_es.bind(tb.elev_sin.data(), (size_t)tb.elev_num, st))) return rc;
     if ((rc = d_ec.bind(tb.elev_cos.data(), (size_t)tb.elev_num, st))) return rc;
+    if ((rc = d_mid.bind(tb.mid_idx.data(), tb.mid_idx.size(), st))) return rc;
     DevOut<float> d_hori, d_svf;
     DevIn<float> d_azim;
     const bool want_svf = opts && opts->svf;
@@ -272,6 +281,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     a.hori_acc = tb.hori_acc; a.low = tb.low; a.up = tb.up; a.dist = dist_m;
     a.hori_fill = hori_fill; a.ray_org_elev = ray_org_elev;
     a.azim_sin = d_as.dev; a.azim_cos = d_ac.dev; a.elev_ang = d_ea.dev; a.elev_sin = d_es.dev; a.elev_cos = d_ec.dev;
+    a.mid_idx = d_mid.dev;
     a.top_nodes = opts ? opts->top_nodes : -1;
     a.regroup = opts ? opts->regroup : -1;
     a.count_work = opts ? opts->count_work : 0;
@@ -365,6 +375,7 @@ static int locations_run(const Scene *sc, const float *coords, const float *vec_
     if (tb.elev_num < 2) return set_error(HZ_ERR_ARG, "elevation table is empty (elev_ang_low_lim too high)");
     Timer t_h2d; t_h2d.start();
     DevIn<float> d_co, d_norm, d_north, d_roe, d_as, d_ac, d_ea, d_es, d_ec;
+    DevIn<int> d_mid;
     const size_t n = (size_t)num_loc;
     if ((rc = d_co.bind(coords, n * 3, st))) return rc;
     if ((rc = d_norm.bind(vec_norm, n * 3, st))) return rc;
@@ -375,6 +386,7 @@ static int locations_run(const Scene *sc, const float *coords, const float *vec_
     if ((rc = d_ea.bind(tb.elev_ang.data(), (size_t)tb.elev_num, st))) return rc;
     if ((rc = d_es.bind(tb.elev_sin.data(), (size_t)tb.elev_num, st))) return rc;
     if ((rc = d_ec.bind(tb.elev_cos.data(), (size_t)tb.elev_num, st))) return rc;
+    if ((rc = d_mid.bind(tb.mid_idx.data(), tb.mid_idx.size(), st))) return rc;
     // outputs are read-modify-write (untouched rows keep the caller's NaN): copy them in first
     DevOut<float> d_hori, d_dist;
     if ((rc = d_hori.bind(hori_buffer, n * (size_t)azim_num))) return rc;
@@ -398,6 +410,7 @@ static int locations_run(const Scene *sc, const float *coords, const float *vec_
     a.num_loc = num_loc; a.azim_num = azim_num; a.elev_num = tb.elev_num; a.alg = alg; a.hori_dist_out = hori_dist_out;
     a.hori_acc = tb.hori_acc; a.low = tb.low; a.up = tb.up; a.dist_m = (float)((double)dist_search * 1000.0);
     a.azim_sin = d_as.dev; a.azim_cos = d_ac.dev; a.elev_ang = d_ea.dev; a.elev_sin = d_es.dev; a.elev_cos = d_ec.dev;
+    a.mid_idx = d_mid.dev;
     a.counters = (unsigned long long *)cnt_dev;
     hipEvent_t e0, e1;
     HZ_HIP(hipEventCreate(&e0)); HZ_HIP(hipEventCreate(&e1));

@@ -177,7 +177,7 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
     HorizonParams p;
     p.sv = scene_view(sc);
     p.tb.azim_sin = a.azim_sin; p.tb.azim_cos = a.azim_cos;
-    p.tb.elev_ang = a.elev_ang; p.tb.elev_sin = a.elev_sin; p.tb.elev_cos = a.elev_cos;
+    p.tb.elev_ang = a.elev_ang; p.tb.elev_sin = a.elev_sin; p.tb.elev_cos = a.elev_cos; p.tb.mid_idx = a.mid_idx;
     p.tb.azim_num = a.azim_num; p.tb.elev_num = a.elev_num;
     p.tb.hori_acc = a.hori_acc; p.tb.low = a.low; p.tb.up = a.up;
     p.tb.step = (double)a.hori_acc / 5.0;

@@ -98,6 +98,7 @@ struct HorizonArgs {
     float hori_acc, low, up, dist;       // radians / metres
     float hori_fill, ray_org_elev;
     const float *azim_sin, *azim_cos, *elev_ang, *elev_sin, *elev_cos;  // device tables
+    const int *mid_idx;
     int top_nodes, regroup, count_work;
     unsigned long long *counters;        // device u64[8]: [0] rays, [1] guards, [2] nodes, [3] tris, [4] cells
 };
@@ -114,6 +115,7 @@ struct LocationsArgs {
     int num_loc, azim_num, elev_num, alg, hori_dist_out;
     float hori_acc, low, up, dist_m;
     const float *azim_sin, *azim_cos, *elev_ang, *elev_sin, *elev_cos;
+    const int *mid_idx;
     unsigned long long *counters;
 };
 int locations_launch(const Scene *sc, const LocationsArgs &a, hipStream_t st);

@@ -13,6 +13,7 @@ enum { PH_NEWAZ = 0, PH_BIN = 1, PH_UP = 2, PH_DOWN = 3, PH_EMIT = 4 };
 
 struct Tables {
     const float *azim_sin, *azim_cos, *elev_ang, *elev_sin, *elev_cos;
+    const int *mid_idx;   // mid_idx[i] = ind_of(half_sum(elev_ang[i], elev_ang[i + 10])), built on the host
     int azim_num, elev_num;
     float hori_acc, low, up;
     double step;   // (double)hori_acc / 5.0
@@ -31,6 +32,15 @@ __device__ __forceinline__ int ind_of(const Tables &t, float elev_samp) {
 // (a + b) / 2.0 -> float, horizon_comp.cpp:350, :330, :462, :490
 __device__ __forceinline__ float half_sum(float a, float b) {
     return (float)((double)(a + b) / 2.0);
+}
+
+// index of the table entry nearest to the midpoint of entries `a` and `b` (horizon_comp.cpp:462-464,
+// :490-492).  The search steps by 10 entries, so the midpoint index comes from a host-built table
+// (same float/double expressions, hz_api.hip); clamped steps at the table ends take the general path.
+__device__ __forceinline__ int mid_index(const Tables &t, int a, int b) {
+    const int lo = min(a, b);
+    if (max(a, b) - lo == 10) return t.mid_idx[lo];
+    return ind_of(t, half_sum(t.elev_ang[a], t.elev_ang[b]));
 }
 
 // per-cell output sink
@@ -117,8 +127,7 @@ __device__ __forceinline__ bool advance(Search &s, bool hit, const Tables &t, Si
                 continue;
             }
             if (s.count > 1) {                               // :460-467
-                const float es = half_sum(t.elev_ang[s.prev], t.elev_ang[s.ind]);
-                s.ind = ind_of(t, es);
+                s.ind = mid_index(t, s.prev, s.ind);
                 s.ev = t.elev_ang[s.ind]; s.pazim = s.ind; s.phase = PH_EMIT;
                 continue;
             }
@@ -138,8 +147,7 @@ __device__ __forceinline__ bool advance(Search &s, bool hit, const Tables &t, Si
                 return true;
             }
             if (guard) guards++;
-            const float es = half_sum(t.elev_ang[s.prev], t.elev_ang[s.ind]);   // :490-494
-            s.ind = ind_of(t, es);
+            s.ind = mid_index(t, s.prev, s.ind);                              // :490-494
             s.ev = t.elev_ang[s.ind]; s.pazim = s.ind; s.phase = PH_EMIT;
             continue;
         }
