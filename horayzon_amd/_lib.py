@@ -52,6 +52,7 @@ SYMBOLS = (
     "hz_sky_view_factor", "hz_visible_sky_fraction", "hz_topographic_openness",
     "hz_slope_plane_meth", "hz_slope_vector_meth", "hz_lonlat2ecef", "hz_ecef2enu",
     "hz_ecef2enu_vector", "hz_surf_norm", "hz_north_dir",
+    "hz_debug_sort_pairs", "hz_debug_exclusive_scan",
     "hz_terrain_create", "hz_terrain_initialise", "hz_terrain_initialise_scene",
     "hz_terrain_shadow", "hz_terrain_sw_dir_cor", "hz_terrain_shadow_batch",
     "hz_terrain_sw_dir_cor_batch", "hz_terrain_destroy",
@@ -126,6 +127,8 @@ def lib():
     L.hz_ecef2enu_vector.argtypes = [vp, C.c_size_t, C.c_double, C.c_double, ip, vp, ip]
     L.hz_surf_norm.argtypes = [vp, vp, C.c_size_t, vp, ip]
     L.hz_north_dir.argtypes = [vp, vp, vp, vp, C.c_size_t, ip, vp, ip]
+    L.hz_debug_sort_pairs.argtypes = [vp, vp, C.c_size_t, ip]
+    L.hz_debug_exclusive_scan.argtypes = [vp, vp, C.c_size_t, ip]
     L.hz_terrain_create.argtypes = [ip, C.POINTER(vp)]
     L.hz_terrain_initialise.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, ip, ip, vp, vp, vp,
                                         C.c_char_p, C.c_float, C.c_float, ip, C.POINTER(hz_stats)]

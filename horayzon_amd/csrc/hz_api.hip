@@ -640,6 +640,48 @@ int hz_topographic_openness(const float *azim, const float *hori, int len_0, int
 }
 
 // ---------------------------------------------------------------------------------------
+// test hooks for the build primitives (hz_sort.hip)
+// ---------------------------------------------------------------------------------------
+int hz_debug_sort_pairs(uint32_t *keys, uint32_t *vals, size_t n, int device) {
+    if (!keys || !vals) return set_error(HZ_ERR_ARG, "NULL argument");
+    int rc = select_device(device);
+    if (rc) return rc;
+    hipStream_t st = nullptr;
+    void *dk = nullptr, *dv = nullptr, *dk2 = nullptr, *dv2 = nullptr, *tmp = nullptr;
+    const size_t bytes = (n ? n : 1) * 4;
+    HZ_HIP(hipMalloc(&dk, bytes)); HZ_HIP(hipMalloc(&dv, bytes)); HZ_HIP(hipMalloc(&dk2, bytes)); HZ_HIP(hipMalloc(&dv2, bytes));
+    HZ_HIP(hipMalloc(&tmp, sort_temp_elems(n) * 4 + 16));
+    HZ_HIP(hipMemcpy(dk, keys, n * 4, hipMemcpyHostToDevice));
+    HZ_HIP(hipMemcpy(dv, vals, n * 4, hipMemcpyHostToDevice));
+    rc = radix_sort_pairs_u32((uint32_t *)dk, (uint32_t *)dv, (uint32_t *)dk2, (uint32_t *)dv2, n, (uint32_t *)tmp, st);
+    if (!rc) {
+        HZ_HIP(hipStreamSynchronize(st));
+        HZ_HIP(hipMemcpy(keys, dk, n * 4, hipMemcpyDeviceToHost));
+        HZ_HIP(hipMemcpy(vals, dv, n * 4, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(dk); (void)hipFree(dv); (void)hipFree(dk2); (void)hipFree(dv2); (void)hipFree(tmp);
+    return rc;
+}
+
+int hz_debug_exclusive_scan(const uint32_t *in, uint32_t *out, size_t n, int device) {
+    if (!in || !out) return set_error(HZ_ERR_ARG, "NULL argument");
+    int rc = select_device(device);
+    if (rc) return rc;
+    hipStream_t st = nullptr;
+    void *di = nullptr, *dout = nullptr, *tmp = nullptr;
+    const size_t bytes = (n ? n : 1) * 4;
+    HZ_HIP(hipMalloc(&di, bytes)); HZ_HIP(hipMalloc(&dout, bytes)); HZ_HIP(hipMalloc(&tmp, scan_temp_elems(n) * 4 + 16));
+    HZ_HIP(hipMemcpy(di, in, n * 4, hipMemcpyHostToDevice));
+    rc = exclusive_scan_u32((const uint32_t *)di, (uint32_t *)dout, n, (uint32_t *)tmp, st);
+    if (!rc) {
+        HZ_HIP(hipStreamSynchronize(st));
+        HZ_HIP(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(di); (void)hipFree(dout); (void)hipFree(tmp);
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------
 // slope and input preparation (hz_prep.hip)
 // ---------------------------------------------------------------------------------------
 static int slope_api(int which, const float *x, const float *y, const float *z, int len_0, int len_1,

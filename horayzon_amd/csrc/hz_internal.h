@@ -135,6 +135,13 @@ struct ShadowArgs {
 };
 int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st);
 
+// hz_sort.hip: hand-written stable LSD radix sort (pairs) and exclusive scan, uint32
+size_t sort_temp_elems(size_t n);
+size_t scan_temp_elems(size_t n);
+int radix_sort_pairs_u32(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, size_t n,
+                         uint32_t *temp, hipStream_t st);
+int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *temp, hipStream_t st);
+
 // hz_prep.hip (device pointers)
 int prep_slope(int which, const float *x, const float *y, const float *z, int len_0, int len_1,
                const float *rot_mat, int output_rot, float *vec_tilt, hipStream_t st);

@@ -7,9 +7,9 @@
 //   1. k_bounds      min/max of all vertices            (HBM streaming, 12 B/vertex)
 //   2. k_morton      one key per primitive: 2 x 16 bit Morton code of the
 //                    centroid (x, y); primitive = DEM quad (2 triangles) or TIN triangle
-//   3. rocprim radix sort of (key, primitive id)
+//   3. radix sort of (key, primitive id): hz_sort.hip (stable LSD, 8 bit digits, hand written)
 //   4. k_karras      binary radix tree over the sorted keys (Karras 2012)
-//   5. k_leaf_boxes / k_refit_pass  leaf AABBs; bottom-up union in level-synchronous passes
+//   5. k_leaf_boxes / k_refit_pass  leaf AABBs; bottom-up union, level synchronous with work lists
 //   6. k_roots/scan  collapse along the 2-bit Morton digits: a binary node starts a 4-wide
 //                    node when its common-prefix length enters a new digit (quadtree level)
 //   7. k_emit4       64 B nodes with conservatively quantised child AABBs (8 bit x/y, 16 bit z)
@@ -18,7 +18,6 @@
 #include <cstring>
 #include <cstdlib>
 #include "hz_internal.h"
-#include <rocprim/rocprim.hpp>
 #include <cfloat>
 #include <cmath>
 #include <cstring>
@@ -164,8 +163,24 @@ __global__ __launch_bounds__(256) void k_karras(const uint32_t *__restrict__ key
 
 // --- leaf boxes + bottom-up refit ---------------------------------------------
 // box arrays: lo/hi as float4 (w of lo = 4-wide levels below the node's digit group, as int bits)
+//
+// Refit is level synchronous with work lists: a finished child bumps its parent's arrival counter
+// (relaxed device atomic); the second arrival appends the parent to the NEXT launch's work list.
+// Boxes are only read in a launch after the one that wrote them, so kernel boundaries give the
+// ordering -- no fences on the data path.  (An in-kernel atomic-counter refit spent 97 % of the
+// build in L2 write-backs on the 8-XCD part; dense per-level passes over all nodes cost
+// O(nodes x height).)  Total work O(nodes), `height` launches.
+__device__ __forceinline__ void refit_notify(int parent, int *__restrict__ arrivals, int *__restrict__ next_list,
+                                             unsigned int *__restrict__ next_count) {
+    if (parent < 0) return;
+    if (atomicAdd(&arrivals[parent], 1) == 1) next_list[atomicAdd(next_count, 1u)] = parent;
+}
+
 __global__ __launch_bounds__(256) void k_leaf_boxes(BuildParams b, const uint32_t *__restrict__ vals,
-                                                   float4 *__restrict__ leaf_lo, float4 *__restrict__ leaf_hi) {
+                                                   const int *__restrict__ parent_leaf,
+                                                   float4 *__restrict__ leaf_lo, float4 *__restrict__ leaf_hi,
+                                                   int *__restrict__ arrivals, int *__restrict__ next_list,
+                                                   unsigned int *__restrict__ next_count) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= b.n_prims) return;
     float a[3], bb[3], c[3], d[3];
@@ -179,42 +194,32 @@ __global__ __launch_bounds__(256) void k_leaf_boxes(BuildParams b, const uint32_
     }
     leaf_lo[s] = make_float4(lo[0], lo[1], lo[2], 0.0f);
     leaf_hi[s] = make_float4(hi[0], hi[1], hi[2], 0.0f);
+    if (b.n_prims > 1) refit_notify(parent_leaf[s], arrivals, next_list, next_count);
 }
 
-// One refit pass: a node whose children were finished in EARLIER passes (done[child] < pass) takes
-// the union of their boxes.  Kernel boundaries give the ordering, so no fences or atomics on the
-// data path (an in-kernel atomic-counter refit spent 97 % of the build in cache write-backs on the
-// 8-XCD part).  The host repeats the pass until every node is done (= binary tree height passes;
-// late passes only stream one byte per node).
-__global__ __launch_bounds__(256) void k_refit_pass(int n_nodes, int pass, const int2 *__restrict__ child,
+__global__ __launch_bounds__(256) void k_refit_pass(const int *__restrict__ list, unsigned int n_list,
+                                                   const int2 *__restrict__ child,
+                                                   const int *__restrict__ parent_int,
                                                    const uint8_t *__restrict__ plen,
                                                    const float4 *__restrict__ leaf_lo,
                                                    const float4 *__restrict__ leaf_hi, float4 *node_lo,
-                                                   float4 *node_hi, uint8_t *done, unsigned int *n_done) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool fin = false;
-    if (i < n_nodes && done[i] == 0) {
-        const int2 ch = child[i];
-        const bool r0 = (ch.x < 0) || (done[ch.x] != 0 && done[ch.x] < pass);
-        const bool r1 = (ch.y < 0) || (done[ch.y] != 0 && done[ch.y] < pass);
-        if (r0 && r1) {
-            const float4 l0 = (ch.x >= 0) ? node_lo[ch.x] : leaf_lo[~ch.x];
-            const float4 h0 = (ch.x >= 0) ? node_hi[ch.x] : leaf_hi[~ch.x];
-            const float4 l1 = (ch.y >= 0) ? node_lo[ch.y] : leaf_lo[~ch.y];
-            const float4 h1 = (ch.y >= 0) ? node_hi[ch.y] : leaf_hi[~ch.y];
-            // 4-wide levels strictly below this node's digit group (see k_roots)
-            const int dg = plen[i] >> 1;
-            const int hgt0 = (ch.x >= 0) ? __float_as_int(l0.w) + (((plen[ch.x] >> 1) != dg) ? 1 : 0) : 0;
-            const int hgt1 = (ch.y >= 0) ? __float_as_int(l1.w) + (((plen[ch.y] >> 1) != dg) ? 1 : 0) : 0;
-            node_lo[i] = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z),
-                                     __int_as_float(max(hgt0, hgt1)));
-            node_hi[i] = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 0.0f);
-            done[i] = (uint8_t)pass;
-            fin = true;
-        }
-    }
-    const unsigned long long m = __ballot(fin);
-    if (m != 0ull && (threadIdx.x & 63) == (unsigned)(__ffsll((long long)m) - 1)) atomicAdd(n_done, (unsigned)__popcll(m));
+                                                   float4 *node_hi, int *__restrict__ arrivals,
+                                                   int *__restrict__ next_list, unsigned int *__restrict__ next_count) {
+    const unsigned int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= n_list) return;
+    const int i = list[q];
+    const int2 ch = child[i];
+    const float4 l0 = (ch.x >= 0) ? node_lo[ch.x] : leaf_lo[~ch.x];
+    const float4 h0 = (ch.x >= 0) ? node_hi[ch.x] : leaf_hi[~ch.x];
+    const float4 l1 = (ch.y >= 0) ? node_lo[ch.y] : leaf_lo[~ch.y];
+    const float4 h1 = (ch.y >= 0) ? node_hi[ch.y] : leaf_hi[~ch.y];
+    // 4-wide levels strictly below this node's digit group (see k_roots)
+    const int dg = plen[i] >> 1;
+    const int hgt0 = (ch.x >= 0) ? __float_as_int(l0.w) + (((plen[ch.x] >> 1) != dg) ? 1 : 0) : 0;
+    const int hgt1 = (ch.y >= 0) ? __float_as_int(l1.w) + (((plen[ch.y] >> 1) != dg) ? 1 : 0) : 0;
+    node_lo[i] = make_float4(fminf(l0.x, l1.x), fminf(l0.y, l1.y), fminf(l0.z, l1.z), __int_as_float(max(hgt0, hgt1)));
+    node_hi[i] = make_float4(fmaxf(h0.x, h1.x), fmaxf(h0.y, h1.y), fmaxf(h0.z, h1.z), 0.0f);
+    refit_notify(parent_int[i], arrivals, next_list, next_count);
 }
 
 // --- collapse to 4-wide nodes --------------------------------------------------------
@@ -397,10 +402,34 @@ __global__ void k_single_node(const float4 *leaf_lo, const float4 *leaf_hi, Node
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Build temporaries come out of (at most) two device arenas: ~25 separate multi-GB hipMalloc /
+// hipFree pairs made the build time of large scenes erratic (0.1 ... 1.9 s for the same input).
+struct Arena {
+    char *base = nullptr;
+    size_t cap = 0, off = 0;
+    ~Arena() { if (base) (void)hipFree(base); }
+    hipError_t reserve(size_t bytes) { cap = bytes; off = 0; return hipMalloc((void **)&base, bytes ? bytes : 256); }
+    static size_t pad(size_t n) { return (n + 255) & ~(size_t)255; }
+};
+static thread_local Arena *g_arena = nullptr;
+
 struct TempBuf {
     void *p = nullptr;
-    ~TempBuf() { if (p) (void)hipFree(p); }
-    hipError_t alloc(size_t n) { return hipMalloc(&p, n ? n : 16); }
+    bool owned = false;
+    ~TempBuf() { if (p && owned) (void)hipFree(p); }
+    hipError_t alloc(size_t n) {
+        n = n ? n : 16;
+        if (g_arena && g_arena->off + Arena::pad(n) <= g_arena->cap) {
+            p = g_arena->base + g_arena->off; g_arena->off += Arena::pad(n); owned = false;
+            return hipSuccess;
+        }
+        owned = true;
+        return hipMalloc(&p, n);
+    }
+};
+struct ArenaScope {   // the arena serves TempBuf::alloc while in scope
+    explicit ArenaScope(Arena *a) { g_arena = a; }
+    ~ArenaScope() { g_arena = nullptr; }
 };
 
 int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
@@ -416,6 +445,21 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     const int n_prims = n_quads + n_tin;
     const int n_bin = (n_prims > 1) ? n_prims - 1 : 1;      // binary radix tree nodes
     hipStream_t st = sc->stream;
+
+    // ---- one arena for all temporaries whose size is known up front ------------------------
+    Arena arena1, arena2;
+    {
+        const size_t P = (size_t)n_prims, B = (size_t)n_bin;
+        const size_t list_cap0 = B / 2 + 2;
+        const size_t sizes[] = {is_device_ptr(vert_grid) ? 0 : nvert * 12, has_tin ? (size_t)nvs * 12 : 0,
+                                has_tin ? (size_t)nts * 12 : 0, 24, P * 4, P * 4, P * 4, P * 4,
+                                sort_temp_elems(P) * 4, B * 8, B * 4, P * 4, B, B * 4, P * 16, P * 16, B * 16, B * 16,
+                                (B + 2 * list_cap0 + 4) * 4, B * 4, B * 4, scan_temp_elems(B) * 4};
+        size_t total = 0;
+        for (size_t x : sizes) total += Arena::pad(x ? x : 16);
+        HZ_HIP(arena1.reserve(total + 4096));
+    }
+    ArenaScope scope1(&arena1);
 
     // ---- vertices on the device (host or device source) -------------------------------
     Timer t_h2d; t_h2d.start();
@@ -488,14 +532,14 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     const int gp = (n_prims + 255) / 256;
     const int gn = (n_bin + 255) / 256;
     hipLaunchKernelGGL(k_morton, dim3(gp), dim3(256), 0, st, bp, (uint32_t *)b_k0.p, (uint32_t *)b_v0.p);
-    size_t sort_bytes = 0;
-    HZ_HIP(rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint32_t *)b_k0.p, (uint32_t *)b_k1.p,
-                                     (uint32_t *)b_v0.p, (uint32_t *)b_v1.p, (size_t)n_prims, 0, 32, st));
-    HZ_HIP(b_sort.alloc(sort_bytes));
-    HZ_HIP(rocprim::radix_sort_pairs(b_sort.p, sort_bytes, (uint32_t *)b_k0.p, (uint32_t *)b_k1.p,
-                                     (uint32_t *)b_v0.p, (uint32_t *)b_v1.p, (size_t)n_prims, 0, 32, st));
-    const uint32_t *keys = (const uint32_t *)b_k1.p;
-    const uint32_t *vals = (const uint32_t *)b_v1.p;
+    HZ_HIP(b_sort.alloc(sort_temp_elems((size_t)n_prims) * 4));
+    {   // sorted pairs come back in (k0, v0); (k1, v1) are scratch
+        const int rc = radix_sort_pairs_u32((uint32_t *)b_k0.p, (uint32_t *)b_v0.p, (uint32_t *)b_k1.p,
+                                            (uint32_t *)b_v1.p, (size_t)n_prims, (uint32_t *)b_sort.p, st);
+        if (rc) return rc;
+    }
+    const uint32_t *keys = (const uint32_t *)b_k0.p;
+    const uint32_t *vals = (const uint32_t *)b_v0.p;
 
     // ---- 4./5. binary hierarchy + refit -------------------------------------------------
     TempBuf b_child, b_pint, b_pleaf, b_plen, b_first, b_llo, b_lhi, b_nlo, b_nhi, b_cnt;
@@ -506,31 +550,40 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     HZ_HIP(b_first.alloc((size_t)n_bin * 4));
     HZ_HIP(b_llo.alloc((size_t)n_prims * 16)); HZ_HIP(b_lhi.alloc((size_t)n_prims * 16));
     HZ_HIP(b_nlo.alloc((size_t)n_bin * 16)); HZ_HIP(b_nhi.alloc((size_t)n_bin * 16));
-    HZ_HIP(b_cnt.alloc((size_t)n_bin + 16));                       // done[] (pass index per node) + counter
-    HZ_HIP(hipMemsetAsync(b_cnt.p, 0, (size_t)n_bin + 16, st));
+    // arrivals[n_bin] | two work lists [n_bin/2 + 1 each, a node enters a list once] | 2 list counters
+    const size_t list_cap = (size_t)n_bin / 2 + 2;
+    HZ_HIP(b_cnt.alloc(((size_t)n_bin + 2 * list_cap + 4) * 4));
+    int *arrivals = (int *)b_cnt.p;
+    int *lists[2] = {arrivals + n_bin, arrivals + n_bin + list_cap};
+    unsigned int *counts = (unsigned int *)(arrivals + n_bin + 2 * list_cap);
+    HZ_HIP(hipMemsetAsync(arrivals, 0, (size_t)n_bin * 4, st));
+    HZ_HIP(hipMemsetAsync(counts, 0, 16, st));
     HZ_HIP(hipMemsetAsync(b_nlo.p, 0, (size_t)n_bin * 16, st));
     if (n_prims > 1)
         hipLaunchKernelGGL(k_karras, dim3((n_prims - 1 + 255) / 256), dim3(256), 0, st, keys, n_prims,
                            (int2 *)b_child.p, (int *)b_pint.p, (int *)b_pleaf.p, (uint8_t *)b_plen.p,
                            (int *)b_first.p);
-    hipLaunchKernelGGL(k_leaf_boxes, dim3(gp), dim3(256), 0, st, bp, vals, (float4 *)b_llo.p, (float4 *)b_lhi.p);
+    hipLaunchKernelGGL(k_leaf_boxes, dim3(gp), dim3(256), 0, st, bp, vals, (const int *)b_pleaf.p,
+                       (float4 *)b_llo.p, (float4 *)b_lhi.p, arrivals, lists[0], &counts[0]);
     if (n_prims > 1) {
-        uint8_t *done = (uint8_t *)b_cnt.p;
-        unsigned int *n_done = (unsigned int *)((char *)b_cnt.p + (((size_t)n_bin + 3) & ~(size_t)3));
-        unsigned int finished = 0;
-        for (int pass = 1; pass < 250 && finished < (unsigned)n_bin; pass++) {
-            hipLaunchKernelGGL(k_refit_pass, dim3(gn), dim3(256), 0, st, n_bin, pass, (const int2 *)b_child.p,
-                               (const uint8_t *)b_plen.p, (const float4 *)b_llo.p, (const float4 *)b_lhi.p,
-                               (float4 *)b_nlo.p, (float4 *)b_nhi.p, done, n_done);
-            if (pass >= 8 && (pass & 3) == 0) {                       // poll the progress counter every 4th pass
-                HZ_HIP(hipMemcpyAsync(&finished, n_done, 4, hipMemcpyDeviceToHost, st));
-                HZ_HIP(hipStreamSynchronize(st));
-            }
+        size_t finished = 0;
+        int cur = 0;
+        for (int pass = 0; pass < 200; pass++) {
+            unsigned int n_list = 0;
+            HZ_HIP(hipMemcpyAsync(&n_list, &counts[cur], 4, hipMemcpyDeviceToHost, st));
+            HZ_HIP(hipStreamSynchronize(st));
+            if (n_list == 0) break;
+            if (n_list > list_cap) return set_error(HZ_ERR_HIP, "BVH refit work list overflow");
+            HZ_HIP(hipMemsetAsync(&counts[cur ^ 1], 0, 4, st));
+            hipLaunchKernelGGL(k_refit_pass, dim3((n_list + 255) / 256), dim3(256), 0, st, (const int *)lists[cur],
+                               n_list, (const int2 *)b_child.p, (const int *)b_pint.p, (const uint8_t *)b_plen.p,
+                               (const float4 *)b_llo.p, (const float4 *)b_lhi.p, (float4 *)b_nlo.p,
+                               (float4 *)b_nhi.p, arrivals, lists[cur ^ 1], &counts[cur ^ 1]);
+            finished += n_list;
+            cur ^= 1;
         }
-        HZ_HIP(hipMemcpyAsync(&finished, n_done, 4, hipMemcpyDeviceToHost, st));
-        HZ_HIP(hipStreamSynchronize(st));
-        if (finished != (unsigned)n_bin)
-            return set_error(HZ_ERR_DEPTH, "BVH refit did not converge (%u of %d nodes)", finished, n_bin);
+        if (finished != (size_t)n_bin)
+            return set_error(HZ_ERR_DEPTH, "BVH refit did not converge (%zu of %d nodes)", finished, n_bin);
     }
 
     // ---- 6. which binary nodes open a 4-wide node; compact indices ------------------------
@@ -541,12 +594,12 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
         HZ_HIP(b_idx.alloc((size_t)n_bin * 4));
         hipLaunchKernelGGL(k_roots, dim3(gn), dim3(256), 0, st, n_bin, (const int *)b_pint.p,
                            (const uint8_t *)b_plen.p, (uint32_t *)b_flag.p);
-        size_t scan_bytes = 0;
-        HZ_HIP(rocprim::exclusive_scan(nullptr, scan_bytes, (uint32_t *)b_flag.p, (uint32_t *)b_idx.p, 0u,
-                                       (size_t)n_bin, rocprim::plus<uint32_t>(), st));
-        HZ_HIP(b_scan.alloc(scan_bytes));
-        HZ_HIP(rocprim::exclusive_scan(b_scan.p, scan_bytes, (uint32_t *)b_flag.p, (uint32_t *)b_idx.p, 0u,
-                                       (size_t)n_bin, rocprim::plus<uint32_t>(), st));
+        HZ_HIP(b_scan.alloc(scan_temp_elems((size_t)n_bin) * 4));
+        {
+            const int rc = exclusive_scan_u32((const uint32_t *)b_flag.p, (uint32_t *)b_idx.p, (size_t)n_bin,
+                                              (uint32_t *)b_scan.p, st);
+            if (rc) return rc;
+        }
         uint32_t last_idx = 0, last_flag = 0;
         HZ_HIP(hipMemcpyAsync(&last_idx, (uint32_t *)b_idx.p + (n_bin - 1), 4, hipMemcpyDeviceToHost, st));
         HZ_HIP(hipMemcpyAsync(&last_flag, (uint32_t *)b_flag.p + (n_bin - 1), 4, hipMemcpyDeviceToHost, st));
@@ -573,6 +626,9 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     int n_top = 1;
     TempBuf b_tmp4, b_perm, b_top, b_intop;
     if (n_prims > 1) {
+        HZ_HIP(arena2.reserve(Arena::pad((size_t)n4 * sizeof(Node)) + Arena::pad((size_t)n4 * 4) + 3 * 4096 +
+                              Arena::pad((size_t)HZ_MAX_TOP_NODES * 8)));
+        g_arena = &arena2;
         HZ_HIP(b_tmp4.alloc((size_t)n4 * sizeof(Node)));
         Emit4 e;
         e.child = (const int2 *)b_child.p; e.plen = (const uint8_t *)b_plen.p; e.first = (const int *)b_first.p;

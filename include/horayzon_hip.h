@@ -170,6 +170,11 @@ int hz_visible_sky_fraction(const float *azim, const float *hori, const float *v
 int hz_topographic_openness(const float *azim, const float *hori, int len_0, int len_1, int len_2,
                             float *top, int device);
 
+/* Test hooks for the hand-written build primitives (stable radix sort of uint32 pairs by key,   */
+/* exclusive prefix sum); host arrays, in place / in -> out.  Not needed by a binding.            */
+int hz_debug_sort_pairs(uint32_t *keys, uint32_t *vals, size_t n, int device);
+int hz_debug_exclusive_scan(const uint32_t *in, uint32_t *out, size_t n, int device);
+
 /* ------------------------------------------------------------------------- */
 /* Steps next to the path: slope and input preparation */
 /* ------------------------------------------------------------------------- */

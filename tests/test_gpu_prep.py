@@ -96,3 +96,24 @@ def test_prepared_input_feeds_the_horizon_path(hip, orc):
                                            elev_ang_low_lim=-89.98, ray_algorithm="binary_search")
     # inputs agree to float32 rounding; the horizon may move by at most one search bracket somewhere
     assert (h_mine != h_ref).mean() < 0.02 and np.abs(h_mine - h_ref).max() <= 2.5 * np.deg2rad(0.25)
+
+
+@pytest.mark.parametrize("n", (1, 63, 1024, 1025, 70001, 3_000_017))
+def test_build_primitives_sort_and_scan(hip, n):
+    """The hand-written radix sort (stable, by key) and exclusive scan of the LBVH build."""
+    from horayzon_amd import _lib
+    rng = np.random.default_rng(n)
+    keys = rng.integers(0, 2 ** 32, n, dtype=np.uint64).astype(np.uint32)
+    keys[::3] = keys[0]                                   # many duplicates: stability matters
+    if n > 100:
+        keys[5:60] &= np.uint32(0xff)                     # and keys that differ in one digit only
+    vals = np.arange(n, dtype=np.uint32)
+    k, v = keys.copy(), vals.copy()
+    _lib.check(_lib.lib().hz_debug_sort_pairs(k.ctypes.data, v.ctypes.data, n, 0))
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(k, keys[order]) and np.array_equal(v, vals[order])
+    x = rng.integers(0, 5, n, dtype=np.uint32)
+    out = np.empty(n, np.uint32)
+    _lib.check(_lib.lib().hz_debug_exclusive_scan(x.ctypes.data, out.ctypes.data, n, 0))
+    ref = np.concatenate([[0], np.cumsum(x[:-1], dtype=np.uint64)]).astype(np.uint32)
+    assert np.array_equal(out, ref)
