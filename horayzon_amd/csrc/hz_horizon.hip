@@ -23,7 +23,6 @@
 // The float/double promotion pattern of the reference's index arithmetic is
 // reproduced exactly (hard part 2); tables are built on the
 // host with the reference's expressions (hz_api.cpp) and only read here.
-#include <cstdlib>
 #include "hz_search.h"
 
 namespace hz {
@@ -188,14 +187,13 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
     const int rows = a.row_end - a.row_begin;
     if (rows <= 0 || a.dim_in_1 <= 0) return HZ_OK;
     const int tiles_i = (rows + 15) / 16;
-    p.tm = make_tile_map(tiles_i, (a.dim_in_1 + 15) / 16, getenv("HZ_GW") ? atoi(getenv("HZ_GW")) : 8);
+    p.tm = make_tile_map(tiles_i, (a.dim_in_1 + 15) / 16);
     p.dist = a.dist; p.hori_fill = a.hori_fill; p.ray_org_elev = a.ray_org_elev;
     // stack: at most 3 pending siblings per 4-wide level
     const int depth = 3 * std::max(sc->hdr.height, 1);
     p.stack_bytes = depth * HZ_TPB * 4;
     // output staging (4 azimuths per lane) when the 16 B stores are aligned: azim_num % 4 == 0
     p.stage_bytes = ((a.azim_num & 3) == 0 && (reinterpret_cast<size_t>(a.hori) & 15) == 0) ? 4 * HZ_TPB * 4 : 0;
-    if (getenv("HZ_NO_STAGE")) p.stage_bytes = 0;   // A/B switch for measurements
     // LDS nodelet: whatever LDS is left at the workgroup residency the stacks allow (160 KiB per CU)
     int top = a.top_nodes;
     if (top < 0) {
