@@ -23,7 +23,7 @@ class hz_opts(C.Structure):
     _fields_ = [("device", C.c_int32), ("verbose", C.c_int32),
                 ("row_begin", C.c_int32), ("row_end", C.c_int32),
                 ("top_nodes", C.c_int32), ("regroup", C.c_int32),
-                ("count_work", C.c_int32), ("reserved", C.c_int32),
+                ("count_work", C.c_int32), ("no_hit_cache", C.c_int32),
                 ("svf", C.c_void_p), ("vec_tilt", C.c_void_p),
                 ("skip_hori", C.c_int32), ("reserved2", C.c_int32)]
 

@@ -285,6 +285,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     a.top_nodes = opts ? opts->top_nodes : -1;
     a.regroup = opts ? opts->regroup : -1;
     a.count_work = opts ? opts->count_work : 0;
+    a.hit_cache = (opts && opts->no_hit_cache) ? 0 : 1;
     a.counters = (unsigned long long *)cnt_dev;
 
     // HIP events on the kernels' stream: horizon kernel and SVF kernel are timed separately

@@ -2,7 +2,7 @@
 //
 // Scene blob layout in HBM (one contiguous, position-independent allocation):
 //
-//   [ BlobHeader (256 B) | vertices f32[3*V] | nodes Node[max(P-1,1)] | prims Prim[P] ]
+//   [ BlobHeader (256 B) | vertices f32[3*V] | nodes Node[~P/3] | prims Prim[P] | anc i32[P] ]
 //
 // vertices : the caller's vert_grid, untouched (ray origins read them;
 //            reference: shared vertex buffer, horizon_comp.cpp:126-127).
@@ -18,6 +18,11 @@
 //            makes the box test conservative with respect to the float32
 //            triangle test: hit decisions depend on the triangle test only,
 //            never on the tree.
+// anc      : per leaf the index of the node a few levels above it.  A ray that is expected to be
+//            blocked (it points below the horizon found for the previous azimuth) first walks the
+//            subtree above the leaf that blocked the previous ray of this cell -- the blocking
+//            ridge moves little between neighbouring azimuths -- and only falls back to the root
+//            when that finds nothing.  Any-hit results cannot change (section 4 of DESIGN.md).
 // prims    : one 48 B record per leaf in Morton order = the 4 corner vertices
 //            of a DEM quad (two triangles a,b,c / b,d,c -- the split of
 //            horizon_comp.cpp:139-151) or the 3 vertices of a TIN triangle
@@ -27,7 +32,7 @@
 #include <hip/hip_runtime.h>
 
 #define HZ_BLOB_MAGIC 0x485a4c42u /* "HZLB" */
-#define HZ_BLOB_VERSION 3u
+#define HZ_BLOB_VERSION 4u
 #define HZ_WAVE 64
 
 struct BlobHeader {
@@ -40,7 +45,9 @@ struct BlobHeader {
     float lo[3], hi[3];
     uint32_t reserved0[2];
     uint64_t off_verts, off_nodes, off_prims, total_bytes;
-    uint8_t reserved[256 - 120];
+    uint64_t off_anc;        // int32[P]: for every leaf the node `anc_levels` levels above it (hit cache)
+    int32_t anc_levels;
+    uint8_t reserved[256 - 132];
 };
 static_assert(sizeof(BlobHeader) == 256, "BlobHeader must be 256 bytes");
 

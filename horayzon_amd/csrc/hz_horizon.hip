@@ -39,7 +39,7 @@ struct HorizonParams {
     int row_begin, row_end;
     TileMap tm;                    // tile grid of the slab -> workgroups (XCD aware)
     float dist, hori_fill, ray_org_elev;
-    int top_nodes, regroup, stack_bytes, leaf_bias, stage_bytes;
+    int top_nodes, regroup, stack_bytes, leaf_bias, stage_bytes, hit_cache;
     unsigned long long *counters;
 };
 
@@ -107,6 +107,8 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
     float dx = 0, dy = 0, dz = 1;
     RayBox rb = hz_raybox(0, 0, 0, 0, 0, 1);
     TravState ts; hz_trav_reset(ts);
+    int cache = 0;           // hit cache: subtree above the leaf that blocked this cell's last blocked ray
+    bool second = false;     // the cache walk found nothing: the root traversal is still due
 
     while (__ballot(!done) != 0ull) {
         // ---- refill: lanes without a ray take the next sample of their search -----------------
@@ -121,6 +123,9 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
                 dz = (r20 * rx + r21 * ry) + r22 * rz;
                 rb = hz_raybox(ocx, ocy, ocz, dx, dy, dz);
                 hz_trav_reset(ts);
+                // a ray below the previous azimuth's horizon is expected to be blocked near the same ridge
+                second = p.hit_cache && (cache != 0) && (s.ind <= s.pazim) && (s.k > 0);
+                if (second) ts.node = cache;
                 ray_active = true;
                 rays++;
             } else {
@@ -131,7 +136,12 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
         if (ray_active) {
             const int r = hz_trace<HZ_TPB, COUNT>(p.sv.nodes, p.sv.prims, top, ntop, stack, tid, ox, oy, oz,
                                                  dx, dy, dz, tfar, rb, ts, p.regroup, p.leaf_bias, tc);
-            if (r != 2) { ray_active = false; last_hit = (r == 1); }
+            if (r == 0 && second) {                      // nothing in the cached subtree: full traversal
+                second = false; hz_trav_reset(ts);
+            } else if (r != 2) {
+                ray_active = false; last_hit = (r == 1);
+                if (r == 1) cache = p.sv.anc[~ts.lq0];   // ts.lq0 is the leaf that blocked the ray
+            }
         }
     }
 
@@ -208,6 +218,7 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
     // are traversing; leaf step when 24 n_leaf > 16 n_node.  opts.regroup = threshold | bias << 8.
     p.regroup = (a.regroup < 0) ? 48 : std::min(a.regroup & 0xff, 64);
     p.leaf_bias = (a.regroup >= 256) ? (a.regroup >> 8) : 24;
+    p.hit_cache = (a.hit_cache != 0) ? 1 : 0;
     p.counters = a.counters;
     const size_t lds = (size_t)p.stack_bytes + (size_t)p.stage_bytes + (size_t)top * sizeof(Node);
     const int grid = p.tm.per_xcd * 8;

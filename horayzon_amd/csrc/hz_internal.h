@@ -10,6 +10,8 @@
 
 #define HZ_MAX_TOP_NODES 2047   // upper bound of BFS-ordered top nodes (LDS staging)
 #define HZ_MAX_STACK 96         // LDS stack entries per lane the traversal kernels accept (3 per 4-wide level)
+// hit cache: levels between a leaf and its cached ancestor (measured 1..9 on the 3601^2 tile: 5-6 best)
+#define HZ_ANC_LEVELS 5
 
 namespace hz {
 
@@ -41,6 +43,7 @@ struct Scene {
     const float *verts() const { return (const float *)((const char *)blob + hdr.off_verts); }
     const Node *nodes() const { return (const Node *)((const char *)blob + hdr.off_nodes); }
     const Prim *prims() const { return (const Prim *)((const char *)blob + hdr.off_prims); }
+    const int *anc() const { return (const int *)((const char *)blob + hdr.off_anc); }
 };
 
 // hz_scene.hip
@@ -52,6 +55,7 @@ struct SceneView {
     const float *verts;
     const Node *nodes;
     const Prim *prims;
+    const int *anc;  // hit-cache ancestors, one per leaf
     int d1;          // DEM row length (vertices)
     int n_top;       // BFS-ordered top nodes available for LDS staging
     float cx, cy, cz;
@@ -59,7 +63,7 @@ struct SceneView {
 
 inline SceneView scene_view(const Scene *sc) {
     SceneView v;
-    v.verts = sc->verts(); v.nodes = sc->nodes(); v.prims = sc->prims();
+    v.verts = sc->verts(); v.nodes = sc->nodes(); v.prims = sc->prims(); v.anc = sc->anc();
     v.d1 = sc->hdr.d1; v.n_top = sc->hdr.n_top;
     v.cx = sc->hdr.center[0]; v.cy = sc->hdr.center[1]; v.cz = sc->hdr.center[2];
     return v;
@@ -99,7 +103,7 @@ struct HorizonArgs {
     float hori_fill, ray_org_elev;
     const float *azim_sin, *azim_cos, *elev_ang, *elev_sin, *elev_cos;  // device tables
     const int *mid_idx;
-    int top_nodes, regroup, count_work;
+    int top_nodes, regroup, count_work, hit_cache;
     unsigned long long *counters;        // device u64[8]: [0] rays, [1] guards, [2] nodes, [3] tris, [4] cells
 };
 int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st);

@@ -380,6 +380,33 @@ __global__ __launch_bounds__(256) void k_emit_prims(BuildParams b, const uint32_
     prims[s] = p;
 }
 
+// --- hit-cache ancestors: for every leaf the node `levels` levels above it --------------------------
+__global__ __launch_bounds__(256) void k_parents4(int n4, const Node *__restrict__ nodes, int *__restrict__ parent4,
+                                                 int *__restrict__ leaf_parent) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    if (i == 0) parent4[0] = -1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int l = nodes[i].link[k];
+        if (l >= 0) parent4[l] = i;
+        else if (l != HZ_EMPTY) leaf_parent[~l] = i;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ancestors(int n_prims, int levels, const int *__restrict__ parent4,
+                                                  const int *__restrict__ leaf_parent, int *__restrict__ anc) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_prims) return;
+    int n = leaf_parent[s];
+    for (int r = 1; r < levels; r++) {
+        const int p = parent4[n];
+        if (p < 0) break;
+        n = p;
+    }
+    anc[s] = n;
+}
+
 // single primitive: a root whose slot 0 is the leaf, quantised against its own box
 __global__ void k_single_node(const float4 *leaf_lo, const float4 *leaf_hi, Node *nodes) {
     const float4 l = leaf_lo[0], h = leaf_hi[0];
@@ -612,7 +639,9 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     h.off_verts = sizeof(BlobHeader);
     h.off_nodes = align_up(h.off_verts + nvert * 12, 256);
     h.off_prims = align_up(h.off_nodes + (size_t)n4 * sizeof(Node), 256);
-    h.total_bytes = align_up(h.off_prims + (size_t)n_prims * sizeof(Prim), 256);
+    h.off_anc = align_up(h.off_prims + (size_t)n_prims * sizeof(Prim), 256);
+    h.anc_levels = HZ_ANC_LEVELS;
+    h.total_bytes = align_up(h.off_anc + (size_t)n_prims * 4, 256);
     HZ_HIP(hipMalloc(&sc->blob, h.total_bytes));
     sc->owns_blob = true;
     sc->blob_bytes = h.total_bytes;
@@ -620,14 +649,15 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     float *d_verts = (float *)(blob + h.off_verts);
     Node *d_nodes = (Node *)(blob + h.off_nodes);
     Prim *d_prims = (Prim *)(blob + h.off_prims);
+    int *d_anc = (int *)(blob + h.off_anc);
     HZ_HIP(hipMemcpyAsync(d_verts, d_verts_src, nvert * 12, hipMemcpyDeviceToDevice, st));
 
     // ---- 7./8. emit 4-wide nodes, relabel the top breadth first ----------------------------------
     int n_top = 1;
     TempBuf b_tmp4, b_perm, b_top, b_intop;
     if (n_prims > 1) {
-        HZ_HIP(arena2.reserve(Arena::pad((size_t)n4 * sizeof(Node)) + Arena::pad((size_t)n4 * 4) + 3 * 4096 +
-                              Arena::pad((size_t)HZ_MAX_TOP_NODES * 8)));
+        HZ_HIP(arena2.reserve(Arena::pad((size_t)n4 * sizeof(Node)) + 2 * Arena::pad((size_t)n4 * 4) + 4 * 4096 +
+                              Arena::pad((size_t)HZ_MAX_TOP_NODES * 8) + Arena::pad((size_t)n_prims * 4)));
         g_arena = &arena2;
         HZ_HIP(b_tmp4.alloc((size_t)n4 * sizeof(Node)));
         Emit4 e;
@@ -651,6 +681,19 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     } else {
         hipLaunchKernelGGL(k_single_node, dim3(1), dim3(1), 0, st, (const float4 *)b_llo.p,
                            (const float4 *)b_lhi.p, d_nodes);
+    }
+    // ---- hit-cache ancestors (from the final node numbering) ---------------------------------------
+    if (n_prims > 1) {
+        TempBuf b_par4, b_lpar;
+        HZ_HIP(b_par4.alloc((size_t)n4 * 4));
+        HZ_HIP(b_lpar.alloc((size_t)n_prims * 4));
+        hipLaunchKernelGGL(k_parents4, dim3((n4 + 255) / 256), dim3(256), 0, st, n4, (const Node *)d_nodes,
+                           (int *)b_par4.p, (int *)b_lpar.p);
+        hipLaunchKernelGGL(k_ancestors, dim3(gp), dim3(256), 0, st, n_prims, std::max(1, h.anc_levels),
+                           (const int *)b_par4.p, (const int *)b_lpar.p, d_anc);
+        HZ_HIP(hipStreamSynchronize(st));      // b_par4 / b_lpar leave scope (arena memory stays valid anyway)
+    } else {
+        HZ_HIP(hipMemsetAsync(d_anc, 0, 4, st));
     }
     // ---- 9. leaf records ------------------------------------------------------------------------
     hipLaunchKernelGGL(k_emit_prims, dim3(gp), dim3(256), 0, st, bp, vals, d_prims);

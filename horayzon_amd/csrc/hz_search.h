@@ -124,6 +124,7 @@ __device__ __forceinline__ bool advance(Search &s, bool hit, const Tables &t, Si
             if (guard) guards++;
             if (ALG == ALG_DISCRETE) {                       // :330
                 s.ev = half_sum(t.elev_ang[s.prev], t.elev_ang[s.ind]); s.phase = PH_EMIT;
+                s.pazim = s.prev;                            // last blocked sample (hit-cache hint only)
                 continue;
             }
             if (s.count > 1) {                               // :460-467

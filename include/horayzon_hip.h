@@ -44,7 +44,8 @@ typedef struct hz_opts {
     int32_t top_nodes;     /* BVH nodes staged in LDS per workgroup (-1 auto)  */
     int32_t regroup;       /* wave regroup threshold in lanes (-1 auto)        */
     int32_t count_work;    /* 1: also count BVH nodes / triangle tests (slow)  */
-    int32_t reserved;
+    int32_t no_hit_cache;  /* 0 (default): rays expected to be blocked first walk the subtree  */
+                           /*   that blocked the cell's previous ray; 1: always start at the root */
     float  *svf;           /* optional fused sky view factor out, f32[y][x]    */
     const float *vec_tilt; /* tilted normals f32[y][x][3] for svf              */
     int32_t skip_hori;     /* 1: hori_buffer may be NULL, only svf is written  */

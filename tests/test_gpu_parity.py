@@ -50,6 +50,22 @@ def test_rough_tilted_frames(hip, orc, alg):
              elev_ang_low_lim=-60.0)
 
 
+@pytest.mark.parametrize("alg", ALGS)
+def test_hit_cache_is_transparent(hip, alg):
+    """The hit cache (blocked rays first walk the subtree above the leaf that blocked the
+    cell's previous ray) only changes the work done, never a result."""
+    g = cases.rough_terrain(150, 170, seed=3, offset=10, tilt_frames=True)
+    kw = cases.grid_kwargs(g)
+    par = dict(dist_search=3.0, azim_num=72, ray_algorithm=alg, elev_ang_low_lim=-60.0, count_work=True)
+    h_on, _ = hip.horizon.horizon_gridded(**kw, **par, _hit_cache=1)
+    st_on = dict(hip.horizon.last_stats)
+    h_off, _ = hip.horizon.horizon_gridded(**kw, **par, _hit_cache=0)
+    st_off = dict(hip.horizon.last_stats)
+    assert np.array_equal(h_on, h_off)
+    assert st_on["num_rays"] == st_off["num_rays"]
+    assert st_on["nodes_visited"] != st_off["nodes_visited"]      # the switch does something
+
+
 def test_large_coordinates(hip, orc):
     """Swiss-grid like offsets (7e5, 2e5): float32 ulp 0.06 m, the AABB padding must hold."""
     g = cases.rough_terrain(80, 90, seed=11, dx=25.0, dy=25.0, offset=5, origin=(668000.0, 172000.0))
