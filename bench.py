@@ -168,6 +168,16 @@ def main():
         rays_total, cells_total = float(stats.num_rays), float(stats.num_cells)
 
     if rank == 0:
+        # device-copy microbenchmark: what a plain HBM stream reaches on this box
+        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+        dst = torch.empty_like(src)
+        dst.copy_(src); torch.cuda.synchronize()
+        tc0 = time.perf_counter()
+        for _ in range(10):
+            dst.copy_(src)
+        torch.cuda.synchronize()
+        copy_gbs = 10 * 2.0 * src.numel() / (time.perf_counter() - tc0) / 1e9
+        del src, dst
         k_launch_s = stats.t_kernel_s / max(args.steps, 1)        # HIP events on the kernel's stream
         rays_launch = stats.num_rays / max(args.steps, 1)
         cells_launch = stats.num_cells / max(args.steps, 1)
@@ -207,7 +217,8 @@ def main():
                          "kernel": "hz::k_horizon<2,false,true>", "kernel_ms_per_launch": 1e3 * k_launch_s,
                          "alg_bytes_per_launch": b_io + b_trav, "nodes_per_ray": nodes_per_ray,
                          "tris_per_ray": tris_per_ray, "mray_per_s_kernel": rays_launch / k_launch_s / 1e6,
-                         "svf_kernel_ms_per_launch": 1e3 * stats.t_svf_s / max(args.steps, 1)},
+                         "svf_kernel_ms_per_launch": 1e3 * stats.t_svf_s / max(args.steps, 1),
+                         "device_copy_gbs": copy_gbs},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(g, args, A)

@@ -25,7 +25,7 @@ class hz_opts(C.Structure):
                 ("top_nodes", C.c_int32), ("regroup", C.c_int32),
                 ("count_work", C.c_int32), ("no_hit_cache", C.c_int32),
                 ("svf", C.c_void_p), ("vec_tilt", C.c_void_p),
-                ("skip_hori", C.c_int32), ("reserved2", C.c_int32)]
+                ("skip_hori", C.c_int32), ("chunk_rows", C.c_int32)]
 
 
 class hz_stats(C.Structure):

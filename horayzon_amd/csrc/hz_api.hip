@@ -245,17 +245,22 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     float *hori_slab_host = hori_buffer ? hori_buffer + (size_t)row_begin * dim_in_1 * azim_num : nullptr;
     float *svf_slab = want_svf ? opts->svf + (size_t)row_begin * dim_in_1 : nullptr;
     if ((rc = d_svf.bind(svf_slab, svf_slab ? slab_cells : 0))) return rc;
-    // rows per launch: the whole slab, unless only the SVF is wanted -- then the horizon of a
-    // chunk of rows lives in a bounded temporary (<= 2 GiB) that the SVF kernel consumes
+    // rows per launch: the whole slab when `hori` is device memory.  Otherwise the horizon of a chunk
+    // of rows lives in a bounded temporary: one <= 4 GiB buffer when only the SVF is wanted, two of
+    // them when `hori` is host memory -- chunk c is copied out on a second stream while chunk c + 1 is
+    // traced, so the D2H time hides behind the kernel and the output may be larger than HBM.
     int chunk_rows = row_end - row_begin;
-    void *tmp_hori = nullptr;
-    struct TmpFree { void **p; ~TmpFree() { if (*p) (void)hipFree(*p); } } tmp_free{&tmp_hori};
-    if (skip_hori) {
-        if (!want_svf) return set_error(HZ_ERR_ARG, "skip_hori without svf: nothing to compute");
-        const size_t row_bytes = (size_t)dim_in_1 * azim_num * 4;
-        chunk_rows = (int)std::max<size_t>(16, std::min<size_t>((size_t)chunk_rows, ((size_t)2 << 30) / row_bytes));
+    void *tmp_hori = nullptr, *tmp_hori2 = nullptr;
+    struct TmpFree { void **p; ~TmpFree() { if (*p) (void)hipFree(*p); } } tmp_free{&tmp_hori}, tmp_free2{&tmp_hori2};
+    const size_t row_bytes = (size_t)dim_in_1 * azim_num * 4;
+    const bool stream_out = !skip_hori && !is_device_ptr(hori_buffer);
+    if (skip_hori || stream_out) {
+        if (skip_hori && !want_svf) return set_error(HZ_ERR_ARG, "skip_hori without svf: nothing to compute");
+        if (opts && opts->chunk_rows > 0) chunk_rows = std::min(chunk_rows, opts->chunk_rows);
+        else chunk_rows = (int)std::max<size_t>(16, std::min<size_t>((size_t)chunk_rows, ((size_t)4 << 30) / row_bytes));
         chunk_rows = std::min(chunk_rows, row_end - row_begin);
         HZ_HIP(hipMalloc(&tmp_hori, (size_t)chunk_rows * row_bytes));
+        if (stream_out && chunk_rows < row_end - row_begin) HZ_HIP(hipMalloc(&tmp_hori2, (size_t)chunk_rows * row_bytes));
     } else {
         if ((rc = d_hori.bind(hori_slab_host, slab_cells * (size_t)azim_num))) return rc;
     }
@@ -289,21 +294,50 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     a.counters = (unsigned long long *)cnt_dev;
 
     // HIP events on the kernels' stream: horizon kernel and SVF kernel are timed separately
-    struct Ev { hipEvent_t a = nullptr, b = nullptr, c = nullptr; };
+    struct Ev { hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr; };
     std::vector<Ev> evs;
-    auto free_events = [&]() { for (auto &e : evs) { if (e.a) (void)hipEventDestroy(e.a); if (e.b) (void)hipEventDestroy(e.b); if (e.c) (void)hipEventDestroy(e.c); } };
-    for (int rb = row_begin; rb < row_end; rb += chunk_rows) {
+    hipStream_t st_copy = nullptr;
+    auto free_events = [&]() {
+        for (auto &e : evs) {
+            if (e.a) (void)hipEventDestroy(e.a);
+            if (e.b) (void)hipEventDestroy(e.b);
+            if (e.c) (void)hipEventDestroy(e.c);
+            if (e.d) (void)hipEventDestroy(e.d);
+        }
+        if (st_copy) (void)hipStreamDestroy(st_copy);
+    };
+    if (stream_out && hipStreamCreateWithFlags(&st_copy, hipStreamNonBlocking) != hipSuccess)
+        return set_error(HZ_ERR_HIP, "hipStreamCreate failed");
+    // copy of chunk k (issued after chunk k + 1 was launched, so a host-blocking pageable copy still overlaps)
+    auto copy_out = [&](int k) -> int {
+        const int rb = row_begin + k * chunk_rows, re = std::min(rb + chunk_rows, row_end);
+        const void *src = (k & 1) ? tmp_hori2 : tmp_hori;
+        if (hipStreamWaitEvent(st_copy, evs[(size_t)k].c, 0) != hipSuccess ||
+            hipMemcpyAsync(hori_buffer + (size_t)rb * dim_in_1 * azim_num, src, (size_t)(re - rb) * row_bytes,
+                           hipMemcpyDeviceToHost, st_copy) != hipSuccess ||
+            hipEventRecord(evs[(size_t)k].d, st_copy) != hipSuccess)
+            return set_error(HZ_ERR_HIP, "copy of the horizon chunk failed: %s", hipGetErrorString(hipGetLastError()));
+        return HZ_OK;
+    };
+    int n_chunk = 0;
+    for (int rb = row_begin; rb < row_end; rb += chunk_rows, n_chunk++) {
         const int re = std::min(rb + chunk_rows, row_end);
         // the kernels index hori by global cell: shift the (slab- or chunk-local) buffer back
-        float *hori_chunk = skip_hori ? (float *)tmp_hori : d_hori.dev + (size_t)(rb - row_begin) * dim_in_1 * azim_num;
+        float *hori_chunk;
+        if (stream_out) hori_chunk = (float *)((n_chunk & 1) ? tmp_hori2 : tmp_hori);
+        else if (skip_hori) hori_chunk = (float *)tmp_hori;
+        else hori_chunk = d_hori.dev + (size_t)(rb - row_begin) * dim_in_1 * azim_num;
         a.hori = hori_chunk - (size_t)rb * dim_in_1 * azim_num;
         a.row_begin = rb; a.row_end = re;
         Ev e;
-        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess || hipEventCreate(&e.c) != hipSuccess) {
+        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess || hipEventCreate(&e.c) != hipSuccess ||
+            hipEventCreate(&e.d) != hipSuccess) {
             evs.push_back(e); free_events();
             return set_error(HZ_ERR_HIP, "hipEventCreate failed");
         }
         evs.push_back(e);
+        // the buffer of chunk n is the one chunk n - 2 was copied out of
+        if (stream_out && n_chunk >= 2) (void)hipStreamWaitEvent(st, evs[(size_t)n_chunk - 2].d, 0);
         (void)hipEventRecord(e.a, st);
         rc = horizon_launch(sc, a, st);
         (void)hipEventRecord(e.b, st);
@@ -311,11 +345,19 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             rc = svf_launch(d_azim.dev, hori_chunk, d_tilt.dev + 3 * (size_t)rb * dim_in_1, re - rb, dim_in_1,
                             azim_num, d_svf.dev + (size_t)(rb - row_begin) * dim_in_1, st);
         (void)hipEventRecord(e.c, st);
-        if (rc) { (void)hipStreamSynchronize(st); free_events(); return rc; }
+        if (!rc && stream_out && n_chunk >= 1) rc = copy_out(n_chunk - 1);
+        if (rc) { (void)hipStreamSynchronize(st); if (st_copy) (void)hipStreamSynchronize(st_copy); free_events(); return rc; }
     }
     {
         const hipError_t se = hipStreamSynchronize(st);
-        if (se != hipSuccess) { free_events(); return set_error(HZ_ERR_HIP, "horizon kernel failed: %s", hipGetErrorString(se)); }
+        if (se != hipSuccess) { if (st_copy) (void)hipStreamSynchronize(st_copy); free_events(); return set_error(HZ_ERR_HIP, "horizon kernel failed: %s", hipGetErrorString(se)); }
+    }
+    Timer t_d2h; t_d2h.start();
+    if (stream_out) {
+        rc = copy_out(n_chunk - 1);
+        const hipError_t se = hipStreamSynchronize(st_copy);
+        if (!rc && se != hipSuccess) rc = set_error(HZ_ERR_HIP, "copy of the horizon failed: %s", hipGetErrorString(se));
+        if (rc) { free_events(); return rc; }
     }
     float ms = 0.0f, ms_svf = 0.0f;
     for (auto &e : evs) {
@@ -327,7 +369,6 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     free_events();
     HZ_HIP(hipGetLastError());
 
-    Timer t_d2h; t_d2h.start();
     unsigned long long cnt[8];
     HZ_HIP(hipMemcpyAsync(cnt, cnt_dev, sizeof(cnt), hipMemcpyDeviceToHost, st));
     if ((rc = d_hori.finish(st))) return rc;

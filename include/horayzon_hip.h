@@ -49,7 +49,9 @@ typedef struct hz_opts {
     float  *svf;           /* optional fused sky view factor out, f32[y][x]    */
     const float *vec_tilt; /* tilted normals f32[y][x][3] for svf              */
     int32_t skip_hori;     /* 1: hori_buffer may be NULL, only svf is written  */
-    int32_t reserved2;
+    int32_t chunk_rows;    /* rows per launch when hori is host memory or skipped (chunks are      */
+                           /*   double buffered and copied out while the next one is traced);      */
+                           /*   <= 0: as many rows as fit 4 GiB                                     */
 } hz_opts;
 
 /* Run-time self report (the quantities the reference prints,                  */

@@ -171,6 +171,27 @@ def test_row_slab(hip, orc):
     assert np.isnan(part[:17]).all() and np.isnan(part[40:]).all()
 
 
+@pytest.mark.parametrize("chunk", (1, 7, 16, 1000))
+def test_streamed_host_output(hip, chunk):
+    """Host `hori`: chunks of rows are double buffered on the device and copied out while the next
+    chunk is traced; any chunking (incl. ragged last chunk, one chunk, a row slab) gives the same array."""
+    g = cases.rough_terrain(70, 66, seed=13, offset=3)
+    kw = cases.grid_kwargs(g)
+    par = dict(dist_search=1.0, azim_num=12, elev_ang_low_lim=-60.0)
+    full, _ = hip.horizon.horizon_gridded(**kw, **par)
+    rays = hip.horizon.last_stats["num_rays"]
+    got, _ = hip.horizon.horizon_gridded(**kw, **par, _chunk_rows=chunk)
+    assert np.array_equal(got, full)
+    assert hip.horizon.last_stats["num_rays"] == rays
+    part, _ = hip.horizon.horizon_gridded(**kw, **par, rows=(5, 41), _chunk_rows=chunk)
+    assert np.array_equal(part[5:41], full[5:41])
+    assert np.isnan(part[:5]).all() and np.isnan(part[41:]).all()
+    vec_tilt = np.zeros(full.shape[:2] + (3,), np.float32); vec_tilt[..., 2] = 1.0
+    h2, _, svf = hip.horizon.horizon_gridded(**kw, **par, svf_vec_tilt=vec_tilt, _chunk_rows=chunk)
+    h1, _, svf1 = hip.horizon.horizon_gridded(**kw, **par, svf_vec_tilt=vec_tilt)
+    assert np.array_equal(h2, full) and np.array_equal(svf, svf1)
+
+
 def test_persistent_scene_and_blob_adopt(hip, orc):
     """A scene blob copied byte for byte (what an RCCL broadcast does) gives identical results."""
     import ctypes as C
