@@ -244,7 +244,9 @@ def horizon_locations(vert_grid, dem_dim_0, dem_dim_1, coords, vec_norm, vec_nor
     opts.verbose = int(bool(verbose))
     stats = hz_stats()
     L = _lib.lib()
-    if scene is None:
+    if num_loc == 0:    # the reference's loop over locations simply does not run
+        rc = 0
+    elif scene is None:
         rc = L.hz_horizon_locations(
             ptr(vert_grid), dem_dim_0, dem_dim_1, ptr(coords), ptr(vec_norm), ptr(vec_north),
             ptr(hori_buffer), ptr(hori_dist_buffer) if hori_dist_out else None, num_loc, azim_num,

@@ -126,6 +126,10 @@ def test_horizon_validation_errors():
         call(vert_grid=kw["vert_grid"].astype(np.float64))
     with pytest.raises(ValueError, match="dimensions"):
         call(vec_norm=kw["vec_norm"][0])
+    # horizon.pyx:149-151: a DEM dimension above 32767 is refused (checked after the buffer sizes)
+    wide = np.zeros(3 * 2 * 32768, np.float32)
+    with pytest.raises(ValueError, match="maximal allowed input length"):
+        f(wide, 2, 32768, np.zeros((1, 1, 3), np.float32), np.zeros((1, 1, 3), np.float32), 0, 0, 1.0)
 
 
 def test_locations_validation_errors():
