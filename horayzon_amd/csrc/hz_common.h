@@ -10,8 +10,7 @@
 //            Morton key (= a quadtree over the (x, y) centroids).  One node is
 //            64 B and holds the conservatively quantised AABBs (8 bit x/y,
 //            16 bit z, relative to the node's own box) and the links of up to 4
-//            children, stored in Morton-digit order (slot = 2*ybit + xbit), so
-//            a front-to-back order follows from the ray's direction signs.
+//            children, stored in Morton-digit order (slot = 2*ybit + xbit).
 //            The first `n_top` nodes are the top of the tree in breadth-first
 //            order (staged in LDS by the kernels).  AABBs live in a frame
 //            centred on the scene (`center`) and are padded by `pad`, which
@@ -232,7 +231,6 @@ __device__ __forceinline__ bool hz_tri_hit_t(float ox, float oy, float oz, float
 struct RayBox {
     float rdx, rdy, rdz;     // 1 / d (clamped away from inf)
     float ordx, ordy, ordz;  // (o - center) * rd
-    int order;               // (dy < 0 ? 2 : 0) | (dx < 0 ? 1 : 0): slot visited r-th = r ^ order
     uint32_t sel_xy, sel_z;  // v_perm selectors that put the NEAR bound first: (x_near, x_far, y_near, y_far)
                              // and (z_near, z_far); near = lo when 1/d > 0, hi otherwise
 };
@@ -247,7 +245,6 @@ __device__ __forceinline__ RayBox hz_raybox(float ocx, float ocy, float ocz,
     RayBox r;
     r.rdx = hz_safe_rcp(dx); r.rdy = hz_safe_rcp(dy); r.rdz = hz_safe_rcp(dz);
     r.ordx = ocx * r.rdx; r.ordy = ocy * r.rdy; r.ordz = ocz * r.rdz;
-    r.order = ((dy < 0.0f) ? 2 : 0) | ((dx < 0.0f) ? 1 : 0);
     // selector bytes 0..3 pick bytes 0..3 of the second v_perm operand
     r.sel_xy = ((r.rdy < 0.0f) ? 0x02030000u : 0x03020000u) | ((r.rdx < 0.0f) ? 0x00000001u : 0x00000100u);
     r.sel_z = (r.rdz < 0.0f) ? 0x01000302u : 0x03020100u;
@@ -384,19 +381,15 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
                 const bool h1 = hz_qbox_hit(nr, rb, tfar, n1.y, n2.y);
                 const bool h2 = hz_qbox_hit(nr, rb, tfar, n1.z, n2.z);
                 const bool h3 = hz_qbox_hit(nr, rb, tfar, n1.w, n2.w);
-                // visit order: slot r ^ order for r = 0..3 (front to back in x / y):
-                // bit 0 of `order` swaps neighbours, bit 1 swaps the halves
-                const bool s1 = (rb.order & 1) != 0, s2 = (rb.order & 2) != 0;
-                const int a0 = s1 ? n3.y : n3.x, a1 = s1 ? n3.x : n3.y, a2 = s1 ? n3.w : n3.z, a3 = s1 ? n3.z : n3.w;
-                const bool b0 = s1 ? h1 : h0, b1 = s1 ? h0 : h1, b2 = s1 ? h3 : h2, b3 = s1 ? h2 : h3;
-                const int l0 = s2 ? a2 : a0, l1 = s2 ? a3 : a1, l2 = s2 ? a0 : a2, l3 = s2 ? a1 : a3;
-                const bool g0 = s2 ? b2 : b0, g1 = s2 ? b3 : b1, g2 = s2 ? b0 : b2, g3 = s2 ? b1 : b3;
+                // children are visited in slot order.  A front-to-back order (slot r ^ direction signs,
+                // ~45 VALU per step) was measured to be a net loss: these are any-hit rays, a blocked ray
+                // is blocked over a long stretch behind the first ridge, and near-horizon rays that only
+                // nick a crest are served by the hit cache.
                 int next = HZ_EMPTY;
-                // r = 3 .. 0: the last hit seen (smallest r) becomes `next`, the previous `next` is pushed
-                if (g3) next = l3;
-                if (g2) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = l2; }
-                if (g1) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = l1; }
-                if (g0) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = l0; }
+                if (h3) next = n3.w;
+                if (h2) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = n3.z; }
+                if (h1) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = n3.y; }
+                if (h0) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = n3.x; }
                 if (next != HZ_EMPTY) node = next; else HZ_POP();
             }
         } else {
