@@ -341,7 +341,7 @@ __device__ __forceinline__ void hz_trav_reset(TravState &t) {
 
 #define HZ_WAVE_TICK(c, lane_) do { const unsigned long long m_ = __ballot(1); if ((lane_) == __ffsll((long long)m_) - 1) (c)++; } while (0)
 
-template <int TPB, bool COUNT, int QLEN = 2>
+template <int TPB, bool COUNT, int QLEN = 2, bool NODELET = false>
 __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Prim *__restrict__ prims,
                                         const float4 *top, int ntop, int *stack, int tid,
                                         float ox, float oy, float oz, float dx, float dy, float dz, float tfar,
@@ -371,9 +371,10 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
             // ---------------- node step ------------------------------------------------------
             if (can_node) {
                 float4 n0; uint4 n1, n2; int4 n3;
-                // top-of-tree nodelet from LDS, the rest from global memory.  Two separate asm paths:
-                // a per-lane pointer select would be compiled into (slow) flat loads.
-                if (node < ntop) hz_load_node_lds(top + 4 * node, n0, n1, n2, n3);
+                // NODELET: top-of-tree nodes from LDS, the rest from global memory (two separate asm paths:
+                // a per-lane pointer select would be compiled into slow flat loads).  Measured 2 % slower
+                // than plain global loads -- the top of the tree is L1 resident -- so it is opt-in.
+                if (NODELET && node < ntop) hz_load_node_lds(top + 4 * node, n0, n1, n2, n3);
                 else hz_load_node(nodes + node, n0, n1, n2, n3);
                 if (COUNT) { cnt.nodes++; HZ_WAVE_TICK(cnt.w_nodes, lane); }
                 const NodeRay nr = hz_node_ray(rb, n0.x, n0.y, n0.z, __float_as_uint(n0.w));

@@ -67,15 +67,9 @@ __device__ __forceinline__ bool occluded(const SceneView &sv, const float4 *top,
 __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *stack = reinterpret_cast<int *>(smem);
-    const float4 *top = reinterpret_cast<const float4 *>(smem + p.stack_bytes);
+    const float4 *top = nullptr;      // no LDS nodelet: the top of the tree is L1 resident
     const int tid = threadIdx.x;
-    const int ntop = p.top_nodes;
-    if (ntop > 0) {
-        float4 *dst = reinterpret_cast<float4 *>(smem + p.stack_bytes);
-        const float4 *src = reinterpret_cast<const float4 *>(p.sv.nodes);
-        for (int i = tid; i < ntop * 4; i += HZ_TPB) dst[i] = src[i];
-        __syncthreads();
-    }
+    const int ntop = 0;
     int ti = 0, tj = 0;
     const bool has_tile = hz_tile_of_block(p.tm, blockIdx.x, &ti, &tj);
     const int wave = tid >> 6, lane = tid & 63;
@@ -163,17 +157,9 @@ int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st) {
     p.refrac = a.refrac_cor; p.which = a.which;
     p.out_u8 = a.out_u8; p.out_f32 = a.out_f32;
     p.stack_bytes = 3 * std::max(sc->hdr.height, 1) * HZ_TPB * 4;
-    // LDS nodelet: whatever LDS is left at the workgroup residency the stacks allow (160 KiB per CU)
-    int top = a.top_nodes;
-    if (top < 0) {
-        const int lds_cu = 160 * 1024;
-        const int blocks = std::max(1, std::min(8, lds_cu / std::max(p.stack_bytes, 1)));
-        top = std::max(0, (lds_cu / blocks - p.stack_bytes) / (int)sizeof(Node));
-    }
-    top = std::min(top, sc->hdr.n_top);
-    p.top_nodes = top;
+    p.top_nodes = 0;
     p.counters = a.counters;
-    const size_t lds = (size_t)p.stack_bytes + (size_t)top * sizeof(Node);
+    const size_t lds = (size_t)p.stack_bytes;
     const int grid = p.tm.per_xcd * 8;
     HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shadow),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

@@ -41,7 +41,8 @@ typedef struct hz_opts {
     int32_t verbose;       /* 1: print the reference's stdout report           */
     int32_t row_begin;     /* inner-domain row slab [row_begin, row_end) to    */
     int32_t row_end;       /*   compute; row_end <= 0 means dim_in_0           */
-    int32_t top_nodes;     /* BVH nodes staged in LDS per workgroup (-1 auto)  */
+    int32_t top_nodes;     /* > 0: stage that many top-of-tree BVH nodes in LDS (guess_constant;   */
+                           /*   measured 2 % slower than L1 reads, so <= 0 means none)            */
     int32_t regroup;       /* wave regroup threshold in lanes (-1 auto)        */
     int32_t count_work;    /* 1: also count BVH nodes / triangle tests (slow)  */
     int32_t no_hit_cache;  /* 0 (default): rays expected to be blocked first walk the subtree  */

@@ -66,6 +66,19 @@ def test_hit_cache_is_transparent(hip, alg):
     assert st_on["nodes_visited"] != st_off["nodes_visited"]      # the switch does something
 
 
+def test_lds_nodelet_variant_is_transparent(hip):
+    """opts.top_nodes > 0 selects the kernel variant that serves the top of the tree from LDS."""
+    g = cases.rough_terrain(150, 170, seed=3, offset=10, tilt_frames=True)
+    kw = cases.grid_kwargs(g)
+    par = dict(dist_search=3.0, azim_num=72, elev_ang_low_lim=-60.0)
+    h0, _ = hip.horizon.horizon_gridded(**kw, **par)
+    rays = hip.horizon.last_stats["num_rays"]
+    for top in (1, 21, 300, 100000):
+        h1, _ = hip.horizon.horizon_gridded(**kw, **par, _top_nodes=top)
+        assert np.array_equal(h0, h1)
+        assert hip.horizon.last_stats["num_rays"] == rays
+
+
 def test_large_coordinates(hip, orc):
     """Swiss-grid like offsets (7e5, 2e5): float32 ulp 0.06 m, the AABB padding must hold."""
     g = cases.rough_terrain(80, 90, seed=11, dx=25.0, dy=25.0, offset=5, origin=(668000.0, 172000.0))
