@@ -213,10 +213,10 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
     top = std::min(top, std::max(0, (80 * 1024 - (p.stack_bytes + p.stage_bytes)) / (int)sizeof(Node)));
     top = std::min(top, sc->hdr.n_top);
     p.top_nodes = top;
-    // defaults from the sweep on the 3601^2 tile: refill when fewer than 48 lanes
-    // are traversing; leaf step when 24 n_leaf > 16 n_node.  opts.regroup = threshold | bias << 8.
-    p.regroup = (a.regroup < 0) ? 48 : std::min(a.regroup & 0xff, 64);
-    p.leaf_bias = (a.regroup >= 256) ? (a.regroup >> 8) : 24;
+    // defaults from the sweep on the 3601^2 tile: refill when fewer than 40 lanes
+    // are traversing; leaf step when 20 n_leaf > 16 n_node.  opts.regroup = threshold | bias << 8.
+    p.regroup = (a.regroup < 0) ? 40 : std::min(a.regroup & 0xff, 64);
+    p.leaf_bias = (a.regroup >= 256) ? (a.regroup >> 8) : 20;
     p.hit_cache = (a.hit_cache != 0) ? 1 : 0;
     p.counters = a.counters;
     const size_t lds = (size_t)p.stack_bytes + (size_t)p.stage_bytes + (size_t)top * sizeof(Node);

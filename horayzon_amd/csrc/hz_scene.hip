@@ -305,6 +305,22 @@ __global__ __launch_bounds__(256) void k_emit4(Emit4 e, Node *__restrict__ nodes
             if (k == slot) { link[k] = lk; lo[k][0] = bl.x; lo[k][1] = bl.y; lo[k][2] = bl.z;
                              hi[k][0] = bh.x; hi[k][1] = bh.y; hi[k][2] = bh.z; }
     }
+    // the traversal visits slot 0 first: put the tallest child there (a blocked ray is most likely
+    // blocked by the child that reaches highest), empty slots last
+    {
+        auto key = [&](int k) { return link[k] == HZ_EMPTY ? -INFINITY : hi[k][2]; };
+        auto cswap = [&](int x, int y) {
+            if (key(x) < key(y)) {
+                const int t = link[x]; link[x] = link[y]; link[y] = t;
+#pragma unroll
+                for (int q = 0; q < 3; q++) {
+                    float f = lo[x][q]; lo[x][q] = lo[y][q]; lo[y][q] = f;
+                    f = hi[x][q]; hi[x][q] = hi[y][q]; hi[y][q] = f;
+                }
+            }
+        };
+        cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
+    }
     const float4 nl = e.node_lo[i], nh = e.node_hi[i];
     const float org[3] = {nl.x, nl.y, nl.z};
     const float ext[3] = {nh.x - nl.x, nh.y - nl.y, nh.z - nl.z};
