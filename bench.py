@@ -214,7 +214,7 @@ def main():
                        "scene_bytes": int(blob_bytes), "scene_bcast_s": t_bcast, "scene_create_wall_s": t_build},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "hz::k_horizon<2,false,true>", "kernel_ms_per_launch": 1e3 * k_launch_s,
+                         "kernel": "hz::k_horizon<2,false,true,false>", "kernel_ms_per_launch": 1e3 * k_launch_s,
                          "alg_bytes_per_launch": b_io + b_trav, "nodes_per_ray": nodes_per_ray,
                          "tris_per_ray": tris_per_ray, "mray_per_s_kernel": rays_launch / k_launch_s / 1e6,
                          "svf_kernel_ms_per_launch": 1e3 * stats.t_svf_s / max(args.steps, 1),

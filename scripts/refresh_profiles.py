@@ -11,7 +11,7 @@ for name, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
         agg.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
     out[name] = {k: {"dispatches": len(v), "mean_KiB": sum(v) / len(v)} for k, v in agg.items() if "hz::" in k}
 json.dump(out, open("profiles/%s/pmc_fetch_write_summary.json" % rnd, "w"), indent=1)
-k = [x for x in out["FETCH_SIZE"] if "k_horizon<2, false" in x][0]
+k = [x for x in out["FETCH_SIZE"] if "k_horizon<2, false, true, false" in x][0]
 f, w = out["FETCH_SIZE"][k]["mean_KiB"], out["WRITE_SIZE"][k]["mean_KiB"]
 cal_r = out["FETCH_SIZE"]["hz::k_bounds"]["mean_KiB"] * 1024 / (12 * 3601 * 3601)
 cal_w = out["WRITE_SIZE"]["hz::k_emit_prims"]["mean_KiB"] * 1024 / (48 * 3600 * 3600)
