@@ -173,6 +173,36 @@ def test_tiny_grids(hip, orc):
         _compare(hip, orc, cases.grid_kwargs(g), dist_search=1.0, azim_num=8, elev_ang_low_lim=-89.98)
 
 
+def _dem(z, dx=30.0, dy=30.0, offset=2):
+    """grid kwargs for an explicit elevation array (planar frames)."""
+    from horayzon_amd import synth
+    n0, n1 = z.shape
+    x = (np.arange(n1) * dx).astype(np.float32)
+    y = ((n0 - 1 - np.arange(n0)) * dy).astype(np.float32)
+    xx, yy = np.meshgrid(x, y)
+    vec_norm, vec_north = synth.planar_frames(n0 - 2 * offset, n1 - 2 * offset)
+    return dict(vert_grid=synth.pack_vertices(xx, yy, z.astype(np.float32)), dem_dim_0=n0, dem_dim_1=n1,
+                vec_norm=vec_norm, vec_north=vec_north, offset_0=offset, offset_1=offset)
+
+
+def test_degenerate_terrain_shapes(hip, orc):
+    """Boxes without extent and extreme aspect ratios: a perfectly flat DEM (zero z extent in every
+    node), a terraced DEM (vertical-walled steps: many coplanar, axis-parallel faces and equal Morton
+    neighbours in z), a single raised cell, and a 3 x 400 strip."""
+    flat = np.full((40, 44), 250.0)
+    _compare(hip, orc, _dem(flat), dist_search=2.0, azim_num=16, elev_ang_low_lim=-30.0)
+    yy, xx = np.mgrid[0:48, 0:52]
+    terraces = 100.0 * ((xx // 6) % 4) + 50.0 * ((yy // 5) % 3)
+    _compare(hip, orc, _dem(terraces), dist_search=2.0, azim_num=24, elev_ang_low_lim=-80.0)
+    spike = np.zeros((33, 35)); spike[16, 17] = 500.0
+    _compare(hip, orc, _dem(spike), dist_search=2.0, azim_num=32, elev_ang_low_lim=-30.0)
+    rng = np.random.default_rng(5)
+    strip = 200.0 * rng.random((3, 400))
+    _compare(hip, orc, _dem(strip, offset=0), dist_search=20.0, azim_num=12, elev_ang_low_lim=-89.98)
+    strip_t = np.ascontiguousarray(strip.T)
+    _compare(hip, orc, _dem(strip_t, offset=0), dist_search=20.0, azim_num=12, elev_ang_low_lim=-89.98)
+
+
 def test_row_slab(hip, orc):
     """opts.row_begin/row_end: the multi-GPU sharding unit."""
     g = cases.rough_terrain(70, 66, seed=13, offset=3)

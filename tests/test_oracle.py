@@ -131,6 +131,34 @@ def test_bvh_equals_brute_force(orc):
     assert (h_brute != h_f64).mean() < 2e-3         # float32 vs exact geometry: only grazing rays
 
 
+def test_degenerate_terrain_bvh_equals_brute_force(orc):
+    """Flat, terraced (vertical walls), single-spike and strip DEMs: boxes without extent and many
+    coplanar faces must not change a decision either (same shapes as the GPU parity test)."""
+    from horayzon_amd import synth
+
+    def dem(z, offset):
+        n0, n1 = z.shape
+        x = (np.arange(n1) * 30.0).astype(np.float32)
+        y = ((n0 - 1 - np.arange(n0)) * 30.0).astype(np.float32)
+        xx, yy = np.meshgrid(x, y)
+        vn, vo = synth.planar_frames(n0 - 2 * offset, n1 - 2 * offset)
+        return dict(vert_grid=synth.pack_vertices(xx, yy, z.astype(np.float32)), dem_dim_0=n0, dem_dim_1=n1,
+                    vec_norm=vn, vec_north=vo, offset_0=offset, offset_1=offset)
+    yy, xx = np.mgrid[0:26, 0:30]
+    spike = np.zeros((21, 23)); spike[10, 11] = 500.0
+    shapes = [(np.full((20, 22), 250.0), 2), (100.0 * ((xx // 6) % 4) + 50.0 * ((yy // 5) % 3), 2), (spike, 2),
+              (200.0 * np.random.default_rng(5).random((3, 120)), 0)]
+    for z, off in shapes:
+        kw = dem(z, off)
+        a, _, sa = orc.horizon_gridded(**kw, dist_search=2.0, azim_num=16, elev_ang_low_lim=-80.0, return_stats=True)
+        b, _, sb = orc.horizon_gridded(**kw, dist_search=2.0, azim_num=16, elev_ang_low_lim=-80.0,
+                                       mode=orc.MODE_BRUTE, return_stats=True)
+        assert np.array_equal(a, b) and sa["rays"] == sb["rays"]
+    # flat plane: every horizon sits in the bracket just below 0
+    a, _ = orc.horizon_gridded(**dem(np.full((20, 22), 250.0), 2), dist_search=2.0, azim_num=16)
+    assert (a <= 0.0).all() and (a > np.deg2rad(-0.3)).all()
+
+
 def test_horizon_bvh_equals_brute_force_and_tin(orc):
     g = cases.rough_terrain(34, 38, seed=15, offset=3, relief=500.0)
     kw = cases.grid_kwargs(g)
