@@ -361,7 +361,15 @@ orc_scene *orc_scene_create(const float *vert_grid, int d0, int d1,
             lo[k] = fminf(lo[k], s->vs[3 * v + k]); hi[k] = fmaxf(hi[k], s->vs[3 * v + k]);
         }
     const float ex = hi[0] - lo[0], ey = hi[1] - lo[1], ez = hi[2] - lo[2];
-    s->pad = 1.0e-6f * sqrtf(ex * ex + ey * ey + ez * ez);
+    /* the padding has to survive being added to a coordinate (boxes are kept in the caller's
+       frame here): 1e-6 of the diagonal alone is below half an ulp at Swiss-grid offsets and
+       left the boxes unpadded, so the tree culled triangles the float test accepts (found by
+       tests/test_gpu_fuzz.py: BVH != brute force on a 4 x 45 strip at x = 2.6e6).  Same rule
+       as the GPU build (hz_scene.hip): + 4 ulp of the largest coordinate. */
+    float maxabs = 0.0f;
+    for (int k = 0; k < 3; k++) maxabs = fmaxf(maxabs, fmaxf(fabsf(lo[k]), fabsf(hi[k])));
+    s->pad = (float)(1.0e-6 * sqrt((double)ex * ex + (double)ey * ey + (double)ez * ez)
+                     + 4.0 * (double)FLT_EPSILON * (double)maxabs) + FLT_MIN;
     /* grid BVH */
     if (d0 >= 2 && d1 >= 2) {
         const size_t nq = (size_t)(d0 - 1) * (size_t)(d1 - 1);

@@ -67,3 +67,37 @@ def terrain_inputs(g):
     elevation = np.ascontiguousarray(g["z"][o:o + in0, o:o + in1], np.float32)
     mask = np.ones((in0, in1), np.uint8)
     return vec_tilt, vec_norm, surf_enl_fac, elevation, mask
+
+
+ALGS = ("guess_constant", "binary_search", "discrete_sampling")
+
+
+def random_config(rng, max_n=90):
+    """One random horizon_gridded configuration (grid kwargs, parameters): sizes, spacings, relief,
+    coordinate offsets, frames, algorithm, table resolution, masks and an outer TIN all vary."""
+    n0, n1 = int(rng.integers(2, max_n)), int(rng.integers(2, max_n))
+    off = int(rng.integers(0, max(1, min(n0, n1) // 3)))
+    if n0 - 2 * off < 1 or n1 - 2 * off < 1:
+        off = 0
+    dx, dy = float(rng.choice([1.0, 10.0, 30.0, 90.0, 500.0])), float(rng.choice([1.0, 10.0, 30.0, 90.0, 500.0]))
+    relief = float(rng.choice([0.0, 5.0, 300.0, 3000.0])) * (dx / 30.0) ** 0.5
+    origin = (float(rng.choice([0.0, 2.6e6, -4.0e5])), float(rng.choice([0.0, 1.2e6])))
+    g = rough_terrain(n0, n1, seed=int(rng.integers(1 << 30)), dx=dx, dy=dy, relief=relief, offset=off,
+                            tilt_frames=bool(rng.integers(2)), origin=origin)
+    kw = grid_kwargs(g)
+    span = max(n0 * dy, n1 * dx) / 1000.0
+    par = dict(dist_search=float(rng.choice([0.3, 1.0, 3.0])) * span,
+               azim_num=int(rng.choice([1, 3, 8, 12, 30, 45])),
+               hori_acc=float(rng.choice([0.1, 0.25, 1.0, 3.0])),
+               ray_algorithm=str(rng.choice(ALGS)),
+               geom_type=str(rng.choice(["triangle", "quad", "grid"])),
+               elev_ang_low_lim=float(rng.choice([-15.0, -45.0, -89.98])),
+               ray_org_elev=float(rng.choice([0.005, 0.01, 0.5, 20.0])),
+               hori_fill=float(rng.choice([0.0, -1.0])))
+    in0, in1 = kw["vec_norm"].shape[:2]
+    if rng.integers(3) == 0:
+        par["mask"] = (rng.random((in0, in1)) < 0.6).astype(np.uint8)
+    if rng.integers(4) == 0 and n0 > 3 and n1 > 3:
+        vs, nvs, ts, nts = outer_tin(g, margin=3.0 * span * 100.0, zval=100.0 + relief)
+        par.update(vert_simp=vs, num_vert_simp=nvs, tri_ind_simp=ts, num_tri_simp=nts)
+    return kw, par

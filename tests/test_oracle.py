@@ -159,6 +159,22 @@ def test_degenerate_terrain_bvh_equals_brute_force(orc):
     assert (a <= 0.0).all() and (a > np.deg2rad(-0.3)).all()
 
 
+def test_random_configurations_bvh_equals_brute_force(orc):
+    """The generator of tests/test_gpu_fuzz.py on the CPU side: the oracle's tree never changes a
+    decision, whatever the spacing, relief or coordinate offset (HZ_FUZZ_N / HZ_FUZZ_SEED widen it)."""
+    import os
+    n = int(os.environ.get("HZ_FUZZ_N", "12"))
+    rng = np.random.default_rng(int(os.environ.get("HZ_FUZZ_SEED", "777")))
+    for it in range(n):
+        kw, par = cases.random_config(rng, max_n=34)
+        a, _, sa = orc.horizon_gridded(**kw, **par, return_stats=True)
+        b, _, sb = orc.horizon_gridded(**kw, **par, mode=orc.MODE_BRUTE, return_stats=True)
+        desc = "config %d: dem %dx%d %s" % (it, kw["dem_dim_0"], kw["dem_dim_1"],
+                                           {k: v for k, v in par.items() if np.isscalar(v)})
+        assert np.array_equal(a, b), desc
+        assert sa["rays"] == sb["rays"] and sa["guards"] == sb["guards"], desc
+
+
 def test_horizon_bvh_equals_brute_force_and_tin(orc):
     g = cases.rough_terrain(34, 38, seed=15, offset=3, relief=500.0)
     kw = cases.grid_kwargs(g)
