@@ -23,3 +23,73 @@ def test_random_configurations(hip, orc):
         assert np.array_equal(a_gpu, a_cpu), desc
         assert np.array_equal(h_gpu, h_cpu), desc
         assert st["num_rays"] == so["rays"] and st["guard_events"] == so["guards"], desc
+
+
+def test_random_locations(hip, orc):
+    """horizon_locations (+ distance) on random terrains, locations, frames and parameters."""
+    n = int(os.environ.get("HZ_FUZZ_N", "24")) // 2
+    rng = np.random.default_rng(int(os.environ.get("HZ_FUZZ_SEED", "20260928")) + 1)
+    for it in range(n):
+        n0, n1 = int(rng.integers(3, 70)), int(rng.integers(3, 70))
+        dx = float(rng.choice([5.0, 30.0, 200.0]))
+        relief = float(rng.choice([0.0, 50.0, 900.0])) * (dx / 30.0) ** 0.5
+        origin = (float(rng.choice([0.0, 2.6e6])), float(rng.choice([0.0, 1.2e6])))
+        g = cases.rough_terrain(n0, n1, seed=int(rng.integers(1 << 30)), dx=dx, dy=dx, relief=relief, offset=0,
+                                origin=origin)
+        m = int(rng.integers(1, 40))
+        ci, cj = rng.integers(0, n0, m), rng.integers(0, n1, m)
+        coords = np.stack([g["x"][cj] + rng.uniform(-0.6, 0.6, m) * dx, g["y"][ci] + rng.uniform(-0.6, 0.6, m) * dx,
+                           g["z"][ci, cj] + rng.uniform(-0.3, 0.6, m) * (relief + 10.0)], axis=1).astype(np.float32)
+        a, b = rng.uniform(-0.05, 0.05, m), rng.uniform(-0.05, 0.05, m)
+        nrm = np.stack([np.sin(b), -np.sin(a) * np.cos(b), np.cos(a) * np.cos(b)], axis=1)
+        north = np.array([0.0, 1.0, 0.0])[None, :] - nrm[:, 1:2] * nrm
+        north /= np.linalg.norm(north, axis=1, keepdims=True)
+        vn, vo = nrm.astype(np.float32), north.astype(np.float32)
+        dist = bool(rng.integers(2))
+        par = dict(azim_num=int(rng.choice([1, 5, 16, 36])), hori_acc=float(rng.choice([0.1, 0.25, 2.0])),
+                   ray_algorithm=str(rng.choice(["binary_search", "discrete_sampling"] if dist else cases.ALGS)),
+                   elev_ang_low_lim=float(rng.choice([-30.0, -89.98])),
+                   ray_org_elev=rng.uniform(0.01, 3.0, m).astype(np.float32), hori_dist_out=dist)
+        ds = float(rng.choice([0.5, 2.0])) * max(n0, n1) * dx / 1000.0
+        out_g = hip.horizon.horizon_locations(g["vert_grid"], n0, n1, coords, vn, vo, ds, **par)
+        st = hip.horizon.last_stats
+        out_c = orc.horizon_locations(g["vert_grid"], n0, n1, coords, vn, vo, ds, **par, return_stats=True)
+        desc = "config %d: dem %dx%d dx %g relief %g %s" % (it, n0, n1, dx, relief,
+                                                            {k: v for k, v in par.items() if np.isscalar(v)})
+        for x, y in zip(out_g, out_c[:len(out_g)]):
+            assert np.array_equal(x, y, equal_nan=True), desc
+        assert st["num_rays"] == out_c[-1]["rays"] and st["num_cells"] == out_c[-1]["found"], desc
+
+
+def test_random_terrain_shadow(hip, orc):
+    """Terrain.shadow / sw_dir_cor (no refraction: bit-identical) for random terrains, masks, sun positions."""
+    from horayzon_amd import synth
+    n = int(os.environ.get("HZ_FUZZ_N", "24")) // 3
+    rng = np.random.default_rng(int(os.environ.get("HZ_FUZZ_SEED", "20260928")) + 2)
+    for it in range(n):
+        n0, n1 = int(rng.integers(5, 80)), int(rng.integers(5, 80))
+        off = int(rng.integers(0, 2))
+        dx = float(rng.choice([10.0, 30.0, 100.0]))
+        g = cases.rough_terrain(n0, n1, seed=int(rng.integers(1 << 30)), dx=dx, dy=dx,
+                                relief=float(rng.choice([20.0, 600.0, 2500.0])), offset=off,
+                                origin=(float(rng.choice([0.0, 7.0e5])), 0.0))
+        vec_tilt, vec_norm, enl, elev, mask = cases.terrain_inputs(g)
+        mask[rng.random(mask.shape) < 0.2] = 0
+        tg, tc = hip.shadow.Terrain(), orc.Terrain()
+        ang_max = float(rng.choice([85.0, 89.0, 89.99]))
+        for t in (tg, tc):
+            t.initialise(g["vert_grid"], n0, n1, off, off, vec_tilt, vec_norm, enl, elev, mask,
+                         sw_dir_cor_fill=-3.0, ang_max=ang_max)
+        for _ in range(6):
+            alt, az = np.deg2rad(rng.uniform(-3.0, 60.0)), rng.uniform(0, 2 * np.pi)
+            r = float(rng.choice([1.0e5, 1.0e7, 1.496e11]))
+            sun = (np.array([g["x"].mean(), g["y"].mean(), 0.0]) +
+                   r * np.array([np.cos(alt) * np.sin(az), np.cos(alt) * np.cos(az), np.sin(alt)])).astype(np.float32)
+            sg = np.full(mask.shape, 255, np.uint8); sc = sg.copy()
+            tg.shadow(sun, sg); tc.shadow(sun, sc)
+            desc = "config %d: dem %dx%d dx %g alt %.2f az %.2f r %g" % (it, n0, n1, dx, np.rad2deg(alt), np.rad2deg(az), r)
+            assert np.array_equal(sg, sc), desc
+            assert tg.last_stats["num_rays"] == tc.rays, desc
+            fg = np.full(mask.shape, np.nan, np.float32); fc = fg.copy()
+            tg.sw_dir_cor(sun, fg); tc.sw_dir_cor(sun, fc)
+            assert np.array_equal(fg, fc), desc
