@@ -40,7 +40,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=7)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--rows-per-step", type=int, default=512)
     ap.add_argument("--tile", type=int, default=3601)
@@ -113,7 +113,9 @@ def main():
     stats = _lib.hz_stats()
 
     def step(s, count=False):
-        slab = (s * world + rank) % n_slabs
+        # weak scaling: rank r walks the slabs of the tile starting at slab r, so with the default 6 steps
+        # every rank computes each of the 6 slabs exactly once (identical work per GPU for any N)
+        slab = (s + rank) % n_slabs
         rb = slab * rps
         opts.row_begin, opts.row_end = rb, rb + rps
         opts.count_work = int(count)
@@ -153,7 +155,7 @@ def main():
         step(args.warmup + s)
     svf_full = None
     if use_dist:    # final gather of the per-rank SVF rows touched in the last step (4 B / cell)
-        rb = ((args.warmup + args.steps - 1) * world + rank) % n_slabs * rps
+        rb = (args.warmup + args.steps - 1 + rank) % n_slabs * rps
         gather_rows(d_svf[rb:rb + rps], [(0, rps)] * world, dst=0)
     barrier()
     elapsed = time.perf_counter() - t0
