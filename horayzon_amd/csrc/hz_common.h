@@ -350,7 +350,9 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
     const int lane = tid & 63;
     int node = t.node, sp = t.sp, lq0 = t.lq0, lq1 = t.lq1, lq2 = t.lq2, lq3 = t.lq3;
     const int n_entry = __popcll(__ballot(1));   // lanes that entered with a ray
-#define HZ_POP() do { if (sp > 0) { sp--; node = stack[sp * TPB + tid]; } else node = HZ_EMPTY; } while (0)
+// branch-free pop: read the (clamped) top entry, keep it only if the stack was not empty
+#define HZ_POP() do { const bool ne = sp > 0; sp = ne ? sp - 1 : 0; const int pv = stack[sp * TPB + tid]; \
+                      node = ne ? pv : HZ_EMPTY; } while (0)
 #define HZ_SAVE() do { t.node = node; t.sp = sp; t.lq0 = lq0; t.lq1 = lq1; t.lq2 = lq2; t.lq3 = lq3; } while (0)
     for (;;) {
         // set leaves aside while the leaf queue (QLEN entries, filled front to back) has room
@@ -387,10 +389,12 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
                 // is blocked over a long stretch behind the first ridge, and near-horizon rays that only
                 // nick a crest are served by the hit cache.
                 int next = HZ_EMPTY;
+                // branch-free pushes: the candidate is always stored at the stack top and only kept
+                // (sp advanced) when it was a real link; a node at level L writes at most index 3 L - 1
                 if (h3) next = n3.w;
-                if (h2) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = n3.z; }
-                if (h1) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = n3.y; }
-                if (h0) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = n3.x; }
+                if (h2) { stack[sp * TPB + tid] = next; sp += (next != HZ_EMPTY) ? 1 : 0; next = n3.z; }
+                if (h1) { stack[sp * TPB + tid] = next; sp += (next != HZ_EMPTY) ? 1 : 0; next = n3.y; }
+                if (h0) { stack[sp * TPB + tid] = next; sp += (next != HZ_EMPTY) ? 1 : 0; next = n3.x; }
                 if (next != HZ_EMPTY) node = next; else HZ_POP();
             }
         } else {
