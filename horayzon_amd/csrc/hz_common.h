@@ -354,7 +354,8 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
 #define HZ_POP() do { const bool ne = sp > 0; sp = ne ? sp - 1 : 0; const int pv = stack[sp * TPB + tid]; \
                       node = ne ? pv : HZ_EMPTY; } while (0)
 #define HZ_SAVE() do { t.node = node; t.sp = sp; t.lq0 = lq0; t.lq1 = lq1; t.lq2 = lq2; t.lq3 = lq3; } while (0)
-    for (;;) {
+    int res = -1;                 // single exit: lanes leave the loop through `res`, state is saved once
+    while (res < 0) {
         // set leaves aside while the leaf queue (QLEN entries, filled front to back) has room
         if (node < 0 && node != HZ_EMPTY && lq0 == HZ_EMPTY) { lq0 = node; HZ_POP(); }
         if (node < 0 && node != HZ_EMPTY && lq1 == HZ_EMPTY) { lq1 = node; HZ_POP(); }
@@ -362,11 +363,11 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
         if (QLEN > 3 && node < 0 && node != HZ_EMPTY && lq3 == HZ_EMPTY) { lq3 = node; HZ_POP(); }
         const bool can_node = node >= 0;
         const bool can_leaf = lq0 != HZ_EMPTY;
-        if (!can_node && !can_leaf) { HZ_SAVE(); return 0; }                  // nothing left: miss
+        if (!can_node && !can_leaf) { res = 0; continue; }                    // nothing left: miss
         const int n_all = __popcll(__ballot(1));
         // ray compaction: suspend only if some lane finished its ray in this call (it can refill,
         // so the caller always makes progress)
-        if (n_all < regroup && n_all < n_entry) { HZ_SAVE(); return 2; }
+        if (n_all < regroup && n_all < n_entry) { res = 2; continue; }
         const int n_node = __popcll(__ballot(can_node));
         const int n_leaf = __popcll(__ballot(can_leaf));
         if (n_node * 16 >= n_leaf * leaf_bias) {
@@ -406,11 +407,13 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
                 if (COUNT) { cnt.tris += (q2.y == q2.y) ? 2 : 1; HZ_WAVE_TICK(cnt.w_leaves, lane); }
                 const bool hit = hz_quad_hit(ox, oy, oz, dx, dy, dz, tfar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
                                              q2.x, q2.y, q2.z, q2.w, q2.y == q2.y);
-                if (hit) { HZ_SAVE(); return 1; }
-                lq0 = lq1; lq1 = lq2; lq2 = lq3; lq3 = HZ_EMPTY;
+                if (hit) res = 1;                       // lq0 stays: the caller reads the blocking leaf
+                else { lq0 = lq1; lq1 = lq2; lq2 = lq3; lq3 = HZ_EMPTY; }
             }
         }
     }
+    HZ_SAVE();
+    return res;
 #undef HZ_POP
 #undef HZ_SAVE
 }
