@@ -363,13 +363,16 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
         if (QLEN > 3 && node < 0 && node != HZ_EMPTY && lq3 == HZ_EMPTY) { lq3 = node; HZ_POP(); }
         const bool can_node = node >= 0;
         const bool can_leaf = lq0 != HZ_EMPTY;
+        // votes taken before any lane leaves: a lane that is finished contributes to neither mask, so the
+        // masks equal those of the lanes that stay (and stay plain scalar compares)
+        const unsigned long long m_node = __ballot(can_node), m_leaf = __ballot(can_leaf);
+        const int n_all = __popcll(m_node | m_leaf);
         if (!can_node && !can_leaf) { res = 0; continue; }                    // nothing left: miss
-        const int n_all = __popcll(__ballot(1));
         // ray compaction: suspend only if some lane finished its ray in this call (it can refill,
         // so the caller always makes progress)
         if (n_all < regroup && n_all < n_entry) { res = 2; continue; }
-        const int n_node = __popcll(__ballot(can_node));
-        const int n_leaf = __popcll(__ballot(can_leaf));
+        const int n_node = __popcll(m_node);
+        const int n_leaf = __popcll(m_leaf);
         if (n_node * 16 >= n_leaf * leaf_bias) {
             // ---------------- node step ------------------------------------------------------
             if (can_node) {
