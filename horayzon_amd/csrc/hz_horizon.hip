@@ -28,6 +28,9 @@
 namespace hz {
 
 #define HZ_TPB 256
+#ifndef HZ_QLEN
+#define HZ_QLEN 2       // leaves a lane sets aside before it needs a leaf step (3 and 4 measured slower)
+#endif
 
 struct HorizonParams {
     SceneView sv;
@@ -134,7 +137,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
         }
         // ---- traversal (hz_common.h: speculative while-while, one postponed leaf per lane) ------
         if (ray_active) {
-            const int r = hz_trace<HZ_TPB, COUNT, 2, NODELET>(p.sv.nodes, p.sv.prims, top, ntop, stack, tid, ox, oy, oz,
+            const int r = hz_trace<HZ_TPB, COUNT, HZ_QLEN, NODELET>(p.sv.nodes, p.sv.prims, top, ntop, stack, tid, ox, oy, oz,
                                                  dx, dy, dz, tfar, rb, ts, p.regroup, p.leaf_bias, tc);
             if (r == 0 && second) {                      // nothing in the cached subtree: full traversal
                 second = false; hz_trav_reset(ts);

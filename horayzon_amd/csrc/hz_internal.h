@@ -11,7 +11,9 @@
 #define HZ_MAX_TOP_NODES 2047   // upper bound of BFS-ordered top nodes (LDS staging)
 #define HZ_MAX_STACK 96         // LDS stack entries per lane the traversal kernels accept (3 per 4-wide level)
 // hit cache: levels between a leaf and its cached ancestor (measured 1..9 on the 3601^2 tile: 5-6 best)
+#ifndef HZ_ANC_LEVELS
 #define HZ_ANC_LEVELS 5
+#endif
 
 namespace hz {
 
