@@ -10,7 +10,7 @@
 //            Morton key (= a quadtree over the (x, y) centroids).  One node is
 //            64 B and holds the conservatively quantised AABBs (8 bit x/y,
 //            16 bit z, relative to the node's own box) and the links of up to 4
-//            children, stored in Morton-digit order (slot = 2*ybit + xbit).
+//            children (the four Morton quadrants), stored tallest (largest z-max) first.
 //            The first `n_top` nodes are the top of the tree in breadth-first
 //            order (staged in LDS by the kernels).  AABBs live in a frame
 //            centred on the scene (`center`) and are padded by `pad`, which
