@@ -207,6 +207,8 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     const bool skip_hori = opts && opts->skip_hori;
     if (!hori_buffer && !skip_hori) return set_error(HZ_ERR_ARG, "hori_buffer is NULL");
     if (opts && opts->svf && !opts->vec_tilt) return set_error(HZ_ERR_ARG, "opts.svf needs opts.vec_tilt");
+    // the SVF weights sectors by azim[1] - azim[0] (topo_param.pyx:433): undefined for a single azimuth
+    if (opts && opts->svf && azim_num < 2) return set_error(HZ_ERR_ARG, "opts.svf needs azim_num >= 2");
     int row_begin = 0, row_end = dim_in_0;
     if (opts) {
         if (opts->row_begin > 0) row_begin = opts->row_begin;

@@ -134,6 +134,8 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
     svf = None
     if svf_vec_tilt is not None:
         _check_f32(svf_vec_tilt, 3, "svf_vec_tilt")
+        if azim_num < 2:      # the azimuth spacing azim[1] - azim[0] does not exist (topo_param.pyx:433)
+            raise ValueError("sky view factor needs azim_num >= 2")
         if svf_vec_tilt.shape != vec_norm.shape:
             raise ValueError("Inconsistent/incorrect shapes of input arrays")
         svf_vec_tilt = np.ascontiguousarray(svf_vec_tilt)

@@ -279,6 +279,8 @@ def sky_view_factor(azim, hori, vec_tilt):
     if ((azim.dtype != "float32") or (hori.dtype != "float32")
             or (vec_tilt.dtype != "float32")):
         raise ValueError("Input array(s) has/have incorrect data type(s)")
+    if len(azim) < 2:    # azim[1] - azim[0] is read (topo_param.pyx:433): out of bounds in the reference
+        raise ValueError("Inconsistent/incorrect shapes of input arrays")
     azim = np.ascontiguousarray(azim)
     hori = np.ascontiguousarray(hori)
     vec_tilt = np.ascontiguousarray(vec_tilt)

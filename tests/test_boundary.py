@@ -217,6 +217,8 @@ def test_svf_validation_errors():
         f(azim[:3], hori, tilt)
     with pytest.raises(ValueError, match="data type"):
         f(azim, hori.astype(np.float64), tilt)
+    with pytest.raises(ValueError, match="shapes"):      # one azimuth: the reference reads azim[1] out of bounds
+        f(azim[:1], hori[:, :, :1], tilt)
 
 
 def test_prep_host_side_matches_reference_fixture():

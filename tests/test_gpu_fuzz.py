@@ -15,14 +15,33 @@ def test_random_configurations(hip, orc):
     rng = np.random.default_rng(int(os.environ.get("HZ_FUZZ_SEED", "20260928")))
     for it in range(n):
         kw, par = cases.random_config(rng)
-        h_gpu, a_gpu = hip.horizon.horizon_gridded(**kw, **par)
+        in0, in1 = kw["vec_norm"].shape[:2]
+        extra = {}
+        if rng.integers(3) == 0 and in0 > 2:                 # a row slab (the multi-GPU sharding unit)
+            r0 = int(rng.integers(0, in0 - 1))
+            extra["rows"] = (r0, int(rng.integers(r0 + 1, in0 + 1)))
+        if rng.integers(3) == 0:                             # streamed host output in small chunks
+            extra["_chunk_rows"] = int(rng.integers(1, 9))
+        tilt = None
+        if rng.integers(3) == 0 and par["azim_num"] >= 2:   # fused sky view factor
+            a, b = rng.uniform(-0.4, 0.4, (in0, in1)), rng.uniform(-0.4, 0.4, (in0, in1))
+            tilt = np.stack([np.sin(b), -np.sin(a) * np.cos(b), np.cos(a) * np.cos(b)], axis=2).astype(np.float32)
+            extra["svf_vec_tilt"] = tilt
+        out = hip.horizon.horizon_gridded(**kw, **par, **extra)
+        h_gpu, a_gpu = out[0], out[1]
         st = hip.horizon.last_stats
-        h_cpu, a_cpu, so = orc.horizon_gridded(**kw, **par, return_stats=True)
-        desc = "config %d: dem %dx%d %s" % (it, kw["dem_dim_0"], kw["dem_dim_1"],
-                                           {k: v for k, v in par.items() if np.isscalar(v)})
+        ro = {"rows": extra["rows"]} if "rows" in extra else {}
+        h_cpu, a_cpu, so = orc.horizon_gridded(**kw, **par, **ro, return_stats=True)
+        desc = "config %d: dem %dx%d %s %s" % (it, kw["dem_dim_0"], kw["dem_dim_1"],
+                                              {k: v for k, v in par.items() if np.isscalar(v)},
+                                              {k: v for k, v in extra.items() if k != "svf_vec_tilt"})
         assert np.array_equal(a_gpu, a_cpu), desc
-        assert np.array_equal(h_gpu, h_cpu), desc
+        assert np.array_equal(h_gpu, h_cpu, equal_nan=True), desc
         assert st["num_rays"] == so["rays"] and st["guard_events"] == so["guards"], desc
+        if tilt is not None:
+            r0, r1 = extra.get("rows", (0, in0))
+            svf_cpu = orc.sky_view_factor(a_cpu, h_cpu[r0:r1], tilt[r0:r1])
+            assert np.abs(out[2][r0:r1] - svf_cpu).max() <= 1.0e-5, desc
 
 
 def test_random_locations(hip, orc):
