@@ -34,7 +34,7 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
                     tri_ind_simp=np.array([0, 0, 0, 0], dtype=np.int32),
                     num_tri_simp=1, elev_ang_low_lim=-15.0, mask=None,
                     hori_fill=0.0, ray_org_elev=0.01, *, device=0, verbose=False,
-                    scene=None, svf_vec_tilt=None, rows=None, count_work=False,
+                    scene=None, svf_vec_tilt=None, rows=None, count_work=False, devices=None,
                     _top_nodes=-1, _regroup=-1, _hit_cache=True, _chunk_rows=0):
     """Horizon computation for gridded domain.
 
@@ -47,7 +47,12 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
     prebuilt ``Scene`` to skip the BVH build), ``svf_vec_tilt`` (tilted normals;
     when given the sky view factor is accumulated in the same kernel and
     returned as a third value), ``rows`` ((begin, end) slab of inner-domain rows
-    to compute; the rest of ``hori_buffer`` stays NaN), ``count_work``.
+    to compute; the rest of ``hori_buffer`` stays NaN), ``count_work``, ``devices``
+    ("all" or a sequence of HIP ordinals: the inner-domain rows are split into one slab per
+    entry, balanced by ``mask``, and each slab is computed by its own host thread on its own
+    GPU -- the scene is built per device, nothing is exchanged, every thread copies its rows
+    straight into the returned array; the multi-process form of the same sharding is
+    ``horayzon_amd.dist``).
     """
     global last_stats
     _check_f32(vert_grid, 1, "vert_grid")
@@ -144,21 +149,65 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
         opts.vec_tilt = ptr(svf_vec_tilt)
     stats = hz_stats()
     L = _lib.lib()
-    if scene is None:
-        rc = L.hz_horizon_gridded(
-            ptr(vert_grid), dem_dim_0, dem_dim_1, ptr(vec_norm), ptr(vec_north),
-            offset_0, offset_1, ptr(hori_buffer), dim_in_0, dim_in_1, azim_num,
-            dist_search, hori_acc, ray_algorithm.encode("utf-8"),
-            geom_type.encode("utf-8"), ptr(vert_simp), num_vert_simp,
-            ptr(tri_ind_simp), num_tri_simp, elev_ang_low_lim, ptr(mask),
-            hori_fill, ray_org_elev, C.byref(opts), C.byref(stats))
-    else:
-        opts.device = scene.device
-        rc = L.hz_horizon_gridded_scene(
+
+    def run(o, st):
+        if scene is None:
+            return L.hz_horizon_gridded(
+                ptr(vert_grid), dem_dim_0, dem_dim_1, ptr(vec_norm), ptr(vec_north),
+                offset_0, offset_1, ptr(hori_buffer), dim_in_0, dim_in_1, azim_num,
+                dist_search, hori_acc, ray_algorithm.encode("utf-8"),
+                geom_type.encode("utf-8"), ptr(vert_simp), num_vert_simp,
+                ptr(tri_ind_simp), num_tri_simp, elev_ang_low_lim, ptr(mask),
+                hori_fill, ray_org_elev, C.byref(o), C.byref(st))
+        o.device = scene.device
+        return L.hz_horizon_gridded_scene(
             scene._h, ptr(vec_norm), ptr(vec_north), offset_0, offset_1,
             ptr(hori_buffer), dim_in_0, dim_in_1, azim_num, dist_search, hori_acc,
             ray_algorithm.encode("utf-8"), elev_ang_low_lim, ptr(mask), hori_fill,
-            ray_org_elev, C.byref(opts), C.byref(stats))
+            ray_org_elev, C.byref(o), C.byref(st))
+
+    if devices is None:
+        rc = run(opts, stats)
+    else:
+        # one host thread per GPU, one row slab each (ctypes releases the GIL during the call;
+        # the library keeps its error string and build arenas per thread)
+        import threading
+        from .dist import row_slabs
+        if scene is not None or rows is not None:
+            raise ValueError("'devices' cannot be combined with 'scene' or 'rows'")
+        devs = list(range(_lib.device_count())) if isinstance(devices, str) and devices == "all" \
+            else [int(d) for d in devices]
+        if not devs:
+            raise ValueError("'devices' is empty")
+        slabs = [sl for sl in row_slabs(mask, len(devs))]
+        part, errs = [None] * len(devs), []
+
+        def work(idx):
+            b, e = slabs[idx]
+            if e <= b:
+                return
+            o = hz_opts.from_buffer_copy(opts)
+            o.device, o.row_begin, o.row_end = devs[idx], b, e
+            st = hz_stats()
+            try:
+                _lib.check(run(o, st))
+                part[idx] = st
+            except Exception as exc:      # re-raised in the calling thread
+                errs.append(exc)
+        threads = [threading.Thread(target=work, args=(i,)) for i in range(len(devs))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errs:
+            raise errs[0]
+        for st in part:                    # counts add up, times are the slowest device's
+            if st is None:
+                continue
+            for name, _ in hz_stats._fields_:
+                a, b = getattr(stats, name), getattr(st, name)
+                setattr(stats, name, max(a, b) if name.startswith("t_") or name in ("bvh_height", "elev_num", "scene_bytes") else a + b)
+        rc = 0
     _lib.check(rc)
     last_stats = stats.as_dict()
 

@@ -5,11 +5,12 @@ import numpy as np
 import horayzon_amd as hz
 from horayzon_amd import synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3601
+devices = [int(d) for d in sys.argv[2].split(",")] if len(sys.argv) > 2 else None   # e.g. 0,1,2,3
 g = synth.fractal_tile(n=n, offset=16)
 kw = {k: g[k] for k in ("vert_grid", "dem_dim_0", "dem_dim_1", "vec_norm", "vec_north", "offset_0", "offset_1")}
 for rep in range(2):
     t = time.time()
-    hori, azim = hz.horizon.horizon_gridded(**kw, dist_search=50.0, azim_num=360)
+    hori, azim = hz.horizon.horizon_gridded(**kw, dist_search=50.0, azim_num=360, devices=devices)
     wall = time.time() - t
     st = hz.horizon.last_stats
     print(json.dumps({"wall_s": wall, "t_bvh_s": st["t_bvh_s"], "t_h2d_s": st["t_h2d_s"], "t_kernel_s": st["t_kernel_s"],

@@ -235,6 +235,29 @@ def test_streamed_host_output(hip, chunk):
     assert np.array_equal(h2, full) and np.array_equal(svf, svf1)
 
 
+def test_devices_threads_match_single_call(hip):
+    """devices=[...]: one host thread and one row slab per entry (here the same GPU three times, which
+    exercises the slab split, the concurrent calls and the merged statistics)."""
+    g = cases.rough_terrain(90, 70, seed=21, offset=4, tilt_frames=True)
+    kw = cases.grid_kwargs(g)
+    in0, in1 = kw["vec_norm"].shape[:2]
+    mask = (np.random.default_rng(3).random((in0, in1)) < 0.8).astype(np.uint8)
+    mask[:7] = 0                                      # an empty leading slab is possible
+    tilt = np.zeros((in0, in1, 3), np.float32); tilt[..., 2] = 1.0
+    par = dict(dist_search=2.0, azim_num=24, elev_ang_low_lim=-60.0, mask=mask, hori_fill=-0.5, svf_vec_tilt=tilt)
+    h1, a1, s1 = hip.horizon.horizon_gridded(**kw, **par)
+    st1 = dict(hip.horizon.last_stats)
+    for devs in ([0], [0, 0, 0], [0] * 7):
+        h2, a2, s2 = hip.horizon.horizon_gridded(**kw, **par, devices=devs)
+        st2 = dict(hip.horizon.last_stats)
+        assert np.array_equal(h1, h2) and np.array_equal(a1, a2) and np.array_equal(s1, s2, equal_nan=True)
+        assert st1["num_rays"] == st2["num_rays"] and st1["num_cells"] == st2["num_cells"]
+    with pytest.raises(ValueError, match="devices"):
+        hip.horizon.horizon_gridded(**kw, **par, devices=[0, 0], rows=(0, 5))
+    with pytest.raises(hip.HorayzonHipError):
+        hip.horizon.horizon_gridded(**kw, **par, devices=[0, 99])
+
+
 def test_persistent_scene_and_blob_adopt(hip, orc):
     """A scene blob copied byte for byte (what an RCCL broadcast does) gives identical results."""
     import ctypes as C
