@@ -84,3 +84,24 @@ def test_c3_shadow_matches_horizon(hip, orc, tile):
     assert clear.mean() > 0.9
     assert np.array_equal(sh[clear] == 2, h[:, :, k][clear] > sun_el)
     assert 0.02 < (sh == 2).mean() < 0.98
+
+
+@pytest.mark.skipif("HZ_FULLSIZE_BANDS" not in __import__("os").environ,
+                    reason="wide full-size sweep: set HZ_FULLSIZE_BANDS=0:32,1760:1792,... (needs many host cores)")
+def test_c3_row_bands_bit_identical(hip, orc, tile):
+    """Bands of rows of the full C3 configuration (tile edges included) against the oracle, bit for bit."""
+    import os
+    kw = cases.grid_kwargs(tile)
+    sc = hip.Scene.create(kw["vert_grid"], 3601, 3601)
+    total = 0
+    for band in os.environ["HZ_FULLSIZE_BANDS"].split(","):
+        rows = tuple(int(v) for v in band.split(":"))
+        got, _ = hip.horizon.horizon_gridded(**kw, dist_search=50.0, azim_num=360, scene=sc, rows=rows)
+        st = dict(hip.horizon.last_stats)
+        ref, _, so = orc.horizon_gridded(**kw, dist_search=50.0, azim_num=360, rows=rows, slab_only=True,
+                                         return_stats=True)
+        assert np.array_equal(got[rows[0]:rows[1]], ref), band
+        assert st["num_rays"] == so["rays"] and st["guard_events"] == so["guards"], band
+        total += (rows[1] - rows[0]) * ref.shape[1]
+        del got, ref
+    print("bit-identical cells: %d" % total)
