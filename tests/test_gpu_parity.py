@@ -391,3 +391,40 @@ def test_shadow_batch_matches_single(hip):
         b = np.empty(mask.shape, np.float32); t.sw_dir_cor(suns[s], b)
         assert np.array_equal(a, sb[s])
         assert np.array_equal(b, fb[s], equal_nan=True)
+
+
+def test_no_device_memory_leak(hip):
+    """Repeated calls through every handle type leave the free HBM where it was."""
+    import gc
+    import torch
+    from horayzon_amd import synth
+    g = cases.rough_terrain(120, 130, seed=9, offset=6, relief=900.0)
+    kw = cases.grid_kwargs(g)
+    vec_tilt, vec_norm, enl, elev, mask = cases.terrain_inputs(g)
+    suns, _, _ = synth.sun_positions(num=4)
+    coords = np.stack([g["x"][10:40], g["y"][10:40], g["z"][10:40, 10:40].diagonal() + 5.0], axis=1).astype(np.float32)
+    vn = np.zeros((30, 3), np.float32); vn[:, 2] = 1.0
+    vo = np.zeros((30, 3), np.float32); vo[:, 1] = 1.0
+
+    def cycle():
+        hip.horizon.horizon_gridded(**kw, dist_search=3.0, azim_num=24, svf_vec_tilt=vec_tilt, _chunk_rows=17)
+        sc = hip.Scene.create(kw["vert_grid"], 120, 130)
+        hip.horizon.horizon_gridded(**kw, dist_search=3.0, azim_num=24, scene=sc, rows=(3, 50))
+        hip.horizon.horizon_locations(g["vert_grid"], 120, 130, coords, vn, vo, 3.0, azim_num=12, scene=sc)
+        sc.close()
+        t = hip.shadow.Terrain()
+        t.initialise(g["vert_grid"], 120, 130, 6, 6, vec_tilt, vec_norm, enl, elev, mask)
+        out = np.empty((4,) + mask.shape, np.uint8)
+        t.shadow_batch(suns, out)
+        del t
+        gc.collect()
+
+    for _ in range(3):
+        cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info(0)[0]
+    for _ in range(40):
+        cycle()
+    torch.cuda.synchronize()
+    free1 = torch.cuda.mem_get_info(0)[0]
+    assert abs(free0 - free1) <= 32 << 20, (free0, free1)
