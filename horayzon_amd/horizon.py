@@ -34,7 +34,7 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
                     tri_ind_simp=np.array([0, 0, 0, 0], dtype=np.int32),
                     num_tri_simp=1, elev_ang_low_lim=-15.0, mask=None,
                     hori_fill=0.0, ray_org_elev=0.01, *, device=0, verbose=False,
-                    scene=None, svf_vec_tilt=None, rows=None, count_work=False, devices=None,
+                    scene=None, svf_vec_tilt=None, svf_only=False, rows=None, count_work=False, devices=None,
                     _top_nodes=-1, _regroup=-1, _hit_cache=True, _chunk_rows=0):
     """Horizon computation for gridded domain.
 
@@ -46,7 +46,9 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
     ordinal), ``verbose`` (print the reference's stdout report), ``scene`` (a
     prebuilt ``Scene`` to skip the BVH build), ``svf_vec_tilt`` (tilted normals;
     when given the sky view factor is accumulated in the same kernel and
-    returned as a third value), ``rows`` ((begin, end) slab of inner-domain rows
+    returned as a third value; with ``svf_only`` the horizon array is never materialised --
+    it lives in a bounded device buffer, chunk by chunk -- and ``None`` is returned in its place:
+    the 14401^2 mosaic would need 298 GB of horizon), ``rows`` ((begin, end) slab of inner-domain rows
     to compute; the rest of ``hori_buffer`` stays NaN), ``count_work``, ``devices``
     ("all" or a sequence of HIP ordinals: the inner-domain rows are split into one slab per
     entry, balanced by ``mask``, and each slab is computed by its own host thread on its own
@@ -121,8 +123,10 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
 
     dim_in_0, dim_in_1 = vec_norm.shape[0], vec_norm.shape[1]
     # Allocate horizon array (horizon.pyx:170-173)
-    hori_buffer = np.empty((dim_in_0, dim_in_1, azim_num), dtype=np.float32)
-    if rows is not None:
+    if svf_only and svf_vec_tilt is None:
+        raise ValueError("'svf_only' needs 'svf_vec_tilt'")
+    hori_buffer = None if svf_only else np.empty((dim_in_0, dim_in_1, azim_num), dtype=np.float32)
+    if rows is not None and hori_buffer is not None:
         hori_buffer.fill(np.nan)   # only a slab is written; every cell is written otherwise
                                    # (masked ones get hori_fill), so the 18 GB pre-fill is skipped
 
@@ -133,6 +137,7 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
     opts.regroup = _regroup
     opts.no_hit_cache = 0 if _hit_cache else 1
     opts.chunk_rows = _chunk_rows
+    opts.skip_hori = 1 if svf_only else 0
     opts.count_work = int(bool(count_work))
     if rows is not None:
         opts.row_begin, opts.row_end = int(rows[0]), int(rows[1])

@@ -235,6 +235,24 @@ def test_streamed_host_output(hip, chunk):
     assert np.array_equal(h2, full) and np.array_equal(svf, svf1)
 
 
+@pytest.mark.parametrize("chunk", (0, 5, 16))
+def test_svf_only_matches_full_path(hip, chunk):
+    """svf_only: the horizon lives only in a bounded device buffer (chunks of rows); same SVF, no hori."""
+    g = cases.rough_terrain(75, 88, seed=17, offset=5)
+    kw = cases.grid_kwargs(g)
+    vec_tilt, *_ = cases.terrain_inputs(g)
+    par = dict(dist_search=2.0, azim_num=36, elev_ang_low_lim=-40.0, svf_vec_tilt=vec_tilt)
+    h, a, svf = hip.horizon.horizon_gridded(**kw, **par)
+    rays = hip.horizon.last_stats["num_rays"]
+    none, a2, svf2 = hip.horizon.horizon_gridded(**kw, **par, svf_only=True, _chunk_rows=chunk)
+    assert none is None and np.array_equal(a, a2) and np.array_equal(svf, svf2)
+    assert hip.horizon.last_stats["num_rays"] == rays
+    _, _, svf3 = hip.horizon.horizon_gridded(**kw, **par, svf_only=True, devices=[0, 0], _chunk_rows=chunk)
+    assert np.array_equal(svf, svf3)
+    with pytest.raises(ValueError, match="svf_only"):
+        hip.horizon.horizon_gridded(**kw, dist_search=2.0, azim_num=36, svf_only=True)
+
+
 def test_devices_threads_match_single_call(hip):
     """devices=[...]: one host thread and one row slab per entry (here the same GPU three times, which
     exercises the slab split, the concurrent calls and the merged statistics)."""
