@@ -12,7 +12,7 @@
 //            16 bit z, relative to the node's own box) and the links of up to 4
 //            children (the four Morton quadrants), stored tallest (largest z-max) first.
 //            The first `n_top` nodes are the top of the tree in breadth-first
-//            order (staged in LDS by the kernels).  AABBs live in a frame
+//            order (contiguous hot levels; the optional LDS nodelet stages them).  AABBs live in a frame
 //            centred on the scene (`center`) and are padded by `pad`, which
 //            makes the box test conservative with respect to the float32
 //            triangle test: hit decisions depend on the triangle test only,
@@ -324,13 +324,15 @@ __device__ __forceinline__ void hz_load_prim(const Prim *q, float4 &q0, float4 &
 // any-hit traversal of one ray, resumable.
 //   TravState : node (current link), sp (stack pointer), up to 4 queued leaves
 //   stack     : per-lane LDS stack, entry k of lane tid at stack[k * TPB + tid]
-//   top       : LDS copy of the first ntop nodes (may be null / ntop = 0)
-//   regroup   : leave when fewer than `regroup` lanes of the wave are still traversing
+//   top       : LDS copy of the first ntop nodes, read only by the NODELET instantiation (else null / 0)
+//   regroup   : leave when fewer than `regroup` lanes of the wave are still traversing (and at least one
+//               lane finished in this call, so the caller can refill it)
+//   leaf_bias : the wave takes the node step when 16 * (lanes with a node) >= leaf_bias * (lanes with a leaf)
 // Scheduling inside the wave: every lane sets leaves aside (up to QLEN) and keeps descending;
 // each iteration the wave executes ONE kind of step -- the node step or the leaf step --
 // whichever more lanes are ready for (ballot + popcount vote).  This keeps the 64 lanes
 // busy although neighbouring rays reach their leaves at different times.
-// returns 0 = miss, 1 = hit, 2 = suspended (state is valid, call again)
+// returns 0 = miss, 1 = hit (t.lq0 is the blocking leaf), 2 = suspended (state is valid, call again)
 // ---------------------------------------------------------------------------
 struct TravCounters { unsigned nodes, tris, w_nodes, w_leaves; };
 struct TravState { int node, sp, lq0, lq1, lq2, lq3; };

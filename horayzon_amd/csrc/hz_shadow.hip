@@ -10,6 +10,9 @@
 namespace hz {
 
 #define HZ_TPB 256
+#ifndef HZ_SHADOW_LEAF_BIAS
+#define HZ_SHADOW_LEAF_BIAS 20   // node step when 16 * n_node >= bias * n_leaf (hz_trace)
+#endif
 
 struct ShadowParams {
     SceneView sv;
@@ -53,23 +56,21 @@ __device__ __forceinline__ float atmos_refrac(float elev_ang_true, float temp, f
     return (float)((double)refrac_cor * (1.0 / 60.0));
 }
 
-// any-hit traversal to completion (regroup = 0: never suspends)
-__device__ __forceinline__ bool occluded(const SceneView &sv, const float4 *top, int ntop, int *stack, int tid,
+// any-hit traversal to completion (regroup = 0: never suspends; no LDS nodelet: top = null)
+__device__ __forceinline__ bool occluded(const SceneView &sv, int *stack, int tid,
                                          float ox, float oy, float oz, float dx, float dy, float dz,
                                          float tfar) {
     const RayBox rb = hz_raybox(ox - sv.cx, oy - sv.cy, oz - sv.cz, dx, dy, dz);
     TravState ts; hz_trav_reset(ts);
     TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.w_nodes = 0; tc.w_leaves = 0;
-    return hz_trace<HZ_TPB, false>(sv.nodes, sv.prims, top, ntop, stack, tid, ox, oy, oz, dx, dy, dz, tfar, rb,
-                                   ts, 0, 16, tc) == 1;
+    return hz_trace<HZ_TPB, false>(sv.nodes, sv.prims, nullptr, 0, stack, tid, ox, oy, oz, dx, dy, dz, tfar, rb,
+                                   ts, 0, HZ_SHADOW_LEAF_BIAS, tc) == 1;
 }
 
 __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *stack = reinterpret_cast<int *>(smem);
-    const float4 *top = nullptr;      // no LDS nodelet: the top of the tree is L1 resident
     const int tid = threadIdx.x;
-    const int ntop = 0;
     int ti = 0, tj = 0;
     const bool has_tile = hz_tile_of_block(p.tm, blockIdx.x, &ti, &tj);
     const int wave = tid >> 6, lane = tid & 63;
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
             if (p.which == 0) {                                    // :451-478
                 if (dot_prod_ts > 0.0f) {
                     rays = 1;
-                    const bool h = occluded(p.sv, top, ntop, stack, tid, ox, oy, oz, sun_x, sun_y, sun_z, inf);
+                    const bool h = occluded(p.sv, stack, tid, ox, oy, oz, sun_x, sun_y, sun_z, inf);
                     p.out_u8[cell] = h ? 2 : 0;
                 } else {
                     p.out_u8[cell] = 1;
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
             } else {                                               // :561-592
                 if (dot_prod_ts > p.dot_prod_min) {
                     rays = 1;
-                    const bool h = occluded(p.sv, top, ntop, stack, tid, ox, oy, oz, sun_x, sun_y, sun_z, inf);
+                    const bool h = occluded(p.sv, stack, tid, ox, oy, oz, sun_x, sun_y, sun_z, inf);
                     if (h) p.out_f32[cell] = 0.0f;
                     else {
                         if (dot_prod_ns < p.dot_prod_min) dot_prod_ns = p.dot_prod_min;
