@@ -9,20 +9,21 @@
 //                   one azimuth to the next, horizon_comp.cpp:431-496)
 //   one wavefront = an 8 x 8 tile of cells -> neighbouring lanes shoot nearly
 //                   parallel rays and fetch the same BVH nodes (coalesced by the TA)
-//   one workgroup = 4 wavefronts = a 16 x 16 tile; stages the breadth-first top of
-//                   the LBVH in LDS once and keeps the per-lane traversal stacks in LDS
-//   blockIdx      -> tile mapping is XCD aware: the 8 XCDs each take a contiguous
-//                   band of tiles so that one XCD's L2 sees one region of the BVH
+//   one workgroup = 4 wavefronts = a 16 x 16 tile; per-lane traversal stacks and the output
+//                   staging (4 azimuths -> one 16 B store) live in LDS
+//   blockIdx      -> tile mapping is XCD aware: each of the 8 XCDs owns a compact region of
+//                   tiles so that one XCD's L2 sees one region of the BVH
 //
 // Per lane a small state machine (Search) produces the next elevation sample as
 // soon as the previous occlusion query finishes; lanes never wait for an azimuth
 // barrier.  When fewer than `regroup` lanes of a wave are still traversing, the
 // wave leaves the traversal loop (ballot + popcount) so idle lanes can fetch
-// their next ray: this is the ray compaction step.
+// their next ray: this is the ray compaction step.  A ray expected to be blocked first
+// walks the subtree above the leaf that blocked the cell's previous ray (hit cache).
 //
 // The float/double promotion pattern of the reference's index arithmetic is
 // reproduced exactly (hard part 2); tables are built on the
-// host with the reference's expressions (hz_api.cpp) and only read here.
+// host with the reference's expressions (hz_api.hip) and only read here.
 #include "hz_search.h"
 
 namespace hz {

@@ -12,8 +12,10 @@
 //   5. k_leaf_boxes / k_refit_pass  leaf AABBs; bottom-up union, level synchronous with work lists
 //   6. k_roots/scan  collapse along the 2-bit Morton digits: a binary node starts a 4-wide
 //                    node when its common-prefix length enters a new digit (quadtree level)
-//   7. k_emit4       64 B nodes with conservatively quantised child AABBs (8 bit x/y, 16 bit z)
-//   8. k_top/k_permute  breadth-first relabel of the top of the tree (for LDS staging)
+//   7. k_emit4       64 B nodes with conservatively quantised child AABBs (8 bit x/y, 16 bit z),
+//                    children sorted tallest first
+//   8. k_top/k_permute  breadth-first relabel of the top of the tree (hot levels contiguous)
+//      k_parents4/k_ancestors  per leaf the node HZ_ANC_LEVELS above it (hit cache)
 //   9. k_emit_prims  48 B leaf records in Morton order
 #include <cstring>
 #include <cstdlib>
