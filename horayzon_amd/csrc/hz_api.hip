@@ -164,7 +164,9 @@ struct Terrain {
     bool own_tilt = false, own_norm = false, own_enl = false, own_elev = false, own_mask = false;
     float fill = 0, ang_max = 89.0f;
     int refrac = 0;
-    unsigned long long *counters = nullptr;
+    unsigned long long *counters = nullptr;   // device u64[16]
+    int stack_entries = 0;                    // 0: default of shadow_launch
+    int stack_level = 0;                      // residency level that has worked so far (shadow_launch)
     hipStream_t stream = nullptr;
     bool initialised = false;
 };
@@ -273,11 +275,10 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         if ((rc = d_azim.bind(azim_h.data(), (size_t)azim_num, st))) return rc;
     }
     DevIn<unsigned long long> d_cnt;
-    unsigned long long zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long zeros[16] = {0};
     void *cnt_dev = nullptr;
     HZ_HIP(hipMalloc(&cnt_dev, sizeof(zeros)));
     d_cnt.owned = cnt_dev;
-    HZ_HIP(hipMemcpyAsync(cnt_dev, zeros, sizeof(zeros), hipMemcpyHostToDevice, st));
     HZ_HIP(hipStreamSynchronize(st));
     const double h2d_s = t_h2d.stop();
 
@@ -293,11 +294,22 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     a.regroup = opts ? opts->regroup : -1;
     a.count_work = opts ? opts->count_work : 0;
     a.hit_cache = (opts && opts->no_hit_cache) ? 0 : 1;
+    a.stack_entries = opts ? opts->stack_entries : 0;
     a.counters = (unsigned long long *)cnt_dev;
+
+    // The LDS traversal stack is sized for residency, not for the worst case (horizon_launch: levels 0, 1, 2
+    // = 5 / 4 workgroups per CU / worst-case depth).  A wave whose ray needed more entries raises
+    // counters[8]; the chunk is then repeated one level up and the scene remembers the level, so that a
+    // deep tree pays for one wasted chunk, once.
+    unsigned long long cnt[16] = {0};
+    float ms = 0.0f, ms_svf = 0.0f;
+    int retries = 0;
+    int level = sc->stack_level.load(std::memory_order_relaxed);
 
     // HIP events on the kernels' stream: horizon kernel and SVF kernel are timed separately
     struct Ev { hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr; };
-    std::vector<Ev> evs;
+    std::vector<Ev> evs;          // one per launch attempt
+    std::vector<size_t> ev_of;    // chunk -> its final attempt
     hipStream_t st_copy = nullptr;
     auto free_events = [&]() {
         for (auto &e : evs) {
@@ -314,13 +326,15 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     auto copy_out = [&](int k) -> int {
         const int rb = row_begin + k * chunk_rows, re = std::min(rb + chunk_rows, row_end);
         const void *src = (k & 1) ? tmp_hori2 : tmp_hori;
-        if (hipStreamWaitEvent(st_copy, evs[(size_t)k].c, 0) != hipSuccess ||
+        Ev &e = evs[ev_of[(size_t)k]];
+        if (hipStreamWaitEvent(st_copy, e.c, 0) != hipSuccess ||
             hipMemcpyAsync(hori_buffer + (size_t)rb * dim_in_1 * azim_num, src, (size_t)(re - rb) * row_bytes,
                            hipMemcpyDeviceToHost, st_copy) != hipSuccess ||
-            hipEventRecord(evs[(size_t)k].d, st_copy) != hipSuccess)
+            hipEventRecord(e.d, st_copy) != hipSuccess)
             return set_error(HZ_ERR_HIP, "copy of the horizon chunk failed: %s", hipGetErrorString(hipGetLastError()));
         return HZ_OK;
     };
+    auto fail = [&](int code) { (void)hipStreamSynchronize(st); if (st_copy) (void)hipStreamSynchronize(st_copy); free_events(); return code; };
     int n_chunk = 0;
     for (int rb = row_begin; rb < row_end; rb += chunk_rows, n_chunk++) {
         const int re = std::min(rb + chunk_rows, row_end);
@@ -331,28 +345,48 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         else hori_chunk = d_hori.dev + (size_t)(rb - row_begin) * dim_in_1 * azim_num;
         a.hori = hori_chunk - (size_t)rb * dim_in_1 * azim_num;
         a.row_begin = rb; a.row_end = re;
-        Ev e;
-        if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess || hipEventCreate(&e.c) != hipSuccess ||
-            hipEventCreate(&e.d) != hipSuccess) {
-            evs.push_back(e); free_events();
-            return set_error(HZ_ERR_HIP, "hipEventCreate failed");
+        bool prev_copied = false;
+        for (;;) {                                     // attempts of this chunk
+            Ev e;
+            if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess || hipEventCreate(&e.c) != hipSuccess ||
+                hipEventCreate(&e.d) != hipSuccess) {
+                evs.push_back(e);
+                return fail(set_error(HZ_ERR_HIP, "hipEventCreate failed"));
+            }
+            evs.push_back(e);
+            if (ev_of.size() <= (size_t)n_chunk) ev_of.push_back(evs.size() - 1); else ev_of[(size_t)n_chunk] = evs.size() - 1;
+            a.stack_level = level;
+            if (hipMemcpyAsync(cnt_dev, zeros, sizeof(zeros), hipMemcpyHostToDevice, st) != hipSuccess)
+                return fail(set_error(HZ_ERR_HIP, "counter reset failed"));
+            // the buffer of chunk n is the one chunk n - 2 was copied out of
+            if (stream_out && n_chunk >= 2) (void)hipStreamWaitEvent(st, evs[ev_of[(size_t)n_chunk - 2]].d, 0);
+            (void)hipEventRecord(e.a, st);
+            int cap_is_full = 0;
+            rc = horizon_launch(sc, a, st, &cap_is_full);
+            (void)hipEventRecord(e.b, st);
+            if (!rc && want_svf)
+                rc = svf_launch(d_azim.dev, hori_chunk, d_tilt.dev + 3 * (size_t)rb * dim_in_1, re - rb, dim_in_1,
+                                azim_num, d_svf.dev + (size_t)(rb - row_begin) * dim_in_1, st);
+            (void)hipEventRecord(e.c, st);
+            if (!rc && stream_out && n_chunk >= 1 && !prev_copied) { rc = copy_out(n_chunk - 1); prev_copied = true; }
+            if (rc) return fail(rc);
+            unsigned long long c[16];
+            if (hipMemcpyAsync(c, cnt_dev, sizeof(c), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipStreamSynchronize(st) != hipSuccess)
+                return fail(set_error(HZ_ERR_HIP, "horizon kernel failed: %s", hipGetErrorString(hipGetLastError())));
+            float m1 = 0.0f, m2 = 0.0f;
+            (void)hipEventElapsedTime(&m1, e.a, e.b);
+            (void)hipEventElapsedTime(&m2, e.b, e.c);
+            ms += m1; ms_svf += m2;
+            if (c[8] != 0 && !cap_is_full) {           // a ray ran out of stack: one level up, same chunk again
+                level++; retries++;
+                int seen = sc->stack_level.load(std::memory_order_relaxed);
+                while (seen < level && !sc->stack_level.compare_exchange_weak(seen, level, std::memory_order_relaxed)) {}
+                continue;
+            }
+            for (int k = 0; k < 16; k++) cnt[k] += c[k];
+            break;
         }
-        evs.push_back(e);
-        // the buffer of chunk n is the one chunk n - 2 was copied out of
-        if (stream_out && n_chunk >= 2) (void)hipStreamWaitEvent(st, evs[(size_t)n_chunk - 2].d, 0);
-        (void)hipEventRecord(e.a, st);
-        rc = horizon_launch(sc, a, st);
-        (void)hipEventRecord(e.b, st);
-        if (!rc && want_svf)
-            rc = svf_launch(d_azim.dev, hori_chunk, d_tilt.dev + 3 * (size_t)rb * dim_in_1, re - rb, dim_in_1,
-                            azim_num, d_svf.dev + (size_t)(rb - row_begin) * dim_in_1, st);
-        (void)hipEventRecord(e.c, st);
-        if (!rc && stream_out && n_chunk >= 1) rc = copy_out(n_chunk - 1);
-        if (rc) { (void)hipStreamSynchronize(st); if (st_copy) (void)hipStreamSynchronize(st_copy); free_events(); return rc; }
-    }
-    {
-        const hipError_t se = hipStreamSynchronize(st);
-        if (se != hipSuccess) { if (st_copy) (void)hipStreamSynchronize(st_copy); free_events(); return set_error(HZ_ERR_HIP, "horizon kernel failed: %s", hipGetErrorString(se)); }
     }
     Timer t_d2h; t_d2h.start();
     if (stream_out) {
@@ -361,18 +395,8 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         if (!rc && se != hipSuccess) rc = set_error(HZ_ERR_HIP, "copy of the horizon failed: %s", hipGetErrorString(se));
         if (rc) { free_events(); return rc; }
     }
-    float ms = 0.0f, ms_svf = 0.0f;
-    for (auto &e : evs) {
-        float m1 = 0.0f, m2 = 0.0f;
-        (void)hipEventElapsedTime(&m1, e.a, e.b);
-        (void)hipEventElapsedTime(&m2, e.b, e.c);
-        ms += m1; ms_svf += m2;
-    }
     free_events();
     HZ_HIP(hipGetLastError());
-
-    unsigned long long cnt[8];
-    HZ_HIP(hipMemcpyAsync(cnt, cnt_dev, sizeof(cnt), hipMemcpyDeviceToHost, st));
     if ((rc = d_hori.finish(st))) return rc;
     if ((rc = d_svf.finish(st))) return rc;
     HZ_HIP(hipStreamSynchronize(st));
@@ -386,6 +410,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         stats->t_d2h_s += d2h_s;
         stats->t_total_s += t_total.stop();
         stats->elev_num = tb.elev_num; stats->bvh_height = sc->hdr.height; stats->scene_bytes = sc->hdr.total_bytes;
+        stats->stack_retries += (uint64_t)retries;
     }
     if (opts && opts->verbose) {   // the reference's report, horizon_comp.cpp:692-700, 805-810
         printf("Number of grid cells for which horizon is computed: %llu \n", cnt[4]);
@@ -874,7 +899,7 @@ static int terrain_init_common(Terrain *t, int offset_0, int offset_1, const flo
     if ((rc = persist(surf_enl_fac, nc * 4, st, &t->enl, &t->own_enl))) return rc;
     if ((rc = persist(elevation, nc * 4, st, &t->elev, &t->own_elev))) return rc;
     if ((rc = persist(mask, nc, st, &t->mask, &t->own_mask))) return rc;
-    if (!t->counters) HZ_HIP(hipMalloc((void **)&t->counters, 8 * sizeof(unsigned long long)));
+    if (!t->counters) HZ_HIP(hipMalloc((void **)&t->counters, 16 * sizeof(unsigned long long)));
     HZ_HIP(hipStreamSynchronize(st));
     t->offset_0 = offset_0; t->offset_1 = offset_1; t->dim_in_0 = dim_in_0; t->dim_in_1 = dim_in_1;
     t->fill = sw_dir_cor_fill; t->ang_max = ang_max; t->refrac = refrac_cor ? 1 : 0;
@@ -935,7 +960,6 @@ static int terrain_run(Terrain *t, const float *sun_positions, int num_sun, int 
     int rc;
     if (which == 0) { if ((rc = d_u8.bind(out_u8, nc * (size_t)num_sun))) return rc; }
     else { if ((rc = d_f32.bind(out_f32, nc * (size_t)num_sun))) return rc; }
-    HZ_HIP(hipMemsetAsync(t->counters, 0, 8 * sizeof(unsigned long long), st));
     ShadowArgs a;
     a.vec_tilt = (const float *)t->tilt; a.vec_norm = (const float *)t->norm;
     a.surf_enl_fac = (const float *)t->enl; a.elevation = (const float *)t->elev; a.mask = (const uint8_t *)t->mask;
@@ -943,23 +967,37 @@ static int terrain_run(Terrain *t, const float *sun_positions, int num_sun, int 
     a.sw_dir_cor_fill = t->fill;
     a.dot_prod_min = cosf(deg2rad_f(t->ang_max));            // shadow_comp.cpp:498
     a.refrac_cor = t->refrac; a.which = which; a.top_nodes = -1; a.counters = t->counters;
-    hipEvent_t e0, e1;
-    HZ_HIP(hipEventCreate(&e0)); HZ_HIP(hipEventCreate(&e1));
-    HZ_HIP(hipEventRecord(e0, st));
-    for (int s = 0; s < num_sun; s++) {
-        a.sun[0] = sun[3 * (size_t)s]; a.sun[1] = sun[3 * (size_t)s + 1]; a.sun[2] = sun[3 * (size_t)s + 2];
-        a.out_u8 = d_u8.dev ? d_u8.dev + nc * (size_t)s : nullptr;
-        a.out_f32 = d_f32.dev ? d_f32.dev + nc * (size_t)s : nullptr;
-        if ((rc = shadow_launch(t->scene, a, st))) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
-    }
-    HZ_HIP(hipEventRecord(e1, st));
-    HZ_HIP(hipEventSynchronize(e1));
+    a.stack_entries = t->stack_entries;
     float ms = 0.0f;
-    HZ_HIP(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    unsigned long long cnt[16];
+    int retries = 0;
+    // LDS stack sized for residency (shadow_launch levels); a ray that needed more raises counters[8], the
+    // batch is repeated one level up and the terrain remembers the level
+    for (;;) {
+        a.stack_level = t->stack_level;
+        HZ_HIP(hipMemsetAsync(t->counters, 0, 16 * sizeof(unsigned long long), st));
+        hipEvent_t e0, e1;
+        HZ_HIP(hipEventCreate(&e0)); HZ_HIP(hipEventCreate(&e1));
+        HZ_HIP(hipEventRecord(e0, st));
+        int cap_is_full = 1;
+        for (int s = 0; s < num_sun; s++) {
+            a.sun[0] = sun[3 * (size_t)s]; a.sun[1] = sun[3 * (size_t)s + 1]; a.sun[2] = sun[3 * (size_t)s + 2];
+            a.out_u8 = d_u8.dev ? d_u8.dev + nc * (size_t)s : nullptr;
+            a.out_f32 = d_f32.dev ? d_f32.dev + nc * (size_t)s : nullptr;
+            if ((rc = shadow_launch(t->scene, a, st, &cap_is_full))) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+        }
+        HZ_HIP(hipEventRecord(e1, st));
+        HZ_HIP(hipEventSynchronize(e1));
+        float m = 0.0f;
+        HZ_HIP(hipEventElapsedTime(&m, e0, e1));
+        ms += m;
+        (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+        HZ_HIP(hipMemcpyAsync(cnt, t->counters, sizeof(cnt), hipMemcpyDeviceToHost, st));
+        HZ_HIP(hipStreamSynchronize(st));
+        if (cnt[8] == 0 || cap_is_full) break;
+        t->stack_level++; retries++;
+    }
     Timer t_d2h; t_d2h.start();
-    unsigned long long cnt[8];
-    HZ_HIP(hipMemcpyAsync(cnt, t->counters, sizeof(cnt), hipMemcpyDeviceToHost, st));
     if ((rc = d_u8.finish(st))) return rc;
     if ((rc = d_f32.finish(st))) return rc;
     HZ_HIP(hipStreamSynchronize(st));
@@ -969,7 +1007,16 @@ static int terrain_run(Terrain *t, const float *sun_positions, int num_sun, int 
         stats->t_d2h_s += t_d2h.stop();
         stats->t_total_s += t_total.stop();
         stats->bvh_height = t->scene->hdr.height; stats->scene_bytes = t->scene->hdr.total_bytes;
+        stats->stack_retries += (uint64_t)retries;
     }
+    return HZ_OK;
+}
+
+int hz_terrain_set_stack_entries(hz_terrain *terrain, int entries) {
+    Terrain *t = reinterpret_cast<Terrain *>(terrain);
+    if (!t || entries < 0) return set_error(HZ_ERR_ARG, "invalid terrain handle or entry count");
+    t->stack_entries = entries;
+    t->stack_level = 0;
     return HZ_OK;
 }
 

@@ -327,6 +327,7 @@ __device__ __forceinline__ void hz_load_prim(const Prim *q, float4 &q0, float4 &
 //   top       : LDS copy of the first ntop nodes, read only by the NODELET instantiation (else null / 0)
 //   regroup   : leave when fewer than `regroup` lanes of the wave are still traversing (and at least one
 //               lane finished in this call, so the caller can refill it)
+//   stack_cap : entries per lane the LDS stack holds (>= 3); `overflow` is set when a ray needed more
 //   leaf_bias : the wave takes the node step when 16 * (lanes with a node) >= leaf_bias * (lanes with a leaf)
 // Scheduling inside the wave: every lane sets leaves aside (up to QLEN) and keeps descending;
 // each iteration the wave executes ONE kind of step -- the node step or the leaf step --
@@ -348,7 +349,7 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
                                         const float4 *top, int ntop, int *stack, int tid,
                                         float ox, float oy, float oz, float dx, float dy, float dz, float tfar,
                                         const RayBox &rb, TravState &t, int regroup, int leaf_bias,
-                                        TravCounters &cnt) {
+                                        TravCounters &cnt, int stack_cap, unsigned &overflow) {
     const int lane = tid & 63;
     int node = t.node, sp = t.sp, lq0 = t.lq0, lq1 = t.lq1, lq2 = t.lq2, lq3 = t.lq3;
     const int n_entry = __popcll(__ballot(1));   // lanes that entered with a ray
@@ -394,6 +395,11 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
                 // ~45 VALU per step) was measured to be a net loss: these are any-hit rays, a blocked ray
                 // is blocked over a long stretch behind the first ridge, and near-horizon rays that only
                 // nick a crest are served by the hit cache.
+                // the LDS stack holds `stack_cap` entries, usually fewer than the worst case of 3 per level
+                // (more workgroups per CU).  A node step stores at most 3: if they would not fit, entries are
+                // dropped -- never written out of bounds -- and the launch is flagged; the host repeats it with
+                // the full-depth stack (hz_api.hip).  With stack_cap = 3 * height this never triggers.
+                if (sp > stack_cap - 3) { overflow = 1u; sp = stack_cap - 3; }
                 int next = HZ_EMPTY;
                 // branch-free pushes: the candidate is always stored at the stack top and only kept
                 // (sp advanced) when it was a real link; a node at level L writes at most index 3 L - 1

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include "../../include/horayzon_hip.h"
 #include "hz_common.h"
+#include <atomic>
 
 #define HZ_MAX_TOP_NODES 2047   // upper bound of BFS-ordered top nodes (LDS staging)
 #define HZ_MAX_STACK 96         // LDS stack entries per lane the traversal kernels accept (3 per 4-wide level)
@@ -41,6 +42,9 @@ struct Scene {
     void *blob = nullptr;
     size_t blob_bytes = 0;
     bool owns_blob = false;
+    // residency level of the LDS traversal stack that has worked for this scene so far (hz_api.hip);
+    // mutable: kernels that hit the limit bump it through a const Scene
+    mutable std::atomic<int> stack_level{0};
     BlobHeader hdr;
     const float *verts() const { return (const float *)((const char *)blob + hdr.off_verts); }
     const Node *nodes() const { return (const Node *)((const char *)blob + hdr.off_nodes); }
@@ -106,9 +110,14 @@ struct HorizonArgs {
     const float *azim_sin, *azim_cos, *elev_ang, *elev_sin, *elev_cos;  // device tables
     const int *mid_idx;
     int top_nodes, regroup, count_work, hit_cache;
-    unsigned long long *counters;        // device u64[8]: [0] rays, [1] guards, [2] nodes, [3] tris, [4] cells
+    int stack_entries, stack_level;      // LDS stack entries per lane (0 = auto) and residency level 0 / 1 / 2
+    unsigned long long *counters;        // device u64[16]: [0] rays, [1] guards, [2] nodes, [3] tris, [4] cells,
+                                         // [5..7] wave iterations, [8] waves with a stack overflow
 };
-int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st);
+int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *cap_is_full = nullptr);
+// entries per lane of the LDS traversal stack for residency level 0 / 1 / 2 (5 / 4 workgroups per CU /
+// worst case 3 per tree level); `other_lds` = bytes of LDS the kernel uses besides the stack
+int stack_cap_for_level(int height, int other_lds, int override_entries, int level);
 int topo_launch(int kind, const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
                 int len_2, float *out, hipStream_t st);
 int svf_launch(const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
@@ -137,9 +146,10 @@ struct ShadowArgs {
     int which;                           // 0 shadow (u8), 1 sw_dir_cor (f32)
     uint8_t *out_u8; float *out_f32;
     int top_nodes;
-    unsigned long long *counters;        // [0] rays
+    int stack_entries, stack_level;      // as in HorizonArgs
+    unsigned long long *counters;        // device u64[16]: [0] rays, [8] waves with a stack overflow
 };
-int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st);
+int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st, int *cap_is_full = nullptr);
 
 // hz_sort.hip: hand-written stable LSD radix sort (pairs) and exclusive scan, uint32
 size_t sort_temp_elems(size_t n);

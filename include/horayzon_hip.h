@@ -53,6 +53,11 @@ typedef struct hz_opts {
     int32_t chunk_rows;    /* rows per launch when hori is host memory or skipped (chunks are      */
                            /*   double buffered and copied out while the next one is traced);      */
                            /*   <= 0: as many rows as fit 4 GiB                                     */
+    int32_t stack_entries; /* LDS traversal-stack entries per lane; 0: as many as still allow 5     */
+                           /*   workgroups per CU.  Rays that need more are detected and the call  */
+                           /*   is repeated with the worst case (3 per tree level): results never  */
+                           /*   depend on it                                                       */
+    int32_t reserved;
 } hz_opts;
 
 /* Run-time self report (the quantities the reference prints,                  */
@@ -75,6 +80,7 @@ typedef struct hz_stats {
     uint64_t wave_leaf_iters; /*   step / leaf step / ray refill section (SIMT  */
     uint64_t wave_refills;    /*   efficiency = lane count / (64 x wave count)) */
     double t_svf_s;        /* sky-view-factor kernel (when opts.svf is set)    */
+    uint64_t stack_retries;/* calls repeated with the worst-case stack depth   */
 } hz_stats;
 
 const char *hz_last_error(void);
@@ -244,6 +250,8 @@ int hz_terrain_shadow_batch(hz_terrain *terrain, const float *sun_positions,
 int hz_terrain_sw_dir_cor_batch(hz_terrain *terrain, const float *sun_positions,
                                 int num_sun, float *sw_dir_cor_buffers, hz_stats *stats);
 /* CppTerrain::~CppTerrain, shadow_comp.cpp:310-316 */
+/* LDS traversal-stack entries per lane for this terrain's kernels (0: default, see hz_opts.stack_entries). */
+int hz_terrain_set_stack_entries(hz_terrain *terrain, int entries);
 int hz_terrain_destroy(hz_terrain *terrain);
 
 #ifdef __cplusplus
