@@ -161,13 +161,17 @@ def main():
     elapsed = time.perf_counter() - t0
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tsum = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
         elapsed = float(t.item())
+        imbalance = elapsed / (float(tsum.item()) / world)      # slowest rank / mean rank
         tot = torch.tensor([stats.num_rays, stats.num_cells], dtype=torch.float64, device=dev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         rays_total, cells_total = float(tot[0].item()), float(tot[1].item())
     else:
         rays_total, cells_total = float(stats.num_rays), float(stats.num_cells)
+        imbalance = 1.0
 
     if rank == 0:
         # device-copy microbenchmark: what a plain HBM stream reaches on this box
@@ -213,7 +217,8 @@ def main():
                        "cells_per_step": int(cells_launch), "rays_per_cell_azimuth": rays_launch / max(cells_launch * A, 1),
                        "parallelism": "row-slab shard x%d, scene broadcast once" % world,
                        "bvh_build_s": scene_stats["t_bvh_s"] if scene_stats else None,
-                       "scene_bytes": int(blob_bytes), "scene_bcast_s": t_bcast, "scene_create_wall_s": t_build},
+                       "scene_bytes": int(blob_bytes), "scene_bcast_s": t_bcast, "scene_create_wall_s": t_build,
+                       "load_imbalance_max_over_mean": imbalance, "stack_retries": int(stats.stack_retries)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "hz::k_horizon<2,false,true,false>", "kernel_ms_per_launch": 1e3 * k_launch_s,
