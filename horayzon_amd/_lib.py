@@ -53,7 +53,7 @@ SYMBOLS = (
     "hz_sky_view_factor", "hz_visible_sky_fraction", "hz_topographic_openness",
     "hz_slope_plane_meth", "hz_slope_vector_meth", "hz_lonlat2ecef", "hz_ecef2enu",
     "hz_ecef2enu_vector", "hz_surf_norm", "hz_north_dir",
-    "hz_debug_sort_pairs", "hz_debug_exclusive_scan",
+    "hz_debug_sort_pairs", "hz_debug_exclusive_scan", "hz_debug_stack_cap",
     "hz_terrain_create", "hz_terrain_set_stack_entries", "hz_terrain_initialise", "hz_terrain_initialise_scene",
     "hz_terrain_shadow", "hz_terrain_sw_dir_cor", "hz_terrain_shadow_batch",
     "hz_terrain_sw_dir_cor_batch", "hz_terrain_destroy",

@@ -1012,6 +1012,10 @@ static int terrain_run(Terrain *t, const float *sun_positions, int num_sun, int 
     return HZ_OK;
 }
 
+int hz_debug_stack_cap(int height, int other_lds_bytes, int override_entries, int level) {
+    return stack_cap_for_level(height, other_lds_bytes, override_entries, level);
+}
+
 int hz_terrain_set_stack_entries(hz_terrain *terrain, int entries) {
     Terrain *t = reinterpret_cast<Terrain *>(terrain);
     if (!t || entries < 0) return set_error(HZ_ERR_ARG, "invalid terrain handle or entry count");

@@ -183,6 +183,8 @@ int hz_topographic_openness(const float *azim, const float *hori, int len_0, int
 /* Test hooks for the hand-written build primitives (stable radix sort of uint32 pairs by key,   */
 /* exclusive prefix sum); host arrays, in place / in -> out.  Not needed by a binding.            */
 int hz_debug_sort_pairs(uint32_t *keys, uint32_t *vals, size_t n, int device);
+/* entries per lane of the LDS traversal stack for a tree of `height` 4-wide levels at residency level 0 / 1 / 2 */
+int hz_debug_stack_cap(int height, int other_lds_bytes, int override_entries, int level);
 int hz_debug_exclusive_scan(const uint32_t *in, uint32_t *out, size_t n, int device);
 
 /* ------------------------------------------------------------------------- */
