@@ -26,7 +26,7 @@ class hz_opts(C.Structure):
                 ("count_work", C.c_int32), ("no_hit_cache", C.c_int32),
                 ("svf", C.c_void_p), ("vec_tilt", C.c_void_p),
                 ("skip_hori", C.c_int32), ("chunk_rows", C.c_int32),
-                ("stack_entries", C.c_int32), ("reserved", C.c_int32)]
+                ("stack_entries", C.c_int32), ("hori_is_slab", C.c_int32)]
 
 
 class hz_stats(C.Structure):
@@ -54,6 +54,7 @@ SYMBOLS = (
     "hz_slope_plane_meth", "hz_slope_vector_meth", "hz_lonlat2ecef", "hz_ecef2enu",
     "hz_ecef2enu_vector", "hz_surf_norm", "hz_north_dir",
     "hz_debug_sort_pairs", "hz_debug_exclusive_scan", "hz_debug_stack_cap",
+    "hz_debug_valu_peak", "hz_debug_copy_peak",
     "hz_terrain_create", "hz_terrain_set_stack_entries", "hz_terrain_initialise", "hz_terrain_initialise_scene",
     "hz_terrain_shadow", "hz_terrain_sw_dir_cor", "hz_terrain_shadow_batch",
     "hz_terrain_sw_dir_cor_batch", "hz_terrain_destroy",
@@ -131,6 +132,8 @@ def lib():
     L.hz_north_dir.argtypes = [vp, vp, vp, vp, C.c_size_t, ip, vp, ip]
     L.hz_debug_sort_pairs.argtypes = [vp, vp, C.c_size_t, ip]
     L.hz_debug_exclusive_scan.argtypes = [vp, vp, C.c_size_t, ip]
+    L.hz_debug_valu_peak.argtypes = [ip, ip, ip, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.hz_debug_copy_peak.argtypes = [ip, C.c_size_t, C.POINTER(C.c_double)]
     L.hz_terrain_create.argtypes = [ip, C.POINTER(vp)]
     L.hz_terrain_initialise.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, ip, ip, vp, vp, vp,
                                         C.c_char_p, C.c_float, C.c_float, ip, C.POINTER(hz_stats)]

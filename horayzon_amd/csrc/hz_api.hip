@@ -246,7 +246,12 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     DevOut<float> d_hori, d_svf;
     DevIn<float> d_azim;
     const bool want_svf = opts && opts->svf;
-    float *hori_slab_host = hori_buffer ? hori_buffer + (size_t)row_begin * dim_in_1 * azim_num : nullptr;
+    // hori_buffer addresses inner-domain row 0 (the reference's layout) unless opts.hori_is_slab says it addresses
+    // row_begin.  Only the slab itself is ever classified or written: `hori_row0` is an address used for
+    // arithmetic alone (it may lie below the caller's allocation when a resident slab buffer is passed).
+    const bool hori_is_slab = opts && opts->hori_is_slab;
+    float *hori_slab_host = hori_buffer ? (hori_is_slab ? hori_buffer : hori_buffer + (size_t)row_begin * dim_in_1 * azim_num) : nullptr;
+    float *hori_row0 = hori_slab_host ? hori_slab_host - (size_t)row_begin * dim_in_1 * azim_num : nullptr;
     float *svf_slab = want_svf ? opts->svf + (size_t)row_begin * dim_in_1 : nullptr;
     if ((rc = d_svf.bind(svf_slab, svf_slab ? slab_cells : 0))) return rc;
     // rows per launch: the whole slab when `hori` is device memory.  Otherwise the horizon of a chunk
@@ -257,7 +262,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     void *tmp_hori = nullptr, *tmp_hori2 = nullptr;
     struct TmpFree { void **p; ~TmpFree() { if (*p) (void)hipFree(*p); } } tmp_free{&tmp_hori}, tmp_free2{&tmp_hori2};
     const size_t row_bytes = (size_t)dim_in_1 * azim_num * 4;
-    const bool stream_out = !skip_hori && !is_device_ptr(hori_buffer);
+    const bool stream_out = !skip_hori && !is_device_ptr(hori_slab_host);
     if (skip_hori || stream_out) {
         if (skip_hori && !want_svf) return set_error(HZ_ERR_ARG, "skip_hori without svf: nothing to compute");
         if (opts && opts->chunk_rows > 0) chunk_rows = std::min(chunk_rows, opts->chunk_rows);
@@ -328,7 +333,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         const void *src = (k & 1) ? tmp_hori2 : tmp_hori;
         Ev &e = evs[ev_of[(size_t)k]];
         if (hipStreamWaitEvent(st_copy, e.c, 0) != hipSuccess ||
-            hipMemcpyAsync(hori_buffer + (size_t)rb * dim_in_1 * azim_num, src, (size_t)(re - rb) * row_bytes,
+            hipMemcpyAsync(hori_row0 + (size_t)rb * dim_in_1 * azim_num, src, (size_t)(re - rb) * row_bytes,
                            hipMemcpyDeviceToHost, st_copy) != hipSuccess ||
             hipEventRecord(e.d, st_copy) != hipSuccess)
             return set_error(HZ_ERR_HIP, "copy of the horizon chunk failed: %s", hipGetErrorString(hipGetLastError()));
@@ -750,6 +755,19 @@ int hz_debug_exclusive_scan(const uint32_t *in, uint32_t *out, size_t n, int dev
     return rc;
 }
 
+int hz_debug_valu_peak(int device, int packed, int waves_per_simd, double *winst_per_s_per_simd,
+                       double *clock_ghz, int *simds) {
+    int rc = select_device(device);
+    if (rc) return rc;
+    return bench_valu_peak(packed, waves_per_simd, winst_per_s_per_simd, clock_ghz, simds);
+}
+
+int hz_debug_copy_peak(int device, size_t bytes, double *gbs) {
+    int rc = select_device(device);
+    if (rc) return rc;
+    return bench_copy_peak(bytes, gbs);
+}
+
 // ---------------------------------------------------------------------------------------
 // slope and input preparation (hz_prep.hip)
 // ---------------------------------------------------------------------------------------
@@ -916,6 +934,7 @@ int hz_terrain_initialise(hz_terrain *terrain, const float *vert_grid, int dem_d
     if (!terrain) return set_error(HZ_ERR_ARG, "terrain is NULL");
     Terrain *t = reinterpret_cast<Terrain *>(terrain);
     terrain_release_arrays(t);
+    HZ_HIP(hipSetDevice(t->device));
     hz_scene *scene = nullptr;
     // no simplified outer TIN in the shadow scene: shadow_comp.cpp:198-298
     int rc = hz_scene_create(vert_grid, dem_dim_0, dem_dim_1, geom_type, nullptr, 0, nullptr, 0, t->device,
@@ -938,6 +957,10 @@ int hz_terrain_initialise_scene(hz_terrain *terrain, const hz_scene *scene, int 
     terrain_release_arrays(t);
     t->scene = const_cast<Scene *>(reinterpret_cast<const Scene *>(scene));
     t->owns_scene = false;
+    // the terrain lives on the scene's GPU: its per-cell arrays are allocated there and its kernels run on the
+    // scene's stream (a Terrain created for another ordinal follows the scene)
+    t->device = t->scene->device;
+    HZ_HIP(hipSetDevice(t->device));
     int rc = terrain_init_common(t, offset_0, offset_1, vec_tilt, vec_norm, dim_in_0, dim_in_1, surf_enl_fac,
                                  elevation, mask, sw_dir_cor_fill, ang_max, refrac_cor);
     if (rc) terrain_release_arrays(t);

@@ -158,6 +158,10 @@ int radix_sort_pairs_u32(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, u
                          uint32_t *temp, hipStream_t st);
 int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *temp, hipStream_t st);
 
+// hz_bench.hip: machine calibration kernels (current device)
+int bench_valu_peak(int packed, int waves_per_simd, double *winst_per_s_per_simd, double *clock_ghz, int *simds);
+int bench_copy_peak(size_t bytes, double *gbs);
+
 // hz_prep.hip (device pointers)
 int prep_slope(int which, const float *x, const float *y, const float *z, int len_0, int len_1,
                const float *rot_mat, int output_rot, float *vec_tilt, hipStream_t st);

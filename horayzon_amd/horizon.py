@@ -141,6 +141,8 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
     opts.skip_hori = 1 if svf_only else 0
     opts.count_work = int(bool(count_work))
     if rows is not None:
+        if len(rows) != 2 or not (0 <= int(rows[0]) < int(rows[1]) <= dim_in_0):
+            raise ValueError("'rows' must be (begin, end) with 0 <= begin < end <= %d" % dim_in_0)
         opts.row_begin, opts.row_end = int(rows[0]), int(rows[1])
     svf = None
     if svf_vec_tilt is not None:

@@ -116,6 +116,7 @@ class Terrain:
                 sw_dir_cor_fill, ang_max, int(refrac_cor), C.byref(st))
         else:
             self._scene = scene   # keep the borrowed scene alive
+            self.device = scene.device   # the terrain follows the scene's GPU (hz_terrain_initialise_scene)
             rc = L.hz_terrain_initialise_scene(
                 self._h, scene._h, offset_0, offset_1, ptr(vec_tilt), ptr(vec_norm),
                 vec_tilt.shape[0], vec_tilt.shape[1], ptr(surf_enl_fac), ptr(elevation),

@@ -39,8 +39,10 @@ extern "C" {
 typedef struct hz_opts {
     int32_t device;        /* HIP device ordinal                               */
     int32_t verbose;       /* 1: print the reference's stdout report           */
-    int32_t row_begin;     /* inner-domain row slab [row_begin, row_end) to    */
-    int32_t row_end;       /*   compute; row_end <= 0 means dim_in_0           */
+    int32_t row_begin;     /* inner-domain row slab [row_begin, row_end) to compute: row_begin <= 0 means 0,      */
+    int32_t row_end;       /*   row_end <= 0 or > dim_in_0 means dim_in_0 (so a zeroed struct = whole domain);   */
+                           /*   an empty slab (row_begin >= row_end after that) is an error.  The Python mirror  */
+                           /*   validates 0 <= begin < end <= dim_in_0 before it gets here                       */
     int32_t top_nodes;     /* > 0: stage that many top-of-tree BVH nodes in LDS (guess_constant;   */
                            /*   measured 2 % slower than L1 reads, so <= 0 means none)            */
     int32_t regroup;       /* wave regroup threshold in lanes (-1 auto)        */
@@ -57,7 +59,10 @@ typedef struct hz_opts {
                            /*   workgroups per CU.  Rays that need more are detected and the call  */
                            /*   is repeated with the worst case (3 per tree level): results never  */
                            /*   depend on it                                                       */
-    int32_t reserved;
+    int32_t hori_is_slab;  /* 0: hori_buffer addresses inner-domain row 0 (reference layout, f32[dim_in_0][..]);  */
+                           /*   1: hori_buffer addresses row_begin, i.e. it holds only the slab                   */
+                           /*   f32[row_end - row_begin][dim_in_1][azim_num] -- the form for a resident HBM slab  */
+                           /*   buffer (no address outside the caller's allocation is ever formed by the caller)  */
 } hz_opts;
 
 /* Run-time self report (the quantities the reference prints,                  */
@@ -186,6 +191,13 @@ int hz_debug_sort_pairs(uint32_t *keys, uint32_t *vals, size_t n, int device);
 /* entries per lane of the LDS traversal stack for a tree of `height` 4-wide levels at residency level 0 / 1 / 2 */
 int hz_debug_stack_cap(int height, int other_lds_bytes, int override_entries, int level);
 int hz_debug_exclusive_scan(const uint32_t *in, uint32_t *out, size_t n, int device);
+/* Machine calibration for the roofline (bench.py, untimed section).  hz_debug_valu_peak: chains of      */
+/* independent v_fma_f32 (packed = 1: v_pk_fma_f32) with `waves_per_simd` resident waves -> wave-level    */
+/* VALU instructions per second and SIMD, the shader clock [GHz] and the number of SIMDs.                */
+/* hz_debug_copy_peak: float4 device-to-device copy of `bytes` -> read + write GB/s.                     */
+int hz_debug_valu_peak(int device, int packed, int waves_per_simd, double *winst_per_s_per_simd,
+                       double *clock_ghz, int *simds);
+int hz_debug_copy_peak(int device, size_t bytes, double *gbs);
 
 /* ------------------------------------------------------------------------- */
 /* Steps next to the path: slope and input preparation */

@@ -101,3 +101,25 @@ def random_config(rng, max_n=90):
         vs, nvs, ts, nts = outer_tin(g, margin=3.0 * span * 100.0, zval=100.0 + relief)
         par.update(vert_simp=vs, num_vert_simp=nvs, tri_ind_simp=ts, num_tri_simp=nts)
     return kw, par
+
+
+def fuzz_case(rng):
+    """One configuration of the gridded random sweep (tests/test_gpu_fuzz.py): random_config plus the
+    extras (row slab, chunked host output, tiny LDS stacks, fused SVF).  Consumes `rng` exactly as the
+    sweep does, so `scripts/stray/replay.py` can regenerate configuration k of a seed."""
+    kw, par = random_config(rng)
+    in0, in1 = kw["vec_norm"].shape[:2]
+    extra = {}
+    if rng.integers(3) == 0 and in0 > 2:                 # a row slab (the multi-GPU sharding unit)
+        r0 = int(rng.integers(0, in0 - 1))
+        extra["rows"] = (r0, int(rng.integers(r0 + 1, in0 + 1)))
+    if rng.integers(3) == 0:                             # streamed host output in small chunks
+        extra["_chunk_rows"] = int(rng.integers(1, 9))
+    if rng.integers(3) == 0:                             # tiny LDS stacks: overflow detection + retry
+        extra["_stack_entries"] = int(rng.integers(3, 13))
+    tilt = None
+    if rng.integers(3) == 0 and par["azim_num"] >= 2:   # fused sky view factor
+        a, b = rng.uniform(-0.4, 0.4, (in0, in1)), rng.uniform(-0.4, 0.4, (in0, in1))
+        tilt = np.stack([np.sin(b), -np.sin(a) * np.cos(b), np.cos(a) * np.cos(b)], axis=2).astype(np.float32)
+        extra["svf_vec_tilt"] = tilt
+    return kw, par, extra, tilt

@@ -14,21 +14,8 @@ def test_random_configurations(hip, orc):
     n = int(os.environ.get("HZ_FUZZ_N", "24"))
     rng = np.random.default_rng(int(os.environ.get("HZ_FUZZ_SEED", "20260928")))
     for it in range(n):
-        kw, par = cases.random_config(rng)
+        kw, par, extra, tilt = cases.fuzz_case(rng)
         in0, in1 = kw["vec_norm"].shape[:2]
-        extra = {}
-        if rng.integers(3) == 0 and in0 > 2:                 # a row slab (the multi-GPU sharding unit)
-            r0 = int(rng.integers(0, in0 - 1))
-            extra["rows"] = (r0, int(rng.integers(r0 + 1, in0 + 1)))
-        if rng.integers(3) == 0:                             # streamed host output in small chunks
-            extra["_chunk_rows"] = int(rng.integers(1, 9))
-        if rng.integers(3) == 0:                             # tiny LDS stacks: overflow detection + retry
-            extra["_stack_entries"] = int(rng.integers(3, 13))
-        tilt = None
-        if rng.integers(3) == 0 and par["azim_num"] >= 2:   # fused sky view factor
-            a, b = rng.uniform(-0.4, 0.4, (in0, in1)), rng.uniform(-0.4, 0.4, (in0, in1))
-            tilt = np.stack([np.sin(b), -np.sin(a) * np.cos(b), np.cos(a) * np.cos(b)], axis=2).astype(np.float32)
-            extra["svf_vec_tilt"] = tilt
         out = hip.horizon.horizon_gridded(**kw, **par, **extra)
         h_gpu, a_gpu = out[0], out[1]
         st = hip.horizon.last_stats
