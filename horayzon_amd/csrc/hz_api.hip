@@ -417,12 +417,18 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         stats->elev_num = tb.elev_num; stats->bvh_height = sc->hdr.height; stats->scene_bytes = sc->hdr.total_bytes;
         stats->stack_retries += (uint64_t)retries;
     }
-    if (opts && opts->verbose) {   // the reference's report, horizon_comp.cpp:692-700, 805-810
+    if (opts && opts->verbose) {   // the reference's report, horizon_comp.cpp:673-700, 805-810 (same lines, same order)
+        static const char *alg_name[3] = {"discrete_sampling", "binary search", "guess horizon from previous azimuth direction"};
+        printf("Horizon detection algorithm: %s\n", alg_name[alg]);
         printf("Number of grid cells for which horizon is computed: %llu \n", cnt[4]);
+        printf("Fraction of total number of grid cells: %g %%\n", (double)((float)cnt[4] / (float)slab_cells * 100.0f));
+        printf("Total memory required for horizon output: %g GB\n",
+               (double)(((float)dim_in_0 * (float)dim_in_1 * (float)azim_num * 4.0f) / 1.0e9f));
         printf("Ray tracing time: %g s\n", (double)ms * 1e-3);
         printf("Number of rays shot: %llu\n", cnt[0]);
-        if (cnt[4]) printf("Average number of rays per location and azimuth: %.2f \n",
-                           (double)cnt[0] / ((double)cnt[4] * azim_num));
+        printf("Average number of rays per location and azimuth: %.2f \n",
+               cnt[4] ? (double)((float)cnt[0] / (float)(cnt[4] * (unsigned long long)azim_num)) : 0.0);
+        fflush(stdout);
     }
     return HZ_OK;
 }
@@ -613,19 +619,43 @@ int hz_horizon_gridded(const float *vert_grid, int dem_dim_0, int dem_dim_1, con
                        float elev_ang_low_lim, const uint8_t *mask, float hori_fill, float ray_org_elev,
                        const hz_opts *opts, hz_stats *stats) {
     Timer t; t.start();
+    const bool verbose = opts && opts->verbose;
+    if (verbose) {   // horizon_comp.cpp:643-645 (the engine named there is Embree)
+        printf("--------------------------------------------------------\n");
+        printf("Horizon computation with libhorayzon_hip (LBVH on MI355X)\n");
+        printf("--------------------------------------------------------\n");
+    }
     hz_scene *scene = nullptr;
     hz_stats local;
     memset(&local, 0, sizeof(local));
     int rc = hz_scene_create(vert_grid, dem_dim_0, dem_dim_1, geom_type, vert_simp, num_vert_simp,
                              tri_ind_simp, num_tri_simp, opts ? opts->device : 0, &scene, &local);
     if (rc) return rc;
-    if (opts && opts->verbose) printf("BVH build time: %g s\n", local.t_bvh_s);
+    if (verbose) {   // horizon_comp.cpp:113-114, :133-135 / :156-158 / :177, :201-203, :227, :664
+        printf("DEM dimensions: (%d, %d) \n", dem_dim_0, dem_dim_1);
+        printf("Number of vertices: %d \n", dem_dim_0 * dem_dim_1);
+        const int nq = (dem_dim_0 - 1) * (dem_dim_1 - 1);
+        if (strcmp(geom_type, "triangle") == 0) { printf("Selected geometry type: triangle\n"); printf("Number of triangles: %d \n", nq * 2); }
+        else if (strcmp(geom_type, "quad") == 0) { printf("Selected geometry type: quad\n"); printf("Number of quads: %d \n", nq); }
+        else printf("Selected geometry type: grid\n");
+        if (num_vert_simp >= 3) {
+            printf("Add triangles for outer simplified domain\n");
+            printf("- number of verties: %d \n", num_vert_simp);
+            printf("- number of triangles: %d \n", num_tri_simp);
+        }
+        printf("BVH build time: %g s\n", local.t_bvh_s);
+        printf("Total initialisation time: %g s\n", t.stop());
+    }
     rc = hz_horizon_gridded_scene(scene, vec_norm, vec_north, offset_0, offset_1, hori_buffer, dim_in_0,
                                   dim_in_1, azim_num, dist_search, hori_acc, ray_algorithm,
                                   elev_ang_low_lim, mask, hori_fill, ray_org_elev, opts, &local);
     hz_scene_destroy(scene);   // the reference also releases the scene per call, horizon_comp.cpp:813-814
     local.t_total_s = t.stop();
-    if (opts && opts->verbose) printf("Total run time: %g s\n", local.t_total_s);
+    if (verbose) {   // :818-820
+        printf("Total run time: %g s\n", local.t_total_s);
+        printf("--------------------------------------------------------\n");
+        fflush(stdout);
+    }
     if (stats) *stats = local;
     return rc;
 }

@@ -1,0 +1,150 @@
+/* hz_crmath.h -- the five float libm calls of the refraction branch (shadow_comp.cpp:135-159, :430-446:
+ * acos, tan, pow, cos, sin on float arguments = the float overloads) as self-contained functions.
+ *
+ * Why not the platform's libm: the reference's result depends on it.  glibc 2.35's acosf / tanf are not
+ * correctly rounded (0.25 % / 2 % of the arguments this path uses are off by one float ulp, measured by
+ * tests/test_oracle.py::test_crmath_*), they come in FMA and non-FMA builds selected at run time, and other
+ * platforms ship other routines -- there is no single "reference value" to be bit-equal to.  The contract
+ * here is the CORRECTLY ROUNDED float result.  Each function evaluates in float64 with plain + - * / sqrt in
+ * a fixed order (both users compile with -ffp-contract=off) to a relative error < 1e-14 and rounds once, so
+ *   - the HIP kernels and the CPU oracle, which both include this header, agree bit for bit by construction;
+ *   - the result is the correctly rounded float except when the exact value lies within 1e-14 (relative) of a
+ *     rounding boundary (about 1 argument in 1e7).
+ * Only the argument ranges of this path are covered accurately: acos [-1, 1]; tan [0, 1.6] rad; sin / cos
+ * |x| <= pi/4 (here |x| < 0.02); pow base > 0 with |y log x| < 700.
+ */
+#ifndef HZ_CRMATH_H
+#define HZ_CRMATH_H
+
+#ifdef __HIPCC__
+#define HZ_CRM __host__ __device__ static inline
+#else
+#define HZ_CRM static inline
+#endif
+
+#define HZ_CRM_PI_HI 3.141592653589793116      /* double nearest to pi          */
+#define HZ_CRM_PI_LO 1.2246467991473532e-16    /* pi - HZ_CRM_PI_HI             */
+#define HZ_CRM_LN2_HI 0.6931471803691238       /* ln 2, upper 33 bits           */
+#define HZ_CRM_LN2_LO 1.9082149292705877e-10   /* ln 2 - HZ_CRM_LN2_HI          */
+
+/* sin(r), cos(r) for |r| <= pi/4: Taylor series, 11 / 11 terms (remainder < 2e-18) */
+HZ_CRM double hz_crm_sin_k(double r) {
+    const double z = r * r;
+    double p = -1.0 / 51090942171709440000.0;                 /* -1/21! */
+    p = p * z + 1.0 / 121645100408832000.0;                    /*  1/19! */
+    p = p * z - 1.0 / 355687428096000.0;                       /* -1/17! */
+    p = p * z + 1.0 / 1307674368000.0;                         /*  1/15! */
+    p = p * z - 1.0 / 6227020800.0;                            /* -1/13! */
+    p = p * z + 1.0 / 39916800.0;                              /*  1/11! */
+    p = p * z - 1.0 / 362880.0;                                /* -1/9!  */
+    p = p * z + 1.0 / 5040.0;                                  /*  1/7!  */
+    p = p * z - 1.0 / 120.0;                                   /* -1/5!  */
+    p = p * z + 1.0 / 6.0;                                     /*  1/3!  */
+    return r - (r * z) * p;
+}
+HZ_CRM double hz_crm_cos_k(double r) {
+    const double z = r * r;
+    double p = 1.0 / 2432902008176640000.0;                    /*  1/20! */
+    p = p * z - 1.0 / 6402373705728000.0;                      /* -1/18! */
+    p = p * z + 1.0 / 20922789888000.0;                        /*  1/16! */
+    p = p * z - 1.0 / 87178291200.0;                           /* -1/14! */
+    p = p * z + 1.0 / 479001600.0;                             /*  1/12! */
+    p = p * z - 1.0 / 3628800.0;                               /* -1/10! */
+    p = p * z + 1.0 / 40320.0;                                 /*  1/8!  */
+    p = p * z - 1.0 / 720.0;                                   /* -1/6!  */
+    p = p * z + 1.0 / 24.0;                                    /*  1/4!  */
+    p = p * z - 0.5;                                           /* -1/2!  */
+    return 1.0 + z * p;
+}
+
+HZ_CRM float hz_crm_sinf(float x) { return (float)hz_crm_sin_k((double)x); }
+HZ_CRM float hz_crm_cosf(float x) { return (float)hz_crm_cos_k((double)x); }
+
+/* tan on [0, ~pi/2 + 0.03]: direct below pi/4, cotangent of the complement above (the float argument makes
+ * pi/2 - x exact to 1e-16 absolute, and |pi/2 - x| >= 4e-8 for every float x) */
+HZ_CRM float hz_crm_tanf(float xf) {
+    const double x = (double)xf;
+    if (!(x == x)) return xf;
+    if (x < 0.0) return -hz_crm_tanf(-xf);
+    if (x <= 0.78539816339744828) return (float)(hz_crm_sin_k(x) / hz_crm_cos_k(x));
+    const double r = (0.5 * HZ_CRM_PI_HI - x) + 0.5 * HZ_CRM_PI_LO;     /* |r| <= pi/4 for x <= 3 pi/4 */
+    return (float)(hz_crm_cos_k(r) / hz_crm_sin_k(r));
+}
+
+/* asin(t) for |t| <= 0.5: t + t^3 * sum c_n t^(2n), c_n = (2n+1)!! / ((2n+2)!! (2n+3)); 26 terms, remainder < 1e-17 */
+HZ_CRM double hz_crm_asin_k(double t) {
+    const double z = t * t;
+    double c[26];
+    double num = 1.0;        /* (2n+1)!! / (2n+2)!! built incrementally */
+    for (int n = 0; n < 26; n++) {
+        num = num * (double)(2 * n + 1) / (double)(2 * n + 2);
+        c[n] = num / (double)(2 * n + 3);
+    }
+    double p = c[25];
+    for (int n = 24; n >= 0; n--) p = p * z + c[n];
+    return t + (t * z) * p;
+}
+
+HZ_CRM float hz_crm_acosf(float xf) {
+    const double x = (double)xf;
+    if (!(x >= -1.0 && x <= 1.0)) return (float)((x - x) / (x - x));   /* NaN, as acosf outside [-1, 1] */
+    if (x >= -0.5 && x <= 0.5) return (float)((0.5 * HZ_CRM_PI_HI - hz_crm_asin_k(x)) + 0.5 * HZ_CRM_PI_LO);
+    if (x > 0.5) return (float)(2.0 * hz_crm_asin_k(__builtin_sqrt((1.0 - x) * 0.5)));
+    return (float)((HZ_CRM_PI_HI - 2.0 * hz_crm_asin_k(__builtin_sqrt((1.0 + x) * 0.5))) + HZ_CRM_PI_LO);
+}
+
+/* 2^k as a double for -1022 <= k <= 1023, built from its bit pattern */
+HZ_CRM double hz_crm_pow2i(int k) {
+    union { unsigned long long u; double d; } v;
+    v.u = (unsigned long long)(k + 1023) << 52;
+    return v.d;
+}
+
+/* log(x), x > 0 finite: x = m 2^e with m in [0.75, 1.5); log m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.2 */
+HZ_CRM double hz_crm_log(double x) {
+    union { double d; unsigned long long u; } v;
+    v.d = x;
+    int e = (int)((v.u >> 52) & 0x7ff) - 1023;
+    if (e == -1023) {                                   /* subnormal: scale up */
+        v.d = x * 18014398509481984.0;                  /* 2^54 */
+        e = (int)((v.u >> 52) & 0x7ff) - 1023 - 54;
+    }
+    v.u = (v.u & 0x000fffffffffffffull) | 0x3ff0000000000000ull;   /* m in [1, 2) */
+    double m = v.d;
+    if (m >= 1.5) { m = m * 0.5; e = e + 1; }
+    const double s = (m - 1.0) / (m + 1.0);
+    const double z = s * s;
+    double p = 1.0 / 37.0;
+    for (int n = 35; n >= 3; n -= 2) p = p * z + 1.0 / (double)n;
+    const double lm = 2.0 * (s + (s * z) * p);
+    return ((double)e * HZ_CRM_LN2_HI + lm) + (double)e * HZ_CRM_LN2_LO;
+}
+
+/* exp(t) for |t| < 700: t = k ln2 + r, |r| <= 0.35; Taylor to r^17 */
+HZ_CRM double hz_crm_exp(double t) {
+    const double kf = __builtin_floor(t * 1.4426950408889634 + 0.5);
+    const int k = (int)kf;
+    const double r = (t - kf * HZ_CRM_LN2_HI) - kf * HZ_CRM_LN2_LO;
+    double p = 1.0 / 355687428096000.0;                  /* 1/17! */
+    const double inv[16] = {1.0 / 20922789888000.0, 1.0 / 1307674368000.0, 1.0 / 87178291200.0, 1.0 / 6227020800.0,
+                            1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0,
+                            1.0 / 5040.0, 1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5, 1.0};
+    for (int n = 0; n < 16; n++) p = p * r + inv[n];
+    return (1.0 + r * p) * hz_crm_pow2i(k);
+}
+
+/* powf for the pressure formula (base = temperature ratio near 1, exponent 5.26): special cases as C99 pow
+ * for the inputs this path can produce (non-positive or non-finite base) */
+HZ_CRM float hz_crm_powf(float xf, float yf) {
+    const double x = (double)xf, y = (double)yf;
+    if (!(x == x) || !(y == y)) return xf + yf;
+    if (x < 0.0) return (float)((x - x) / (x - x));       /* negative base, non-integer exponent: NaN */
+    if (x == 0.0) return (y > 0.0) ? 0.0f : (float)(1.0 / (x * x));
+    if (x > 1.7976931348623157e308) return (y > 0.0) ? xf : 0.0f;
+    const double t = y * hz_crm_log(x);
+    if (t > 700.0) return (float)(1.0e300 * 1.0e300);
+    if (t < -700.0) return 0.0f;
+    return (float)hz_crm_exp(t);
+}
+
+#endif /* HZ_CRMATH_H */

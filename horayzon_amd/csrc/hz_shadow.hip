@@ -6,6 +6,7 @@
 // shadow_comp.cpp:430-446).  Same tile / XCD mapping and LDS staging as the horizon
 // kernel; the BVH is persistent in the Terrain handle (built once, :318-380).
 #include "hz_internal.h"
+#include "hz_crmath.h"
 
 namespace hz {
 
@@ -28,14 +29,14 @@ struct ShadowParams {
     unsigned long long *counters;
 };
 
-// float-precision libm calls of the reference (acos/tan/pow/cos/sin on float arguments
-// resolve to the float overloads, shadow_comp.cpp:19) evaluated through double and
-// rounded once: agrees with glibc's float routines to <= 1 ulp.
-__device__ __forceinline__ float f_acos(float x) { return (float)acos((double)x); }
-__device__ __forceinline__ float f_tan(float x) { return (float)tan((double)x); }
-__device__ __forceinline__ float f_cos(float x) { return (float)cos((double)x); }
-__device__ __forceinline__ float f_sin(float x) { return (float)sin((double)x); }
-__device__ __forceinline__ float f_pow(float x, float y) { return (float)pow((double)x, (double)y); }
+// The float libm calls of the reference's refraction branch (acos / tan / pow / cos / sin on float arguments
+// resolve to the float overloads, shadow_comp.cpp:19): self-contained correctly rounded versions shared with
+// the CPU oracle (hz_crmath.h), so shadow codes and sw_dir_cor are bit-identical with refraction too.
+__device__ __forceinline__ float f_acos(float x) { return hz_crm_acosf(x); }
+__device__ __forceinline__ float f_tan(float x) { return hz_crm_tanf(x); }
+__device__ __forceinline__ float f_cos(float x) { return hz_crm_cosf(x); }
+__device__ __forceinline__ float f_sin(float x) { return hz_crm_sinf(x); }
+__device__ __forceinline__ float f_pow(float x, float y) { return hz_crm_powf(x, y); }
 
 __device__ __forceinline__ float deg2rad_f(float a) { return (float)(((double)a / 180.0) * 3.14159265358979323846); }
 __device__ __forceinline__ float rad2deg_f(float a) { return (float)(((double)a / 3.14159265358979323846) * 180.0); }

@@ -38,6 +38,43 @@
 #include <string.h>
 #include <stdio.h>
 #include <time.h>
+/* The five float libm calls of the refraction branch (shadow_comp.cpp:135-159, :430-446) go through
+ * hz_crmath.h: self-contained, correctly rounded, shared with the HIP kernels (the platform's float routines
+ * are not a fixed target -- see that header).  orc_set_libm(1) switches this file to the platform's
+ * acosf / tanf / powf / cosf / sinf so that a test can measure how much of the output depends on them. */
+#include "../horayzon_amd/csrc/hz_crmath.h"
+static int g_platform_libm = 0;
+void orc_set_libm(int platform) { g_platform_libm = platform; }
+static inline float r_acosf(float x) { return g_platform_libm ? acosf(x) : hz_crm_acosf(x); }
+static inline float r_tanf(float x) { return g_platform_libm ? tanf(x) : hz_crm_tanf(x); }
+static inline float r_cosf(float x) { return g_platform_libm ? cosf(x) : hz_crm_cosf(x); }
+static inline float r_sinf(float x) { return g_platform_libm ? sinf(x) : hz_crm_sinf(x); }
+static inline float r_powf(float x, float y) { return g_platform_libm ? powf(x, y) : hz_crm_powf(x, y); }
+/* exhaustive comparison of hz_crmath.h with (float) of the platform's float64 routine over the float range
+ * [lo, hi] (which: 0 acos, 1 tan, 2 cos, 3 sin, 4 pow(x, y)); out[0] = values, out[1] = differing from the
+ * rounded float64 result, out[2] = differing from the platform's float routine */
+void orc_crmath_sweep(int which, float lo, float hi, float y, uint64_t *out) {
+    uint32_t a, b;
+    memcpy(&a, &lo, 4); memcpy(&b, &hi, 4);
+    uint64_t n = 0, bad_d = 0, bad_f = 0;
+#pragma omp parallel for reduction(+ : n, bad_d, bad_f)
+    for (int64_t u = (int64_t)a; u <= (int64_t)b; u++) {
+        const uint32_t uu = (uint32_t)u;
+        float x, rc, rd, rf;
+        memcpy(&x, &uu, 4);
+        switch (which) {
+            case 0: rc = hz_crm_acosf(x); rd = (float)acos((double)x); rf = acosf(x); break;
+            case 1: rc = hz_crm_tanf(x); rd = (float)tan((double)x); rf = tanf(x); break;
+            case 2: rc = hz_crm_cosf(x); rd = (float)cos((double)x); rf = cosf(x); break;
+            case 3: rc = hz_crm_sinf(x); rd = (float)sin((double)x); rf = sinf(x); break;
+            default: rc = hz_crm_powf(x, y); rd = (float)pow((double)x, (double)y); rf = powf(x, y); break;
+        }
+        n++;
+        if (memcmp(&rc, &rd, 4) != 0 && !(rc != rc && rd != rd)) bad_d++;
+        if (memcmp(&rc, &rf, 4) != 0 && !(rc != rc && rf != rf)) bad_f++;
+    }
+    out[0] = n; out[1] = bad_d; out[2] = bad_f;
+}
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -824,7 +861,7 @@ static inline void vec_unit(float *x, float *y, float *z) {       /* :96-106   *
 
 static inline void vec_rot(float kx, float ky, float kz, float theta,
                            float *vx, float *vy, float *vz) {     /* :109-132  */
-    const float ct = cosf(theta), st = sinf(theta);
+    const float ct = r_cosf(theta), st = r_sinf(theta);
     const float part = (float)((double)((kx * *vx + ky * *vy) + kz * *vz) * (1.0 - (double)ct));
     const float rx = (*vx * ct + (ky * *vz - kz * *vy) * st) + kx * part;
     const float ry = (*vy * ct + (kz * *vx - kx * *vz) * st) + ky * part;
@@ -835,7 +872,7 @@ static inline void vec_rot(float kx, float ky, float kz, float theta,
 static inline float atmos_refrac(float elev_ang_true, float temp, float pressure) { /* :135-159 */
     const float lower = -1.0f, upper = 90.0f;
     elev_ang_true = fmaxf(lower, fminf(elev_ang_true, upper));
-    float refrac_cor = (float)(1.02 / (double)tanf(deg2rad_f(
+    float refrac_cor = (float)(1.02 / (double)r_tanf(deg2rad_f(
         (float)((double)elev_ang_true + 10.3 / ((double)elev_ang_true + 5.11)))));
     refrac_cor = (float)((double)refrac_cor + 0.0019279);
     refrac_cor = (float)((double)refrac_cor * (((double)pressure / 101.0) * (283.0 / (273.0 + (double)temp))));
@@ -907,9 +944,9 @@ static void terrain_run(const orc_terrain *t, const float *sun_position, int whi
             vec_unit(&sun_x, &sun_y, &sun_z);
             float dot_prod_ns = (norm_x * sun_x + norm_y * sun_y) + norm_z * sun_z;
             if (t->refrac == 1) {                                  /* :430-446  */
-                const float elev_ang_true = (float)(90.0 - (double)rad2deg_f(acosf(dot_prod_ns)));
+                const float elev_ang_true = (float)(90.0 - (double)rad2deg_f(r_acosf(dot_prod_ns)));
                 const float temperature = t->temperature_ref - (t->lapse_rate * t->elev[ind_arr]);
-                const float pressure = t->pressure_ref * powf(temperature / t->temperature_ref, t->expo);
+                const float pressure = t->pressure_ref * r_powf(temperature / t->temperature_ref, t->expo);
                 const float refrac_cor = atmos_refrac(elev_ang_true, K2degC_f(temperature), pressure);
                 float k_x = sun_y * norm_z - sun_z * norm_y;
                 float k_y = sun_z * norm_x - sun_x * norm_z;

@@ -20,11 +20,8 @@ _lib = None
 
 
 def build(force=False):
-    """Compile libhz_oracle.so with gcc (oracle/Makefile)."""
-    src = os.path.join(_HERE, "hz_oracle.c")
-    if (force or not os.path.exists(_LIB_PATH)
-            or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
-        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libhz_oracle.so"])
+    """Compile libhz_oracle.so with gcc (oracle/Makefile tracks hz_oracle.c and the shared hz_crmath.h)."""
+    subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []) + ["libhz_oracle.so"])
     return _LIB_PATH
 
 
@@ -64,6 +61,8 @@ def lib():
         L.orc_terrain_sw_dir_cor.argtypes = [C.c_void_p, fp, fp, C.c_int, u64p]
         L.orc_sky_view_factor.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, fp]
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_libm.argtypes = [C.c_int]
+        L.orc_crmath_sweep.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, u64p]
         _lib = L
     return _lib
 
@@ -85,6 +84,21 @@ MODE_BVH, MODE_BRUTE, MODE_BRUTE_F64 = 0, 1, 2
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def set_libm(platform):
+    """False (default): the refraction branch uses the shared correctly rounded hz_crmath.h routines;
+    True: the platform's acosf / tanf / powf / cosf / sinf (to measure how much depends on them)."""
+    lib().orc_set_libm(int(bool(platform)))
+
+
+def crmath_sweep(which, lo, hi, y=0.0):
+    """Exhaustive sweep of hz_crmath.h over the floats in [lo, hi] (which: "acos", "tan", "cos", "sin", "pow").
+    Returns (values, differing from the rounded float64 libm result, differing from the platform float routine)."""
+    out = np.zeros(3, np.uint64)
+    lib().orc_crmath_sweep(("acos", "tan", "cos", "sin", "pow").index(which), lo, hi, y,
+                           out.ctypes.data_as(C.POINTER(C.c_uint64)))
+    return int(out[0]), int(out[1]), int(out[2])
 
 
 def tables(azim_num, hori_acc, elev_ang_low_lim, dist_search):

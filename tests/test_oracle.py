@@ -296,3 +296,53 @@ def test_shadow_consistent_with_horizon(orc):
     t.shadow(sun, sh)
     clear = np.abs(h[:, :, k] - sun_el) > np.deg2rad(0.3)       # skip cells within the accuracy band
     assert np.array_equal(sh[clear] == 2, h[:, :, k][clear] > sun_el)
+
+
+# ---------------------------------------------------------------------------------------
+# the refraction branch's float libm calls (hz_crmath.h, shared by the HIP kernels and the oracle)
+# ---------------------------------------------------------------------------------------
+def test_crmath_is_the_correctly_rounded_float(orc):
+    """Exhaustive over the argument ranges the path uses (a few 1e8 floats): hz_crmath.h equals the float64
+    libm result rounded once -- i.e. the correctly rounded float -- for every argument, while the platform's
+    float routines (glibc 2.35 here) are NOT a fixed target: acosf / tanf differ from it for 0.2 % / 2 %."""
+    exp = np.float32(9.81) / (np.float32(287.0) * np.float32(0.0065))           # shadow_comp.cpp:353-354
+    for which, lo, hi, y in (("acos", 0.5, 1.0, 0.0), ("acos", -1.0, -0.5, 0.0), ("acos", 0.30, 0.52, 0.0),
+                             ("acos", -0.52, -0.30, 0.0), ("acos", 1.0e-20, 1.0e-3, 0.0),
+                             ("tan", 0.02, 1.62, 0.0), ("cos", 1.0e-12, 0.02, 0.0), ("sin", 1.0e-12, 0.02, 0.0),
+                             ("pow", 0.6, 1.1, float(exp))):
+        if lo < 0:      # floats are swept by bit pattern: negative ranges run from -|hi| "up" to -|lo|
+            n, bad_d, bad_f = orc.crmath_sweep(which, hi, lo, y)
+        else:
+            n, bad_d, bad_f = orc.crmath_sweep(which, lo, hi, y)
+        assert n > 100000, (which, lo, hi, n)
+        assert bad_d == 0, "%s [%g, %g]: %d of %d differ from the rounded float64 result" % (which, lo, hi, bad_d, n)
+    # specials the kernel can meet: |dot| marginally above 1, non-positive temperature ratio
+    assert orc.crmath_sweep("acos", 1.0, 1.0)[1] == 0 and orc.crmath_sweep("acos", 1.0000001, 1.0000002)[1] == 0
+    assert orc.crmath_sweep("pow", 0.0, 0.0, 5.25)[1] == 0
+
+
+def test_refraction_depends_little_on_the_platform_libm(orc):
+    """With the platform's float routines instead of hz_crmath.h a handful of cells per million change: the
+    reference's own output moves by that much from one libm to the next."""
+    g = cases.c2_hill(height=1500.0)
+    vec_tilt, vec_norm, enl, elev, mask = cases.terrain_inputs(g)
+    from horayzon_amd import synth
+    suns, _, _ = synth.sun_positions(num=24)
+    suns = suns + np.array([5000.0, 5000.0, 0.0], np.float32)
+    t = orc.Terrain()
+    t.initialise(g["vert_grid"], 200, 200, 10, 10, vec_tilt, vec_norm, enl, elev, mask, refrac_cor=True)
+    diff = tot = 0
+    worst = 0.0
+    try:
+        for s in range(suns.shape[0]):
+            a = np.empty(mask.shape, np.uint8); b = a.copy()
+            fa = np.empty(mask.shape, np.float32); fb = fa.copy()
+            orc.set_libm(False); t.shadow(suns[s], a); t.sw_dir_cor(suns[s], fa)
+            orc.set_libm(True); t.shadow(suns[s], b); t.sw_dir_cor(suns[s], fb)
+            diff += int((a != b).sum()); tot += a.size
+            both = (fa != 0) & (fb != 0)
+            if both.any():
+                worst = max(worst, float(np.abs(fa[both] / fb[both] - 1.0).max()))
+    finally:
+        orc.set_libm(False)
+    assert diff / tot <= 1.0e-4 and worst <= 2.0e-5, (diff, tot, worst)
