@@ -1,29 +1,32 @@
 #!/usr/bin/env python
 """bench.py -- horizon_gridded throughput on MI355X (BASELINE.json metric).
 
-Workload (N = 1): BASELINE.json config 3 -- 3601 x 3601 synthetic SRTM-like tile
-(1 arc-second spacing at 46 deg N, seeded fractal, integer metres), 16-cell ring,
-360 azimuth sectors, guess_constant, dist_search 50 km, hori_acc 0.25 deg, with the
-horizon array AND the fused sky view factor written to HBM.
+--workload c3 (default; the N = 1 headline): BASELINE.json config 3 -- 3601 x 3601 synthetic
+SRTM-like tile (1 arc-second spacing at 46 deg N, seeded fractal, integer metres), 16-cell ring,
+360 azimuth sectors, guess_constant, dist_search 50 km, hori_acc 0.25 deg, with the horizon array AND
+the fused sky view factor written to HBM.  A "step" is one pass of the hot path over one batch of
+grid cells: a slab of `--rows-per-step` inner-domain rows (512 x 3569 cells x 360 azimuths = 1.83 M
+cells, 6.6e8 output values, ~1.4e9 rays) against the full-tile LBVH.  The 3569 rows make 7 slabs (six
+of 512 rows and a ragged last one of 497); consecutive steps take consecutive slabs (wrapping), so the
+default K = 7 steps cover the whole tile exactly once.  Inputs (scene blob, per-cell frames, mask,
+tilt) are resident in HBM before the timed region and outputs stay in HBM; the library is called through
+its C ABI with device pointers (slab-local output buffers, opts.hori_is_slab).
+N > 1 (torch.distributed.run, one rank per GPU, RCCL): weak scaling -- rank 0 builds the scene and
+broadcasts the blob over xGMI once (set-up, untimed, like the BVH build); rank r then takes steps
+r K ... r K + K - 1 of the same slab sequence (no data-path collective); the SVF rows of every rank's
+last step are gathered on rank 0 inside the timed region.
 
-A "step" is one pass of the hot path over one batch of grid cells: a slab of
-`--rows-per-step` inner-domain rows (default 512 x 3569 cells x 360 azimuths = 1.83 M cells,
-6.6e8 output values, ~1.4e9 rays) against the full-tile LBVH.  Consecutive steps take
-consecutive slabs of the tile (wrapping around), so the default K = 7 steps cover the tile
-once.  (Slabs much smaller than the GPU's resident capacity of 262 k cells leave a tail:
-128-row steps run 17 % slower per cell.)  Inputs (scene blob, per-cell frames,
-mask, tilt) are resident in HBM before the timed region and outputs stay in HBM; the
-library is called through its C ABI with device pointers.
-
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): rank 0 builds the scene
-and broadcasts the blob over xGMI once (set-up, untimed -- like the BVH build); every rank
-then processes its own slabs with no data-path collective (weak scaling: per-GPU work is
-fixed); the per-rank SVF slabs are gathered at the end of the timed region.
+--workload c5 (BASELINE.json config 5, strong scaling): the 4 x 4 mosaic (14401 x 14401, 206 M cells),
+SVF-fused (the 298 GB horizon is never materialised), inner rows split by dist.row_slabs over WORLD_SIZE
+ranks after ONE broadcast of the scene blob; each rank computes its slab (chunked inside the library),
+the SVF is gathered on rank 0.  The timed region is the whole sharded job; `--steps` repeats it.
+Reports cells/s, scene_bcast_s and the measured load imbalance (slowest rank / mean rank).
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
 import sys
@@ -35,21 +38,50 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable
+KERNEL_SOURCES = ("hz_common.h", "hz_search.h", "hz_horizon.hip")   # what the traffic figure was measured for
+
+# wave-level VALU instructions per wave iteration of k_horizon<guess_constant> (calibrated against
+# SQ_INSTS_VALU of the PMC pass, profiles/<round>/valu_model.json)
+VALU_MODEL_DEFAULT = {"node_iter": 147.0, "leaf_iter": 218.0, "refill_iter": 160.0, "per_cell": 0.0}
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--workload", choices=("c3", "c5"), default="c3")
     ap.add_argument("--rows-per-step", type=int, default=512)
-    ap.add_argument("--tile", type=int, default=3601)
+    ap.add_argument("--tile", type=int, default=None, help="DEM size (3601 for c3, 14401 for c5)")
     ap.add_argument("--azim", type=int, default=360)
     ap.add_argument("--dist-search", type=float, default=50.0)
     ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the tile the CPU baseline computes (0: cores / 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-count", action="store_true", help="skip the counter pass (roofline.achieved becomes I/O only)")
+    ap.add_argument("--no-count", action="store_true", help="skip the counter pass (roofline is I/O only)")
+    ap.add_argument("--no-peaks", action="store_true", help="skip the machine calibration kernels")
     return ap.parse_args()
+
+
+def kernel_source_sha():
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "horayzon_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def machine_peaks(L, dev_index):
+    """VALU issue ceiling (wave-level instructions / s, all SIMDs) and float4 copy bandwidth, measured here."""
+    best, clk, simds = 0.0, C.c_double(0), C.c_int(0)
+    for w in (4, 8):
+        r = C.c_double(0)
+        if L.hz_debug_valu_peak(dev_index, 0, w, C.byref(r), C.byref(clk), C.byref(simds)) == 0:
+            best = max(best, r.value)
+    g = C.c_double(0)
+    L.hz_debug_copy_peak(dev_index, 1 << 30, C.byref(g))
+    return {"valu_winst_per_s": best * simds.value, "valu_winst_per_s_per_simd": best, "simds": simds.value,
+            "clock_ghz": clk.value, "cycles_per_wave_inst": (clk.value * 1e9 / best) if best else None,
+            "copy_gbs": g.value}
 
 
 def main():
@@ -59,39 +91,76 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
     import torch.distributed as dist
-    import horayzon_amd as hz
-    from horayzon_amd import _lib, synth
-    from horayzon_amd.dist import broadcast_scene, gather_rows
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
     torch.cuda.set_device(local_rank)
-    dev = "cuda:%d" % local_rank
     # HZ_FORCE_DIST=1 runs the multi-rank code path (RCCL broadcast of the scene, gather, all-reduce)
     # even with a single rank -- used to exercise it on a 1-GPU box
-    use_dist = world > 1 or bool(os.environ.get("HZ_FORCE_DIST"))
+    # (config 5 always runs the sharded code path: one rank is simply the N = 1 point of its scaling curve)
+    use_dist = world > 1 or bool(os.environ.get("HZ_FORCE_DIST")) or args.workload == "c5"
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
-    L = _lib.lib()
+        dist.init_process_group("nccl", device_id=torch.device("cuda:%d" % local_rank))
+    ctx = dict(args=args, world=world, rank=rank, local_rank=local_rank, use_dist=use_dist,
+               dev="cuda:%d" % local_rank)
+    out = run_c5(ctx) if args.workload == "c5" else run_c3(ctx)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
 
-    # ---- synthetic tile + scene (set-up, untimed) ----------------------------------------
-    n, off, A = args.tile, 16, args.azim
-    g = synth.fractal_tile(n=n, offset=off)
-    in0 = in1 = n - 2 * off
+
+def make_scene(ctx, g, n):
+    """Rank 0 builds the scene; with several ranks the blob is broadcast once (RCCL over xGMI)."""
+    import torch
+    import torch.distributed as dist
+    import horayzon_amd as hz
+    from horayzon_amd.dist import broadcast_scene
     t0 = time.time()
-    scene = hz.Scene.create(g["vert_grid"], n, n, device=local_rank) if rank == 0 else None
+    scene = hz.Scene.create(g["vert_grid"], n, n, device=ctx["local_rank"]) if ctx["rank"] == 0 else None
     t_build = time.time() - t0
     scene_stats = scene.stats if scene is not None else None
     t_bcast = 0.0
-    if use_dist:
+    if ctx["use_dist"]:
         torch.cuda.synchronize(); dist.barrier()
         t0 = time.time()
-        scene = broadcast_scene(scene, local_rank, src=0)
+        scene = broadcast_scene(scene, ctx["local_rank"], src=0)
         torch.cuda.synchronize(); dist.barrier()
         t_bcast = time.time() - t0
+    return scene, scene_stats, t_build, t_bcast
+
+
+def barrier(ctx):
+    import torch
+    import torch.distributed as dist
+    torch.cuda.synchronize()
+    if ctx["use_dist"]:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+# ------------------------------------------------------------------------------------------------
+# config 3: slab steps on the 3601^2 tile
+# ------------------------------------------------------------------------------------------------
+def run_c3(ctx):
+    import torch
+    import torch.distributed as dist
+    from horayzon_amd import _lib, synth
+    from horayzon_amd.dist import gather_rows
+    args, rank, world, dev = ctx["args"], ctx["rank"], ctx["world"], ctx["dev"]
+    L = _lib.lib()
+    n, off, A = args.tile or 3601, 16, args.azim
+    rps = args.rows_per_step
+    g = synth.fractal_tile(n=n, offset=off)
+    in0 = in1 = n - 2 * off
+    scene, scene_stats, t_build, t_bcast = make_scene(ctx, g, n)
     blob_ptr, blob_bytes = scene.blob()
+    n_slabs = (in0 + rps - 1) // rps                 # 7 for the 3601^2 tile: six of 512 rows + one of 497
+    steps = args.steps if args.steps is not None else n_slabs
+    warmup = args.warmup if args.warmup is not None else 1
 
     # per-cell inputs resident in HBM
     vec_tilt_h, _ = synth.tilt_from_planar_dem(g["x"], g["y"], g["z"], off)
@@ -99,67 +168,54 @@ def main():
     d_north = torch.zeros((in0, in1, 3), dtype=torch.float32, device=dev); d_north[..., 1] = 1.0
     d_mask = torch.ones((in0, in1), dtype=torch.uint8, device=dev)
     d_tilt = torch.from_numpy(vec_tilt_h).to(dev)
-    rps = args.rows_per_step
-    n_slabs = in0 // rps
     d_hori = torch.empty((rps, in1, A), dtype=torch.float32, device=dev)       # reused slab buffer
     d_svf = torch.full((in0, in1), float("nan"), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
 
     opts = _lib.hz_opts()
-    opts.device = local_rank
+    opts.device = ctx["local_rank"]
     opts.top_nodes = -1
     opts.regroup = -1
     opts.vec_tilt = d_tilt.data_ptr()
+    opts.hori_is_slab = 1                     # d_hori and the svf pointer below address the slab's first row
     stats = _lib.hz_stats()
 
-    def step(s, count=False):
-        # weak scaling: rank r walks the slabs of the tile starting at slab r, so with the default 6 steps
-        # every rank computes each of the 6 slabs exactly once (identical work per GPU for any N)
-        slab = (s + rank) % n_slabs
-        rb = slab * rps
-        opts.row_begin, opts.row_end = rb, rb + rps
+    def slab_of(v):
+        s = v % n_slabs
+        return s * rps, min(s * rps + rps, in0)
+
+    def step(v, st, count=False):
+        rb, re = slab_of(v)
+        opts.row_begin, opts.row_end = rb, re
         opts.count_work = int(count)
-        opts.svf = d_svf.data_ptr()
-        # the library indexes hori by global cell; hand it the slab buffer shifted back by rb rows
-        hori_ptr = d_hori.data_ptr() - 4 * rb * in1 * A
+        opts.svf = d_svf.data_ptr() + 4 * rb * in1
         rc = L.hz_horizon_gridded_scene(scene._h, d_norm.data_ptr(), d_north.data_ptr(), off, off,
-                                        hori_ptr, in0, in1, A, args.dist_search, 0.25, b"guess_constant",
-                                        -15.0, d_mask.data_ptr(), 0.0, 0.01, C.byref(opts), C.byref(stats))
+                                        d_hori.data_ptr(), in0, in1, A, args.dist_search, 0.25, b"guess_constant",
+                                        -15.0, d_mask.data_ptr(), 0.0, 0.01, C.byref(opts), C.byref(st))
         _lib.check(rc)
-        return rb
+        return rb, re
 
-    def barrier():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # ---- counter pass (untimed): BVH nodes / triangle tests per ray for the roofline -------
-    nodes_per_ray = tris_per_ray = None
+    # ---- counter pass (untimed): wave-level work of one slab for the roofline ----------------------
+    cw = None
     if rank == 0 and not args.no_count:
-        c = _lib.hz_stats()
-        opts.count_work = 1
-        saved = stats
-        stats = c
-        step(n_slabs // 2, count=True)
-        stats = saved
-        nodes_per_ray = c.nodes_visited / max(c.num_rays, 1)
-        tris_per_ray = c.tris_tested / max(c.num_rays, 1)
+        cw = _lib.hz_stats()
+        step(n_slabs // 2, cw, count=True)
+    peaks = machine_peaks(L, ctx["local_rank"]) if (rank == 0 and not args.no_peaks) else None
 
-    for w in range(args.warmup):
-        step(w)
-    barrier()
+    # weak scaling: rank r takes steps r K ... r K + K - 1 of the slab sequence (per-GPU work fixed)
+    base = rank * steps
+    for w in range(warmup):
+        step(base + w, _lib.hz_stats())
+    barrier(ctx)
     stats = _lib.hz_stats()
     t0 = time.perf_counter()
-    for s in range(args.steps):
-        step(args.warmup + s)
-    svf_full = None
-    if use_dist:    # final gather of the per-rank SVF rows touched in the last step (4 B / cell)
-        rb = (args.warmup + args.steps - 1 + rank) % n_slabs * rps
-        gather_rows(d_svf[rb:rb + rps], [(0, rps)] * world, dst=0)
-    barrier()
+    for s in range(steps):
+        rb, re = step(base + warmup + s, stats)
+    if ctx["use_dist"] and steps > 0:    # final gather of the SVF rows of every rank's last step (4 B / cell)
+        gather_rows(d_svf[rb:re], [(0, rps)] * world, dst=0)
+    barrier(ctx)
     elapsed = time.perf_counter() - t0
-    if use_dist:
+    if ctx["use_dist"]:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         tsum = t.clone()
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -172,67 +228,185 @@ def main():
     else:
         rays_total, cells_total = float(stats.num_rays), float(stats.num_cells)
         imbalance = 1.0
+    if rank != 0:
+        return None
 
-    if rank == 0:
-        # device-copy microbenchmark: what a plain HBM stream reaches on this box
-        src = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
-        dst = torch.empty_like(src)
-        dst.copy_(src); torch.cuda.synchronize()
-        tc0 = time.perf_counter()
-        for _ in range(10):
-            dst.copy_(src)
-        torch.cuda.synchronize()
-        copy_gbs = 10 * 2.0 * src.numel() / (time.perf_counter() - tc0) / 1e9
-        del src, dst
-        k_launch_s = stats.t_kernel_s / max(args.steps, 1)        # HIP events on the kernel's stream
-        rays_launch = stats.num_rays / max(args.steps, 1)
-        cells_launch = stats.num_cells / max(args.steps, 1)
-        # algorithmic bytes per launch: per-cell I/O + BVH traversal
-        b_io = (12 + 12 + 12 + 1 + 12 + 4) * cells_launch + 4.0 * A * cells_launch
-        b_trav = 0.0
-        if nodes_per_ray is not None:
-            b_trav = rays_launch * (nodes_per_ray * 64.0 + tris_per_ray * 24.0)
-        achieved = (b_io + b_trav) / k_launch_s / 1e9
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                if tj.get("rows_per_step") == rps and tj.get("tile") == n and tj.get("azim") == A:
-                    traffic = tj.get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "grid_cells_per_s (horizon_gridded, 360 azimuths, 3601^2 SRTM-like tile)",
-            "value": cells_total / elapsed,
-            "unit": "cells/s",
-            "mray_per_s": rays_total / elapsed / 1e6,
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "horizon_gridded guess_constant + fused SVF, %dx%d synthetic SRTM-like tile, "
-                                   "%d azimuths, dist_search %g km, slab of %d rows per step"
-                                   % (n, n, A, args.dist_search, rps),
-                       "cells_per_step": int(cells_launch), "rays_per_cell_azimuth": rays_launch / max(cells_launch * A, 1),
-                       "parallelism": "row-slab shard x%d, scene broadcast once" % world,
-                       "bvh_build_s": scene_stats["t_bvh_s"] if scene_stats else None,
-                       "scene_bytes": int(blob_bytes), "scene_bcast_s": t_bcast, "scene_create_wall_s": t_build,
-                       "load_imbalance_max_over_mean": imbalance, "stack_retries": int(stats.stack_retries)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "hz::k_horizon<2,false,true,false>", "kernel_ms_per_launch": 1e3 * k_launch_s,
-                         "alg_bytes_per_launch": b_io + b_trav, "nodes_per_ray": nodes_per_ray,
-                         "tris_per_ray": tris_per_ray, "mray_per_s_kernel": rays_launch / k_launch_s / 1e6,
-                         "svf_kernel_ms_per_launch": 1e3 * stats.t_svf_s / max(args.steps, 1),
-                         "device_copy_gbs": copy_gbs},
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(g, args, A)
-        print(json.dumps(out), flush=True)
-    if use_dist:
-        dist.barrier()
-        dist.destroy_process_group()
+    k_launch_s = stats.t_kernel_s / max(steps, 1)        # HIP events on the kernel's stream
+    rays_launch = stats.num_rays / max(steps, 1)
+    cells_launch = stats.num_cells / max(steps, 1)
+    out = {
+        "metric": "grid_cells_per_s (horizon_gridded, 360 azimuths, 3601^2 SRTM-like tile)",
+        "value": cells_total / elapsed,
+        "unit": "cells/s",
+        "mray_per_s": rays_total / elapsed / 1e6,
+        "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": 1e3 * elapsed / max(steps, 1),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "c3: horizon_gridded guess_constant + fused SVF, %dx%d synthetic SRTM-like tile, "
+                               "%d azimuths, dist_search %g km, slabs of <= %d rows per step (%d slabs cover the tile)"
+                               % (n, n, A, args.dist_search, rps, n_slabs),
+                   "cells_per_step": cells_launch, "rays_per_cell_azimuth": rays_launch / max(cells_launch * A, 1),
+                   "parallelism": "weak scaling x%d: same slab sequence, rank r starts at step r K; scene broadcast once" % world,
+                   "bvh_build_s": scene_stats["t_bvh_s"] if scene_stats else None,
+                   "scene_bytes": int(blob_bytes), "scene_bcast_s": t_bcast, "scene_create_wall_s": t_build,
+                   "load_imbalance_max_over_mean": imbalance, "stack_retries": int(stats.stack_retries)},
+        "roofline": roofline(args, stats, steps, cw, peaks, A, n, rps),
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(g, args, A)
+    return out
+
+
+def roofline(args, stats, steps, cw, peaks, A, n, rps):
+    """The bound of k_horizon is VALU issue: achieved = wave-level VALU instructions per
+    second (wave-iteration counters of the COUNT instantiation x the calibrated instructions per iteration),
+    peak = the measured issue rate of independent v_fma_f32 chains on this box.  The HBM pair (algorithmic
+    bytes -- mostly cache-served node re-reads -- and the counter-measured traffic) is reported next to it."""
+    k_launch_s = stats.t_kernel_s / max(steps, 1)
+    rays_launch = stats.num_rays / max(steps, 1)
+    cells_launch = stats.num_cells / max(steps, 1)
+    b_io = (12 + 12 + 12 + 1 + 12 + 4) * cells_launch + 4.0 * A * cells_launch
+    r = {"kernel": "hz::k_horizon<2,false,true,false>", "kernel_ms_per_launch": 1e3 * k_launch_s,
+         "mray_per_s_kernel": rays_launch / k_launch_s / 1e6 if k_launch_s else None,
+         "svf_kernel_ms_per_launch": 1e3 * stats.t_svf_s / max(steps, 1)}
+    model = dict(VALU_MODEL_DEFAULT)
+    mpath = os.path.join(ROOT, "profiles", "valu_model.json")
+    sha = kernel_source_sha()
+    if os.path.exists(mpath):
+        try:
+            mj = json.load(open(mpath))
+            if mj.get("kernel_source_sha") == sha:
+                model.update({k: mj[k] for k in model if k in mj})
+                r["valu_model"] = "profiles/valu_model.json (calibrated on SQ_INSTS_VALU, same kernel sources)"
+            else:
+                r["valu_model"] = "default constants (profiles/valu_model.json was measured for other kernel sources)"
+        except Exception:
+            pass
+    b_trav = 0.0
+    if cw is not None and cw.num_rays:
+        # the counter pass ran one slab: scale its wave-level counts to a mean launch by the ray count
+        scale = rays_launch / cw.num_rays
+        winst = scale * (cw.wave_node_iters * model["node_iter"] + cw.wave_leaf_iters * model["leaf_iter"]
+                         + cw.wave_refills * model["refill_iter"]) + model["per_cell"] * cells_launch / 64.0
+        nodes_per_ray = cw.nodes_visited / cw.num_rays
+        tris_per_ray = cw.tris_tested / cw.num_rays
+        b_trav = rays_launch * (nodes_per_ray * 64.0 + tris_per_ray * 24.0)
+        lanes = (cw.nodes_visited + cw.tris_tested / 2.0) / max(64.0 * (cw.wave_node_iters + cw.wave_leaf_iters), 1.0)
+        r.update({"nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray,
+                  "valu_winst_per_launch": winst, "lane_utilisation_node_leaf_steps": lanes})
+        if peaks and peaks["valu_winst_per_s"]:
+            r.update({"bound": "valu_issue", "achieved": winst / k_launch_s / 1e9, "peak": peaks["valu_winst_per_s"] / 1e9,
+                      "unit": "G wave-instructions/s", "frac": winst / k_launch_s / peaks["valu_winst_per_s"],
+                      "peak_cycles_per_wave_inst": peaks["cycles_per_wave_inst"], "clock_ghz": peaks["clock_ghz"]})
+    alg = (b_io + b_trav) / k_launch_s / 1e9 if k_launch_s else None
+    traffic, tnote = None, "profiles/traffic.json missing"
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath):
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("kernel_source_sha") != sha:
+                tnote = "profiles/traffic.json was measured for other kernel sources (stale): not reported"
+            elif tj.get("rows_per_step") == rps and tj.get("tile") == n and tj.get("azim") == A:
+                traffic, tnote = tj.get("hbm_bytes_per_launch"), "rocprofv3 PMC passes of this kernel (profiles/traffic.json)"
+        except Exception:
+            pass
+    r.update({"traffic": traffic, "traffic_note": tnote,
+              "hbm": {"peak_gbs": HBM_PEAK_GBS, "copy_kernel_gbs": peaks["copy_gbs"] if peaks else None,
+                      "alg_bytes_per_launch": b_io + b_trav, "alg_gbs_cache_served": alg,
+                      "alg_frac_of_peak_cache_served": alg / HBM_PEAK_GBS if alg else None,
+                      "hbm_counter_gbs": traffic / k_launch_s / 1e9 if traffic else None,
+                      "hbm_frac": traffic / k_launch_s / 1e9 / HBM_PEAK_GBS if traffic else None}})
+    if "bound" not in r:      # no counter pass / no calibration kernels: only the HBM view is available
+        r.update({"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                  "frac": alg / HBM_PEAK_GBS if alg else None})
+    return r
+
+
+# ------------------------------------------------------------------------------------------------
+# config 5: the 14401^2 mosaic, SVF-fused, row-sharded over the ranks
+# ------------------------------------------------------------------------------------------------
+def run_c5(ctx):
+    import torch
+    import torch.distributed as dist
+    from horayzon_amd import _lib, synth
+    from horayzon_amd.dist import sharded_rows, row_slabs
+    args, rank, world, dev = ctx["args"], ctx["rank"], ctx["world"], ctx["dev"]
+    L = _lib.lib()
+    n, off, A = args.tile or 14401, 16, args.azim
+    steps = args.steps if args.steps is not None else 1
+    warmup = args.warmup if args.warmup is not None else 1
+    g = synth.fractal_tile(n=n, offset=off)       # every rank generates the same seeded mosaic
+    in0 = in1 = n - 2 * off
+    scene, scene_stats, t_build, t_bcast = make_scene(ctx, g, n)
+    blob_ptr, blob_bytes = scene.blob()
+    vec_tilt_h, _ = synth.tilt_from_planar_dem(g["x"], g["y"], g["z"], off)
+    d_tilt = torch.from_numpy(vec_tilt_h).to(dev)
+    del vec_tilt_h, g
+    d_norm = torch.zeros((in0, in1, 3), dtype=torch.float32, device=dev); d_norm[..., 2] = 1.0
+    d_north = torch.zeros((in0, in1, 3), dtype=torch.float32, device=dev); d_north[..., 1] = 1.0
+    mask_h = np.ones((in0, in1), np.uint8)
+    d_mask = torch.from_numpy(mask_h).to(dev)
+    stats = _lib.hz_stats()
+
+    def compute(b, e, st=None):
+        svf = torch.full((max(e - b, 0), in1), float("nan"), dtype=torch.float32, device=dev)
+        if e <= b:
+            return svf
+        opts = _lib.hz_opts()
+        opts.device = ctx["local_rank"]
+        opts.top_nodes = -1; opts.regroup = -1
+        opts.vec_tilt = d_tilt.data_ptr()
+        opts.svf = svf.data_ptr()
+        opts.hori_is_slab = 1
+        opts.skip_hori = 1                       # the horizon lives in a bounded device buffer, chunk by chunk
+        opts.row_begin, opts.row_end = b, e
+        rc = L.hz_horizon_gridded_scene(scene._h, d_norm.data_ptr(), d_north.data_ptr(), off, off, None, in0, in1, A,
+                                        args.dist_search, 0.25, b"guess_constant", -15.0, d_mask.data_ptr(), 0.0,
+                                        0.01, C.byref(opts), C.byref(st if st is not None else stats))
+        _lib.check(rc)
+        return svf
+
+    slabs = row_slabs(mask_h, world)
+    for w in range(warmup):      # a short slab of this rank's rows: clocks, allocator, stack-level escalation
+        b, e = slabs[rank]
+        compute(b, min(b + 64, e), _lib.hz_stats())
+    barrier(ctx)
+    t0 = time.perf_counter()
+    res = None
+    for s in range(steps):
+        res = sharded_rows(mask_h, compute, sync=torch.cuda.synchronize, dst=0)
+    barrier(ctx)
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    tot = torch.tensor([stats.num_rays, stats.num_cells], dtype=torch.float64, device=dev)
+    dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    rays_total, cells_total = float(tot[0].item()), float(tot[1].item())
+    if rank != 0:
+        return None
+    svf_ok = None
+    if res is not None and res["full"] is not None:
+        svf_ok = bool(torch.isfinite(res["full"]).all().item()) and tuple(res["full"].shape) == (in0, in1)
+    return {
+        "metric": "grid_cells_per_s (horizon_gridded + SVF, 360 azimuths, 4x4 mosaic of 3601^2 SRTM-like tiles)",
+        "value": cells_total / elapsed, "unit": "cells/s", "mray_per_s": rays_total / elapsed / 1e6,
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / max(steps, 1),
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "c5: horizon_gridded guess_constant, SVF-fused (horizon never materialised), %dx%d synthetic "
+                               "mosaic, %d azimuths, dist_search %g km; one step = the whole inner domain (%d x %d cells)"
+                               % (n, n, A, args.dist_search, in0, in1),
+                   "parallelism": "row slabs over %d ranks (dist.row_slabs), scene broadcast once, SVF gathered on rank 0" % world,
+                   "slabs": res["slabs"] if res else None, "t_ranks_s": res["t_ranks"] if res else None,
+                   "load_imbalance_max_over_mean": res["imbalance"] if res else None,
+                   "bvh_build_s": scene_stats["t_bvh_s"] if scene_stats else None, "scene_bytes": int(blob_bytes),
+                   "scene_bcast_s": t_bcast, "scene_create_wall_s": t_build, "kernel_s_rank0": stats.t_kernel_s,
+                   "svf_kernel_s_rank0": stats.t_svf_s, "stack_retries_rank0": int(stats.stack_retries),
+                   "gathered_svf_finite": svf_ok},
+        "roofline": {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None,
+                     "traffic": None, "note": "see the c3 line: same kernel; c5 reports scaling, not the kernel roofline"},
+    }
 
 
 def cpu_baseline(g, args, A):

@@ -252,7 +252,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     const bool hori_is_slab = opts && opts->hori_is_slab;
     float *hori_slab_host = hori_buffer ? (hori_is_slab ? hori_buffer : hori_buffer + (size_t)row_begin * dim_in_1 * azim_num) : nullptr;
     float *hori_row0 = hori_slab_host ? hori_slab_host - (size_t)row_begin * dim_in_1 * azim_num : nullptr;
-    float *svf_slab = want_svf ? opts->svf + (size_t)row_begin * dim_in_1 : nullptr;
+    float *svf_slab = want_svf ? (hori_is_slab ? opts->svf : opts->svf + (size_t)row_begin * dim_in_1) : nullptr;
     if ((rc = d_svf.bind(svf_slab, svf_slab ? slab_cells : 0))) return rc;
     // rows per launch: the whole slab when `hori` is device memory.  Otherwise the horizon of a chunk
     // of rows lives in a bounded temporary: one <= 4 GiB buffer when only the SVF is wanted, two of

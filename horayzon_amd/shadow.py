@@ -167,13 +167,31 @@ class Terrain:
         _lib.check(_lib.lib().hz_terrain_set_stack_entries(self._h, int(entries)))
 
     # --- additive batch API (not in the reference): many sun positions, one call ------
+    @staticmethod
+    def _batch_out(buf, np_dtype, name):
+        """The batch forms (additive API) also take torch tensors in HBM: outputs of 144 sun positions of a
+        3601^2 tile are 1.8 GB / 7.3 GB and usually consumed on the GPU."""
+        if isinstance(buf, np.ndarray):
+            _typed(buf, np_dtype, 3, name)
+            if not buf.flags["C_CONTIGUOUS"]:
+                raise ValueError("array '%s' is not C-contiguous" % name)
+            return
+        if not hasattr(buf, "data_ptr"):
+            raise TypeError("Argument '%s' has incorrect type (expected numpy.ndarray or torch.Tensor, got %s)"
+                            % (name, type(buf).__name__))
+        if buf.dim() != 3:
+            raise ValueError("Buffer has wrong number of dimensions (expected 3, got %d)" % buf.dim())
+        if str(buf.dtype).split(".")[-1] != np.dtype(np_dtype).name:
+            raise ValueError("Buffer dtype mismatch, expected '%s' but got '%s'" % (np.dtype(np_dtype).name, buf.dtype))
+        if not buf.is_contiguous():
+            raise ValueError("array '%s' is not C-contiguous" % name)
+
     def shadow_batch(self, sun_positions, shadow_buffers):
+        """``shadow`` for sun_positions f32[num][3] -> shadow_buffers u8[num][y][x] (NumPy or torch/HBM)."""
         _typed(sun_positions, np.float32, 2, "sun_positions")
-        _typed(shadow_buffers, np.uint8, 3, "shadow_buffers")
+        self._batch_out(shadow_buffers, np.uint8, "shadow_buffers")
         if sun_positions.shape[1] != 3 or shadow_buffers.shape[0] != sun_positions.shape[0]:
             raise ValueError("array 'sun_positions' has incorrect shape")
-        if not shadow_buffers.flags["C_CONTIGUOUS"]:
-            raise ValueError("array 'shadow_buffers' is not C-contiguous")
         self._check_out(shadow_buffers, "shadow_buffers")
         st = hz_stats()
         _lib.check(_lib.lib().hz_terrain_shadow_batch(
@@ -182,12 +200,11 @@ class Terrain:
         self.last_stats = st.as_dict()
 
     def sw_dir_cor_batch(self, sun_positions, sw_dir_cor_buffers):
+        """``sw_dir_cor`` for sun_positions f32[num][3] -> sw_dir_cor_buffers f32[num][y][x] (NumPy or torch/HBM)."""
         _typed(sun_positions, np.float32, 2, "sun_positions")
-        _typed(sw_dir_cor_buffers, np.float32, 3, "sw_dir_cor_buffers")
+        self._batch_out(sw_dir_cor_buffers, np.float32, "sw_dir_cor_buffers")
         if sun_positions.shape[1] != 3 or sw_dir_cor_buffers.shape[0] != sun_positions.shape[0]:
             raise ValueError("array 'sun_positions' has incorrect shape")
-        if not sw_dir_cor_buffers.flags["C_CONTIGUOUS"]:
-            raise ValueError("array 'sw_dir_cor_buffers' is not C-contiguous")
         self._check_out(sw_dir_cor_buffers, "sw_dir_cor_buffers")
         st = hz_stats()
         _lib.check(_lib.lib().hz_terrain_sw_dir_cor_batch(

@@ -59,10 +59,11 @@ typedef struct hz_opts {
                            /*   workgroups per CU.  Rays that need more are detected and the call  */
                            /*   is repeated with the worst case (3 per tree level): results never  */
                            /*   depend on it                                                       */
-    int32_t hori_is_slab;  /* 0: hori_buffer addresses inner-domain row 0 (reference layout, f32[dim_in_0][..]);  */
-                           /*   1: hori_buffer addresses row_begin, i.e. it holds only the slab                   */
-                           /*   f32[row_end - row_begin][dim_in_1][azim_num] -- the form for a resident HBM slab  */
-                           /*   buffer (no address outside the caller's allocation is ever formed by the caller)  */
+    int32_t hori_is_slab;  /* 0: hori_buffer (and svf) address inner-domain row 0 (reference layout, [dim_in_0][..]); */
+                           /*   1: they address row_begin, i.e. hold only the slab [row_end - row_begin][dim_in_1].. */
+                           /*   -- the form for resident HBM slab buffers (the caller never forms an address        */
+                           /*   outside its allocation).  Inputs (vec_norm, vec_north, mask, vec_tilt) always cover  */
+                           /*   the whole inner domain                                                               */
 } hz_opts;
 
 /* Run-time self report (the quantities the reference prints,                  */

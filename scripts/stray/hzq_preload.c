@@ -16,6 +16,7 @@
  */
 #define _GNU_SOURCE
 #include <dlfcn.h>
+#include <link.h>
 #include <execinfo.h>
 #include <pthread.h>
 #include <signal.h>
@@ -49,6 +50,22 @@ static void *(*real_calloc)(size_t, size_t);
 static void *(*real_realloc)(void *, size_t);
 static size_t (*real_usable)(void *);
 
+/* libgcc's unwinder calls malloc / free while it holds its own mutex (__register_frame_info & co.); a backtrace
+ * from inside those calls would take that mutex again.  Calls that come from libgcc_s are not backtraced. */
+static uintptr_t gcc_lo, gcc_hi;
+static int find_libgcc(struct dl_phdr_info *info, size_t sz, void *data) {
+    (void)sz; (void)data;
+    if (info->dlpi_name && strstr(info->dlpi_name, "libgcc_s")) {
+        for (int i = 0; i < info->dlpi_phnum; i++) if (info->dlpi_phdr[i].p_type == PT_LOAD) {
+            const uintptr_t a = info->dlpi_addr + info->dlpi_phdr[i].p_vaddr, b = a + info->dlpi_phdr[i].p_memsz;
+            if (!gcc_lo || a < gcc_lo) gcc_lo = a;
+            if (b > gcc_hi) gcc_hi = b;
+        }
+    }
+    return 0;
+}
+static int from_libgcc(void *ra) { return (uintptr_t)ra >= gcc_lo && (uintptr_t)ra < gcc_hi; }
+
 static char boot[1 << 16]; static size_t boot_off;   /* dlsym() calls calloc before we are resolved */
 static int is_boot(void *p) { return (char *)p >= boot && (char *)p < boot + sizeof(boot); }
 
@@ -69,6 +86,7 @@ static void init(void) {
     tab = mmap(NULL, sizeof(ent_t) * TAB_N, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     fifo = mmap(NULL, sizeof(size_t) * fifo_cap, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     void *warm[4]; backtrace(warm, 4);              /* loads libgcc now, not inside a hook */
+    dl_iterate_phdr(find_libgcc, NULL);
     in_hook--;
     ready = 1;
 }
@@ -155,24 +173,28 @@ int hzq_check(void) {                 /* scan the quarantine now (fill mode); re
 }
 __attribute__((destructor)) static void dtor(void) { if (ready && mode_fill) { hzq_check(); fprintf(stderr, "[hzq] exit: %d damaged blocks reported\n", reports); } }
 
-static void *q_alloc(size_t size) {
+static void *q_alloc(size_t size, int no_bt) {
     const size_t maplen = (size + 4095) & ~(size_t)4095;
     char *m = mmap(NULL, maplen, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
     if (m == MAP_FAILED) return NULL;
+    void *bt[NBT];                       /* outside the lock: backtrace() takes the loader lock */
+    const int nb = (want_bt && !no_bt) ? backtrace(bt, NBT) : 0;
     pthread_mutex_lock(&mu);
     ent_t *e = slot_for(m);
     if (!e) { pthread_mutex_unlock(&mu); munmap(m, maplen); return NULL; }
     e->user = m; e->size = size; e->maplen = maplen; e->state = 1; e->nf = 0;
-    e->na = want_bt ? backtrace(e->abt, NBT) : 0;
+    e->na = nb; memcpy(e->abt, bt, sizeof(void *) * (size_t)nb);
     pthread_mutex_unlock(&mu);
     return m;
 }
 
-static int q_free(void *p) {           /* 1 if p was ours */
+static int q_free(void *p, int no_bt) {           /* 1 if p was ours */
+    void *bt[NBT];
+    const int nb = (want_bt && !no_bt) ? backtrace(bt, NBT) : 0;
     pthread_mutex_lock(&mu);
     ent_t *e = find(p);
     if (!e || e->state != 1) { pthread_mutex_unlock(&mu); return 0; }
-    e->nf = want_bt ? backtrace(e->fbt, NBT) : 0;
+    e->nf = nb; memcpy(e->fbt, bt, sizeof(void *) * (size_t)nb);
     e->state = 2;
     if (mode_fill) memset(p, 0xA5, e->size); else mprotect(p, e->maplen, PROT_NONE);
     if (fifo_n == fifo_cap) evict_one();
@@ -184,7 +206,7 @@ static int q_free(void *p) {           /* 1 if p was ours */
 void *malloc(size_t size) {
     if (!real_malloc) { init(); if (!real_malloc) { void *p = boot + boot_off; boot_off += (size + 15) & ~(size_t)15; return p; } }
     if (ready && !in_hook && size >= q_min && size <= q_max) {
-        in_hook++; void *p = q_alloc(size); in_hook--;
+        in_hook++; void *p = q_alloc(size, from_libgcc(__builtin_return_address(0))); in_hook--;
         if (p) return p;
     }
     return real_malloc(size);
@@ -193,15 +215,15 @@ void *calloc(size_t n, size_t s) {
     if (!real_calloc) { void *p = boot + boot_off; boot_off += (n * s + 15) & ~(size_t)15; return p; }   /* zeroed static */
     const size_t size = n * s;
     if (ready && !in_hook && size >= q_min && size <= q_max && (s == 0 || size / s == n)) {
-        in_hook++; void *p = q_alloc(size); in_hook--;
+        in_hook++; void *p = q_alloc(size, from_libgcc(__builtin_return_address(0))); in_hook--;
         if (p) return p;                /* fresh anonymous pages are zero */
     }
     return real_calloc(n, s);
 }
 void free(void *p) {
     if (!p || is_boot(p)) return;
-    if (ready && !in_hook) { in_hook++; const int ours = q_free(p); in_hook--; if (ours) return; }
-    else if (ready) { pthread_mutex_lock(&mu); ent_t *e = find(p); const int ours = e && e->state == 1; pthread_mutex_unlock(&mu); if (ours) { in_hook++; q_free(p); in_hook--; return; } }
+    if (ready && !in_hook) { in_hook++; const int ours = q_free(p, from_libgcc(__builtin_return_address(0))); in_hook--; if (ours) return; }
+    else if (ready) { pthread_mutex_lock(&mu); ent_t *e = find(p); const int ours = e && e->state == 1; pthread_mutex_unlock(&mu); if (ours) { in_hook++; q_free(p, 1); in_hook--; return; } }
     real_free(p);
 }
 void *realloc(void *p, size_t size) {

@@ -4,14 +4,15 @@
 out=${1:-gpurun_out/stray}; n=${2:-5}
 mkdir -p $out
 gcc -O1 -g -fPIC -shared -o scripts/stray/libhzq.so scripts/stray/hzq_preload.c -ldl -lpthread || exit 1
+gcc -O1 -g -fPIC -shared -o scripts/stray/libhzwatch.so scripts/stray/hzwatch.c || exit 1
 hzq=$PWD/scripts/stray/libhzq.so
-run() {   # tag, env...
-    tag=$1; shift
+run() {   # tag, replay args (quoted), env...
+    tag=$1; rargs=$2; shift; shift
     fails=0
     for i in $(seq 1 $n); do
-        env "$@" timeout 120 python scripts/stray/replay.py > $out/$tag.$i.log 2>&1
+        env "$@" timeout 150 python scripts/stray/replay.py $rargs > $out/$tag.$i.log 2>&1
         rc=$?
-        echo "$tag run $i rc=$rc $(grep -c DIRTY $out/$tag.$i.log) dirty" >> $out/summary.txt
+        echo "$tag run $i rc=$rc dirty=$(grep -c DIRTY $out/$tag.$i.log) damaged=$(grep -c DAMAGED $out/$tag.$i.log) trapped=$(grep -c 'WRITE to watched' $out/$tag.$i.log)" >> $out/summary.txt
         [ $rc -ne 0 ] && fails=$((fails+1))
         # a tripwire hit ends the variant early: the log holds the backtraces
         if [ $rc -eq 97 ] || grep -q "DAMAGED" $out/$tag.$i.log; then break; fi
@@ -19,9 +20,10 @@ run() {   # tag, env...
     echo "== $tag: $fails non-zero exits" >> $out/summary.txt
 }
 nproc >> $out/summary.txt
-run base X=1
-run page LD_PRELOAD=$hzq
-run fill LD_PRELOAD=$hzq HZQ_MODE=fill
-run page_nobt LD_PRELOAD=$hzq HZQ_BT=0
-run page_wide LD_PRELOAD=$hzq HZQ_MIN=64 HZQ_MAX=16384 HZQ_CAP=60000
+run base "" X=1
+run page "" LD_PRELOAD=$hzq HZQ_CAP=8000
+run fill "" LD_PRELOAD=$hzq HZQ_MODE=fill HZQ_CAP=8000
+run page_wide "" LD_PRELOAD=$hzq HZQ_MIN=48 HZQ_MAX=70000 HZQ_CAP=12000
+run fill_wide "" LD_PRELOAD=$hzq HZQ_MODE=fill HZQ_MIN=48 HZQ_MAX=70000 HZQ_CAP=12000
+run watch_post "--watch post" X=1
 cat $out/summary.txt

@@ -1,7 +1,8 @@
-"""world_size-2 gloo test of the multi-GPU sharding plumbing (row slabs, blob broadcast
-as bytes, final gather).  On CPU there is no HIP compute, so the per-slab computation is
-done by the oracle -- here only as the stand-in that makes the gathered result checkable
-against the unsharded one."""
+"""world_size-2 gloo test of the multi-GPU code path: the SAME functions bench.py runs on RCCL --
+``dist.broadcast_scene`` (blob bytes from the building rank, adopted by the receivers) and
+``dist.sharded_rows`` (mask-balanced row slabs, per-rank compute with no collective, timing exchange,
+final gather) -- with CPU tensors.  There is no HIP compute on CPU, so the per-slab computation is done
+by the oracle: only as the stand-in that makes the gathered result checkable against the unsharded one."""
 import os
 import socket
 import sys
@@ -16,7 +17,7 @@ def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
-    from horayzon_amd.dist import gather_rows, row_slabs
+    from horayzon_amd.dist import broadcast_scene, sharded_rows
     from oracle import oracle as orc
     from tests import cases
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
@@ -26,19 +27,33 @@ def _worker(rank, world, port, q):
         rng = np.random.default_rng(0)
         mask = (rng.random(kw["vec_norm"].shape[:2]) > 0.3).astype(np.uint8)
         mask[:10] = 0                                   # unbalanced: slabs follow the mask
-        # "scene" broadcast: rank 0 owns the vertex bytes, the others receive them
-        blob = torch.from_numpy(kw["vert_grid"].copy()) if rank == 0 else torch.empty(kw["vert_grid"].size)
-        dist.broadcast(blob, src=0)
-        kw["vert_grid"] = blob.numpy()
-        slabs = row_slabs(mask, world)
-        b, e = slabs[rank]
-        local, _ = orc.horizon_gridded(**kw, dist_search=1.0, azim_num=12, elev_ang_low_lim=-60.0,
-                                       mask=mask, hori_fill=-2.0, rows=(b, e), slab_only=True)
-        full = gather_rows(torch.from_numpy(local), slabs, dst=0)
+        vec_tilt, *_ = cases.terrain_inputs(g)
+        # the "scene": rank 0 owns the vertex bytes (stand-in for the LBVH blob), the others adopt what arrives
+        verts0 = kw["vert_grid"].copy()
+        scene = verts0 if rank == 0 else None
+        got = broadcast_scene(
+            scene, 0, src=0, torch_device="cpu",
+            to_tensor=lambda s: (torch.from_numpy(s.view(np.uint8)), s.nbytes),
+            adopt=lambda buf, n: buf.numpy()[:n].view(np.float32))
+        kw["vert_grid"] = np.ascontiguousarray(got)
+        assert np.array_equal(kw["vert_grid"], verts0)
+
+        def compute(b, e):          # SVF of the slab, horizon never leaves the rank
+            if e <= b:
+                return torch.empty((0, mask.shape[1]), dtype=torch.float32)
+            h, azim = orc.horizon_gridded(**kw, dist_search=1.0, azim_num=12, elev_ang_low_lim=-60.0,
+                                          mask=mask, hori_fill=-2.0, rows=(b, e), slab_only=True)
+            return torch.from_numpy(orc.sky_view_factor(azim, h, np.ascontiguousarray(vec_tilt[b:e])))
+
+        res = sharded_rows(mask, compute, dst=0)
         if rank == 0:
-            ref, _ = orc.horizon_gridded(**kw, dist_search=1.0, azim_num=12, elev_ang_low_lim=-60.0,
-                                         mask=mask, hori_fill=-2.0)
-            q.put(("ok", bool(np.array_equal(full.numpy(), ref)), slabs))
+            h, azim = orc.horizon_gridded(**kw, dist_search=1.0, azim_num=12, elev_ang_low_lim=-60.0,
+                                          mask=mask, hori_fill=-2.0)
+            ref = orc.sky_view_factor(azim, h, vec_tilt)
+            q.put(("ok", bool(np.array_equal(res["full"].numpy(), ref)), res["slabs"], res["t_ranks"],
+                   res["imbalance"]))
+        else:
+            assert res["full"] is None
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -56,6 +71,18 @@ def test_sharded_equals_unsharded_gloo():
     for p in procs:
         p.join(180)
         assert p.exitcode == 0
-    tag, equal, slabs = q.get(timeout=10)
+    tag, equal, slabs, t_ranks, imbalance = q.get(timeout=10)
     assert tag == "ok" and equal
     assert slabs[0][1] > 17                             # mask-balanced, not an even row split
+    assert len(t_ranks) == 2 and all(t > 0 for t in t_ranks) and 1.0 <= imbalance <= 2.0
+
+
+def test_row_slabs_edge_cases():
+    from horayzon_amd.dist import row_slabs
+    assert row_slabs(10, 1) == [(0, 10)]
+    assert row_slabs(3, 8)[-1][1] == 3 and sum(e - b for b, e in row_slabs(3, 8)) == 3
+    m = np.zeros((12, 5), np.uint8); m[8:] = 1           # all the work in the last rows
+    sl = row_slabs(m, 4)
+    assert sl[0][0] == 0 and sl[-1][1] == 12 and all(sl[i][1] == sl[i + 1][0] for i in range(3))
+    work = [int(m[b:e].sum()) for b, e in sl]
+    assert max(work) - min(work) <= 5                    # balanced to within one row of cells

@@ -29,11 +29,12 @@ def test_c5_mosaic_scene_and_row_parity(hip, orc):
     rb = in0 // 2
     opts = _lib.hz_opts(); opts.device = 0; opts.top_nodes = -1; opts.regroup = -1
     opts.row_begin, opts.row_end = rb, rb + rows
+    opts.hori_is_slab = 1              # d_hori holds only the slab (no address outside the allocation is formed)
     st = _lib.hz_stats()
     for _ in range(2):
         st = _lib.hz_stats()
         _lib.check(_lib.lib().hz_horizon_gridded_scene(
-            sc._h, d_norm.data_ptr(), d_north.data_ptr(), off, off, d_hori.data_ptr() - 4 * rb * in1 * A, in0, in1,
+            sc._h, d_norm.data_ptr(), d_north.data_ptr(), off, off, d_hori.data_ptr(), in0, in1,
             A, 50.0, 0.25, b"guess_constant", -15.0, d_mask.data_ptr(), 0.0, 0.01, C.byref(opts), C.byref(st)))
     assert st.num_cells == rows * in1 and st.guard_events == 0
     kw = {k: g[k] for k in ("vert_grid", "dem_dim_0", "dem_dim_1", "vec_norm", "vec_north", "offset_0", "offset_1")}
