@@ -10,6 +10,7 @@ from . import shadow       # noqa: F401
 from . import topo_param   # noqa: F401
 from . import transform    # noqa: F401
 from . import direction    # noqa: F401
+from . import auxiliary    # noqa: F401
 from . import synth        # noqa: F401
 from ._lib import HorayzonHipError, Scene, device_count, device_info   # noqa: F401
 

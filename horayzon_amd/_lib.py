@@ -52,7 +52,7 @@ SYMBOLS = (
     "hz_horizon_locations_scene", "hz_horizon_tables",
     "hz_sky_view_factor", "hz_visible_sky_fraction", "hz_topographic_openness",
     "hz_slope_plane_meth", "hz_slope_vector_meth", "hz_lonlat2ecef", "hz_ecef2enu",
-    "hz_ecef2enu_vector", "hz_surf_norm", "hz_north_dir",
+    "hz_ecef2enu_vector", "hz_surf_norm", "hz_north_dir", "hz_vert_grid_len", "hz_pack_vertices",
     "hz_debug_sort_pairs", "hz_debug_exclusive_scan", "hz_debug_stack_cap",
     "hz_debug_valu_peak", "hz_debug_copy_peak",
     "hz_terrain_create", "hz_terrain_set_stack_entries", "hz_terrain_initialise", "hz_terrain_initialise_scene",
@@ -130,6 +130,8 @@ def lib():
     L.hz_ecef2enu_vector.argtypes = [vp, C.c_size_t, C.c_double, C.c_double, ip, vp, ip]
     L.hz_surf_norm.argtypes = [vp, vp, C.c_size_t, vp, ip]
     L.hz_north_dir.argtypes = [vp, vp, vp, vp, C.c_size_t, ip, vp, ip]
+    L.hz_vert_grid_len.argtypes = [C.c_size_t]
+    L.hz_pack_vertices.argtypes = [vp, vp, vp, C.c_size_t, vp, C.c_size_t, ip]
     L.hz_debug_sort_pairs.argtypes = [vp, vp, C.c_size_t, ip]
     L.hz_debug_exclusive_scan.argtypes = [vp, vp, C.c_size_t, ip]
     L.hz_debug_valu_peak.argtypes = [ip, ip, ip, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
@@ -145,8 +147,9 @@ def lib():
     L.hz_terrain_sw_dir_cor_batch.argtypes = [vp, vp, ip, vp, C.POINTER(hz_stats)]
     L.hz_terrain_destroy.argtypes = [vp]
     for name in SYMBOLS:
-        if name != "hz_last_error":
+        if name not in ("hz_last_error", "hz_vert_grid_len"):
             getattr(L, name).restype = C.c_int
+    L.hz_vert_grid_len.restype = C.c_size_t
     a, b = C.c_int(0), C.c_int(0)
     L.hz_abi_struct_sizes(C.byref(a), C.byref(b))
     if a.value != C.sizeof(hz_opts) or b.value != C.sizeof(hz_stats):

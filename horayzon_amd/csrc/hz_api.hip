@@ -9,6 +9,8 @@
 #include <string>
 #include <vector>
 #include <limits>
+#include <mutex>
+#include <utility>
 
 namespace hz {
 
@@ -136,13 +138,48 @@ static int check_geom(const char *s) {
     return set_error(HZ_ERR_ARG, "invalid input argument for geom_type");
 }
 
+// ---- stream pool --------------------------------------------------------------------------------
+// Streams are taken from a per-device pool and go back to it; the library NEVER calls hipStreamDestroy.
+// Reason (root cause of the "stray element" of round 1): with the HIP runtime of
+// ROCm 7.0 (libamdhip64 as bundled with PyTorch 2.10+rocm7.0) hipStreamDestroy() frees the ~920-byte stream
+// object while a completion callback of that stream can still be pending on the ROCr async-events thread;
+// the callback then decrements a counter at offset 152 and stores a 32-bit zero at offset 888 of the FREED
+// block -- i.e. into whatever the application allocated there next (a 912-byte NumPy array shares the malloc
+// size class: one float of a result array turned 0.0 after the call had returned).  Caught with the heap
+// tripwire scripts/stray/hzq_preload.c: writer = libhsa-runtime64 AsyncEventsLoop -> libamdhip64 callback,
+// block allocated in hipStreamCreateWithFlags, freed in hipStreamDestroy.  A pooled stream is synchronised
+// before it is reused, so no work ever outlives its owner.
+static std::mutex g_stream_mu;
+static std::vector<std::pair<int, hipStream_t>> g_stream_pool;    // (device, idle stream)
+
+static int stream_acquire(int device, hipStream_t *st) {
+    {
+        std::lock_guard<std::mutex> lk(g_stream_mu);
+        for (size_t i = 0; i < g_stream_pool.size(); i++)
+            if (g_stream_pool[i].first == device) {
+                *st = g_stream_pool[i].second;
+                g_stream_pool.erase(g_stream_pool.begin() + (long)i);
+                return HZ_OK;
+            }
+    }
+    const hipError_t e = hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+    if (e != hipSuccess) return set_error(HZ_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    return HZ_OK;
+}
+
+static void stream_release(int device, hipStream_t st) {
+    if (!st) return;
+    (void)hipStreamSynchronize(st);
+    std::lock_guard<std::mutex> lk(g_stream_mu);
+    g_stream_pool.emplace_back(device, st);
+}
+
 static int scene_new(int device, Scene **out) {
     int rc = select_device(device);
     if (rc) return rc;
     Scene *sc = new Scene();
     sc->device = device;
-    const hipError_t e = hipStreamCreateWithFlags(&sc->stream, hipStreamNonBlocking);
-    if (e != hipSuccess) { delete sc; return set_error(HZ_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+    if ((rc = stream_acquire(device, &sc->stream))) { delete sc; return rc; }
     *out = sc;
     return HZ_OK;
 }
@@ -150,7 +187,7 @@ static int scene_new(int device, Scene **out) {
 static void scene_free(Scene *sc) {
     if (!sc) return;
     (void)hipSetDevice(sc->device);
-    if (sc->stream) { (void)hipStreamSynchronize(sc->stream); (void)hipStreamDestroy(sc->stream); }
+    stream_release(sc->device, sc->stream);
     if (sc->owns_blob && sc->blob) (void)hipFree(sc->blob);
     delete sc;
 }
@@ -323,10 +360,9 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             if (e.c) (void)hipEventDestroy(e.c);
             if (e.d) (void)hipEventDestroy(e.d);
         }
-        if (st_copy) (void)hipStreamDestroy(st_copy);
+        if (st_copy) { stream_release(sc->device, st_copy); st_copy = nullptr; }
     };
-    if (stream_out && hipStreamCreateWithFlags(&st_copy, hipStreamNonBlocking) != hipSuccess)
-        return set_error(HZ_ERR_HIP, "hipStreamCreate failed");
+    if (stream_out && (rc = stream_acquire(sc->device, &st_copy))) return rc;
     // copy of chunk k (issued after chunk k + 1 was launched, so a host-blocking pageable copy still overlaps)
     auto copy_out = [&](int k) -> int {
         const int rb = row_begin + k * chunk_rows, re = std::min(rb + chunk_rows, row_end);
@@ -910,6 +946,31 @@ int hz_north_dir(const double *x_ecef, const double *y_ecef, const double *z_ece
     if ((rc = dx.bind(x_ecef, n, st)) || (rc = dy.bind(y_ecef, n, st)) || (rc = dz.bind(z_ecef, n, st))) return rc;
     if ((rc = dn.bind(vec_norm_ecef, n * 3, st)) || (rc = dout.bind(vec_north_ecef, n * 3))) return rc;
     if ((rc = prep_north_dir(ellps, dx.dev, dy.dev, dz.dev, dn.dev, n, dout.dev, st))) return rc;
+    if ((rc = dout.finish(st))) return rc;
+    HZ_HIP(hipStreamSynchronize(st));
+    return HZ_OK;
+}
+
+size_t hz_vert_grid_len(size_t num_vertices) {
+    // pad_buffer (auxiliary.py:128-131): 16 extra elements, plus what makes the byte size a multiple of 16
+    const size_t n3 = 3 * num_vertices;
+    size_t add = 16;
+    if ((n3 * 4) % 16 != 0) add += (16 - (n3 * 4) % 16) / 4;
+    return n3 + add;
+}
+
+int hz_pack_vertices(const float *x, const float *y, const float *z, size_t num_vertices, float *vert_grid,
+                     size_t vert_grid_len, int device) {
+    if (!x || !y || !z || !vert_grid) return set_error(HZ_ERR_ARG, "NULL argument");
+    if (vert_grid_len < hz_vert_grid_len(num_vertices))
+        return set_error(HZ_ERR_ARG, "vert_grid is shorter than hz_vert_grid_len(num_vertices)");
+    int rc = select_device(device);
+    if (rc) return rc;
+    hipStream_t st = nullptr;
+    DevIn<float> dx, dy, dz; DevOut<float> dout;
+    if ((rc = dx.bind(x, num_vertices, st)) || (rc = dy.bind(y, num_vertices, st)) || (rc = dz.bind(z, num_vertices, st))) return rc;
+    if ((rc = dout.bind(vert_grid, vert_grid_len))) return rc;
+    if ((rc = prep_pack_vertices(dx.dev, dy.dev, dz.dev, num_vertices, vert_grid_len, dout.dev, st))) return rc;
     if ((rc = dout.finish(st))) return rc;
     HZ_HIP(hipStreamSynchronize(st));
     return HZ_OK;

@@ -267,4 +267,26 @@ int prep_north_dir(int ellps, const double *X, const double *Y, const double *Z,
     return HZ_OK;
 }
 
+// x, y, z planes -> interleaved xyz vertex buffer + zero padding (the vert_grid layout of the boundary:
+// reference auxiliary.py:49-95, rearrange_pad_buffer / pad_buffer).  One lane per output float4 where the
+// buffer allows it would need a 3:4 shuffle; a lane per vertex with three 4 B stores is HBM-bound enough
+// (24 B moved per vertex, once per DEM).
+__global__ __launch_bounds__(256) void k_pack_vertices(const float *__restrict__ x, const float *__restrict__ y,
+                                                      const float *__restrict__ z, size_t n, size_t n_total,
+                                                      float *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { out[3 * i] = x[i]; out[3 * i + 1] = y[i]; out[3 * i + 2] = z[i]; }
+    const size_t pad = n_total - 3 * n;          // trailing zeros (>= 16 floats)
+    if (i < pad) out[3 * n + i] = 0.0f;
+}
+
+int prep_pack_vertices(const float *x, const float *y, const float *z, size_t n, size_t n_total, float *out,
+                       hipStream_t st) {
+    if (n_total == 0) return HZ_OK;
+    const size_t work = std::max(n, n_total - 3 * n);
+    hipLaunchKernelGGL(k_pack_vertices, dim3(grid_of(work)), dim3(256), 0, st, x, y, z, n, n_total, out);
+    HZ_HIP(hipGetLastError());
+    return HZ_OK;
+}
+
 }  // namespace hz

@@ -228,6 +228,14 @@ int hz_surf_norm(const double *lon, const double *lat, size_t n, float *vec_norm
 int hz_north_dir(const double *x_ecef, const double *y_ecef, const double *z_ecef,
                  const float *vec_norm_ecef, size_t n, int ellps, float *vec_north_ecef, int device);
 
+/* rearrange_pad_buffer / pad_buffer, auxiliary.py:49-95, :99-133: coordinate planes x, y, z f32[num_vertices]  */
+/* (row-major DEM) -> the interleaved xyz vertex buffer `vert_grid` every entry point above takes, with the    */
+/* reference's zero padding.  hz_vert_grid_len gives the padded length in floats.  With device pointers the     */
+/* whole chain lon/lat/elevation -> ENU -> vert_grid -> scene -> horizon / SVF / shadow never leaves HBM.       */
+size_t hz_vert_grid_len(size_t num_vertices);
+int hz_pack_vertices(const float *x, const float *y, const float *z, size_t num_vertices, float *vert_grid,
+                     size_t vert_grid_len, int device);
+
 /* ------------------------------------------------------------------------- */
 /* Shadow: handle API mirroring class CppTerrain (shadow_comp.h:4-39)          */
 /* ------------------------------------------------------------------------- */

@@ -287,3 +287,14 @@ def test_stack_residency_levels():
             c = cap(h, 4096, 0, lvl)
             assert 3 <= c <= 3 * h or h == 0
             assert (c + 4) * 1024 <= (31, 40, 10 ** 9)[lvl] * 1024 or c == 3 * h or c == 3
+
+
+def test_library_never_destroys_a_stream():
+    """hipStreamDestroy of the ROCm 7.0 HIP runtime can free a stream object that a pending completion callback
+    still writes to: the library pools streams instead, so the symbol must not even be
+    imported."""
+    import subprocess
+    from horayzon_amd import _lib
+    out = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "hipStreamCreateWithFlags" in out
+    assert "hipStreamDestroy" not in out

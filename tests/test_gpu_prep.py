@@ -117,3 +117,131 @@ def test_build_primitives_sort_and_scan(hip, n):
     _lib.check(_lib.lib().hz_debug_exclusive_scan(x.ctypes.data, out.ctypes.data, n, 0))
     ref = np.concatenate([[0], np.cumsum(x[:-1], dtype=np.uint64)]).astype(np.uint32)
     assert np.array_equal(out, ref)
+
+
+def _device_chain(hip, torch, lon, lat, elev_t, off, azim_num, dist_km, rows=None):
+    """lon (n1), lat (n0) float64 [degree], elev_t (n0, n1) float32 torch CUDA tensor -> horizon / SVF / shadow,
+    every intermediate a torch tensor in HBM, every step a C-ABI call with device pointers."""
+    import ctypes as C
+    from horayzon_amd import _lib
+    L = _lib.lib()
+    dev = elev_t.device
+    n0, n1 = elev_t.shape
+    lon2 = torch.from_numpy(lon).to(dev)[None, :].expand(n0, n1).contiguous()
+    lat2 = torch.from_numpy(lat).to(dev)[:, None].expand(n0, n1).contiguous()
+    n = n0 * n1
+    f64 = lambda: torch.empty(n, dtype=torch.float64, device=dev)
+    f32 = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
+    X, Y, Z = f64(), f64(), f64()
+    _lib.check(L.hz_lonlat2ecef(lon2.data_ptr(), lat2.data_ptr(), elev_t.data_ptr(), n, 2, X.data_ptr(), Y.data_ptr(), Z.data_ptr(), 0))
+    lon_or, lat_or = float(lon.mean()), float(lat.mean())
+    xe, ye, ze = f32(n0, n1), f32(n0, n1), f32(n0, n1)
+    _lib.check(L.hz_ecef2enu(X.data_ptr(), Y.data_ptr(), Z.data_ptr(), n, lon_or, lat_or, 2, xe.data_ptr(), ye.data_ptr(), ze.data_ptr(), 0))
+    vert_grid = hip.auxiliary.rearrange_pad_buffer(xe, ye, ze)               # torch in -> torch (HBM) out
+    sl = (slice(off, n0 - off), slice(off, n1 - off))
+    in0, in1 = n0 - 2 * off, n1 - 2 * off
+    lon_i, lat_i = lon2[sl].contiguous(), lat2[sl].contiguous()
+    Xi, Yi, Zi = (a.view(n0, n1)[sl].contiguous() for a in (X, Y, Z))
+    vn_e, vno_e, vec_norm, vec_north = f32(in0, in1, 3), f32(in0, in1, 3), f32(in0, in1, 3), f32(in0, in1, 3)
+    m = in0 * in1
+    _lib.check(L.hz_surf_norm(lon_i.data_ptr(), lat_i.data_ptr(), m, vn_e.data_ptr(), 0))
+    _lib.check(L.hz_north_dir(Xi.data_ptr(), Yi.data_ptr(), Zi.data_ptr(), vn_e.data_ptr(), m, 2, vno_e.data_ptr(), 0))
+    _lib.check(L.hz_ecef2enu_vector(vn_e.data_ptr(), m, lon_or, lat_or, 2, vec_norm.data_ptr(), 0))
+    _lib.check(L.hz_ecef2enu_vector(vno_e.data_ptr(), m, lon_or, lat_or, 2, vec_north.data_ptr(), 0))
+    tilt_full = f32(n0, n1, 3)
+    _lib.check(L.hz_slope_plane_meth(xe.data_ptr(), ye.data_ptr(), ze.data_ptr(), n0, n1, None, 0, tilt_full.data_ptr(), 0))
+    vec_tilt = tilt_full[sl].contiguous()
+    scene = hip.Scene.create(vert_grid, n0, n1)                                # device vert_grid: no upload
+    rb, re = rows if rows else (0, in0)
+    hori = f32(re - rb, in1, azim_num)
+    svf = torch.full((re - rb, in1), float("nan"), dtype=torch.float32, device=dev)
+    mask = torch.ones((in0, in1), dtype=torch.uint8, device=dev)
+    opts = _lib.hz_opts(); opts.top_nodes = -1; opts.regroup = -1
+    opts.row_begin, opts.row_end, opts.hori_is_slab = rb, re, 1
+    opts.svf, opts.vec_tilt = svf.data_ptr(), vec_tilt.data_ptr()
+    st = _lib.hz_stats()
+    _lib.check(L.hz_horizon_gridded_scene(scene._h, vec_norm.data_ptr(), vec_north.data_ptr(), off, off, hori.data_ptr(),
+                                          in0, in1, azim_num, dist_km, 0.25, b"guess_constant", -15.0, mask.data_ptr(),
+                                          0.0, 0.01, C.byref(opts), C.byref(st)))
+    # shadow for one sun position on the same scene, inputs and output in HBM
+    enl = torch.ones((in0, in1), dtype=torch.float32, device=dev)
+    elev_i = elev_t[sl].contiguous()
+    t = hip.shadow.Terrain()
+    _lib.check(L.hz_terrain_initialise_scene(t._h, scene._h, off, off, vec_tilt.data_ptr(), vec_norm.data_ptr(), in0, in1,
+                                             enl.data_ptr(), elev_i.data_ptr(), mask.data_ptr(), float("nan"), 89.0, 0))
+    t._shape, t._scene = (in0, in1), scene
+    sun = np.array([[4.0e10, 2.0e10, 1.2e10]], np.float32)
+    sh = torch.full((1, in0, in1), 255, dtype=torch.uint8, device=dev)
+    t.shadow_batch(sun, sh)
+    torch.cuda.synchronize()
+    return dict(xe=xe, ye=ye, ze=ze, vec_norm=vec_norm, vec_north=vec_north, vec_tilt=vec_tilt, hori=hori, svf=svf,
+                shadow=sh[0], stats=st, scene=scene, sun=sun[0])
+
+
+def test_device_resident_chain_equals_host_chain(hip, orc):
+    """SURVEY 8f row 4 closed: raw lon / lat / elevation in HBM -> ENU vertices, packed vert_grid
+    (hz_pack_vertices), normals, north vectors, slope, scene, horizon + fused SVF, shadow -- no host round trip.
+    Bit-identical to the same steps through the NumPy mirrors (same kernels), which the other tests of this file
+    pin against the reference-made fixtures."""
+    torch = pytest.importorskip("torch")
+    d = np.load(os.path.join(os.path.dirname(GOLD), "curved_dem_reference.npz"))
+    off = int(d["offset"])
+    elev_t = torch.from_numpy(np.ascontiguousarray(d["elevation"], np.float32)).to("cuda:0")
+    r = _device_chain(hip, torch, d["lon"], d["lat"], elev_t, off, 18, 3.0)
+    # host chain through the mirrors
+    lon2, lat2 = np.meshgrid(d["lon"], d["lat"])
+    T, D, P = hip.transform, hip.direction, hip.topo_param
+    X, Y, Z = T.lonlat2ecef(lon2, lat2, d["elevation"], ellps="WGS84")
+    tr = T.TransformerEcef2enu(lon_or=d["lon"].mean(), lat_or=d["lat"].mean(), ellps="WGS84")
+    xe, ye, ze = T.ecef2enu(X, Y, Z, tr)
+    sl = (slice(off, lat2.shape[0] - off), slice(off, lat2.shape[1] - off))
+    vn_e = D.surf_norm(lon2[sl], lat2[sl])
+    vec_norm = T.ecef2enu_vector(vn_e, tr)
+    vec_north = T.ecef2enu_vector(D.north_dir(X[sl], Y[sl], Z[sl], vn_e, ellps="WGS84"), tr)
+    vec_tilt = np.ascontiguousarray(P.slope_plane_meth(xe, ye, ze)[sl])
+    vg = hip.auxiliary.rearrange_pad_buffer(xe, ye, ze)
+    from horayzon_amd import synth
+    assert np.array_equal(vg, synth.pack_vertices(xe, ye, ze)) and len(vg) % 4 == 0 and len(vg) >= 3 * xe.size + 16
+    assert np.array_equal(r["xe"].cpu().numpy(), xe) and np.array_equal(r["vec_norm"].cpu().numpy(), vec_norm)
+    assert np.array_equal(r["vec_north"].cpu().numpy(), vec_north)
+    assert np.array_equal(r["vec_tilt"].cpu().numpy(), vec_tilt, equal_nan=True)
+    n0, n1 = xe.shape
+    h, azim, svf = hip.horizon.horizon_gridded(vg, n0, n1, vec_norm, vec_north, off, off, 3.0, azim_num=18,
+                                               svf_vec_tilt=vec_tilt)
+    assert np.array_equal(r["hori"].cpu().numpy(), h) and np.array_equal(r["svf"].cpu().numpy(), svf, equal_nan=True)
+    # ... and the oracle agrees on the horizon computed from the device-prepared input
+    h_o, _ = orc.horizon_gridded(vg, n0, n1, vec_norm, vec_north, off, off, 3.0, azim_num=18)
+    assert np.array_equal(h, h_o)
+    sh = np.empty(vec_tilt.shape[:2], np.uint8)
+    tc = orc.Terrain()
+    tc.initialise(vg, n0, n1, off, off, vec_tilt, vec_norm, np.ones(sh.shape, np.float32),
+                  np.ascontiguousarray(d["elevation"][sl], np.float32), np.ones(sh.shape, np.uint8))
+    tc.shadow(r["sun"], sh)
+    assert np.array_equal(r["shadow"].cpu().numpy(), sh)
+
+
+def test_device_resident_chain_on_the_c3_tile(hip):
+    """The same chain at config-3 size (3601 x 3601 one-arc-second tile on the WGS84 ellipsoid), timed: raw tile in
+    HBM -> everything up to the scene, then a 64-row slab of horizon + SVF and one shadow mask."""
+    torch = pytest.importorskip("torch")
+    import json
+    import time
+    from horayzon_amd import synth
+    n, off = 3601, 16
+    lon = 8.0 + np.arange(n) / 3600.0
+    lat = 47.0 - np.arange(n) / 3600.0
+    elev_t = torch.from_numpy(synth.fractal_elevation(n, n)).to("cuda:0")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    r = _device_chain(hip, torch, lon, lat, elev_t, off, 360, 50.0, rows=(1760, 1824))
+    wall = time.perf_counter() - t0
+    st = r["stats"]
+    assert st.num_cells == 64 * (n - 2 * off) and st.guard_events == 0
+    svf = r["svf"]
+    assert bool(torch.isfinite(svf).all().item()) and 0.2 < float(svf.min().item()) and float(svf.max().item()) <= 1.0 + 1e-5
+    assert int(r["shadow"].max().item()) <= 2 and float((r["shadow"] == 0).float().mean().item()) > 0.3
+    # curved-earth frames: normals tilt away from the ENU z axis towards the tile edges
+    vn = r["vec_norm"]
+    assert float(vn[..., 2].min().item()) < 0.99999 and abs(float((vn ** 2).sum(-1).mean().item()) - 1.0) < 1e-6
+    print(json.dumps({"chain_wall_s": wall, "bvh_build_s": r["scene"].stats["t_bvh_s"], "slab_kernel_s": st.t_kernel_s,
+                      "slab_cells_per_s": st.num_cells / st.t_kernel_s, "rays_per_cell_azimuth": st.num_rays / (st.num_cells * 360.0)}))
