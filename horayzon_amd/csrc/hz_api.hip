@@ -188,6 +188,7 @@ static void scene_free(Scene *sc) {
     if (!sc) return;
     (void)hipSetDevice(sc->device);
     stream_release(sc->device, sc->stream);
+    if (sc->near_buf) (void)hipFree(sc->near_buf);
     if (sc->owns_blob && sc->blob) (void)hipFree(sc->blob);
     delete sc;
 }
@@ -338,6 +339,14 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     a.hit_cache = (opts && opts->no_hit_cache) ? 0 : 1;
     a.stack_entries = opts ? opts->stack_entries : 0;
     a.counters = (unsigned long long *)cnt_dev;
+    // near-field certificates (hz_near.hip): one pre-pass per chunk into a scratch buffer kept with the scene.
+    // Off with an outer-domain TIN (its triangles are not part of the height field the distance bound relies on),
+    // beyond the azimuth count the pre-pass holds in LDS, and on request.
+    const bool use_near = !(opts && opts->no_near_skip) && sc->hdr.n_tin == 0 && azim_num <= near_max_azim() &&
+                          tb.elev_num <= 65534;
+    a.near_idx = nullptr; a.near_r = nullptr;
+    a.verify_near = (opts && opts->verify_near) ? 1 : 0;
+    float ms_near = 0.0f;
 
     // The LDS traversal stack is sized for residency, not for the worst case (horizon_launch: levels 0, 1, 2
     // = 5 / 4 workgroups per CU / worst-case depth).  A wave whose ray needed more entries raises
@@ -386,6 +395,37 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         else hori_chunk = d_hori.dev + (size_t)(rb - row_begin) * dim_in_1 * azim_num;
         a.hori = hori_chunk - (size_t)rb * dim_in_1 * azim_num;
         a.row_begin = rb; a.row_end = re;
+        if (use_near) {
+            const size_t cells = (size_t)(re - rb) * dim_in_1;
+            const size_t idx_bytes = (cells * (size_t)azim_num * 2 + 255) & ~(size_t)255;
+            const size_t need = idx_bytes + cells * 4;
+            if (sc->near_bytes < need) {
+                if (sc->near_buf) (void)hipFree(sc->near_buf);
+                sc->near_buf = nullptr; sc->near_bytes = 0;
+                if (hipMalloc(&sc->near_buf, need) != hipSuccess) return fail(set_error(HZ_ERR_HIP, "hipMalloc of the near-field certificates failed"));
+                sc->near_bytes = need;
+            }
+            NearArgs na;
+            na.vec_norm = d_norm.dev; na.vec_north = d_north.dev; na.mask = d_mask.dev;
+            na.azim_sin = d_as.dev; na.azim_cos = d_ac.dev;
+            na.offset_0 = offset_0; na.offset_1 = offset_1; na.dim_in_1 = dim_in_1; na.row_begin = rb; na.row_end = re;
+            na.azim_num = azim_num; na.elev_num = tb.elev_num;
+            na.ray_org_elev = ray_org_elev; na.hori_acc = tb.hori_acc; na.low = tb.low; na.up = tb.up;
+            na.near_idx = (unsigned short *)sc->near_buf;
+            na.near_r = (float *)((char *)sc->near_buf + idx_bytes);
+            hipEvent_t n0 = nullptr, n1 = nullptr;
+            if (hipEventCreate(&n0) != hipSuccess || hipEventCreate(&n1) != hipSuccess) return fail(set_error(HZ_ERR_HIP, "hipEventCreate failed"));
+            (void)hipEventRecord(n0, st);
+            rc = near_launch(sc, na, st);
+            (void)hipEventRecord(n1, st);
+            if (rc) { (void)hipEventDestroy(n0); (void)hipEventDestroy(n1); return fail(rc); }
+            (void)hipEventSynchronize(n1);
+            float mn = 0.0f;
+            (void)hipEventElapsedTime(&mn, n0, n1);
+            ms_near += mn;
+            (void)hipEventDestroy(n0); (void)hipEventDestroy(n1);
+            a.near_idx = na.near_idx; a.near_r = na.near_r;
+        }
         bool prev_copied = false;
         for (;;) {                                     // attempts of this chunk
             Ev e;
@@ -452,6 +492,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         stats->t_total_s += t_total.stop();
         stats->elev_num = tb.elev_num; stats->bvh_height = sc->hdr.height; stats->scene_bytes = sc->hdr.total_bytes;
         stats->stack_retries += (uint64_t)retries;
+        stats->rays_shortened += cnt[9]; stats->near_violations += cnt[10]; stats->t_near_s += (double)ms_near * 1e-3;
     }
     if (opts && opts->verbose) {   // the reference's report, horizon_comp.cpp:673-700, 805-810 (same lines, same order)
         static const char *alg_name[3] = {"discrete_sampling", "binary search", "guess horizon from previous azimuth direction"};

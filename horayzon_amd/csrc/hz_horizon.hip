@@ -44,6 +44,9 @@ struct HorizonParams {
     TileMap tm;                    // tile grid of the slab -> workgroups (XCD aware)
     float dist, hori_fill, ray_org_elev;
     int top_nodes, regroup, stack_bytes, leaf_bias, stage_bytes, hit_cache, stack_cap;
+    const unsigned short *near_idx;   // near-field certificates of this launch's rows (hz_near.hip) or null
+    const float *near_r;
+    int verify_near;
     unsigned long long *counters;
 };
 
@@ -114,6 +117,12 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
     int cache = 0;           // hit cache: subtree above the leaf that blocked this cell's last blocked ray
     bool second = false;     // the cache walk found nothing: the root traversal is still due
     unsigned overflow = 0;   // a ray needed more stack entries than this launch has (see hz_trace)
+    // near-field certificate of this cell (hz_near.hip): rays of azimuth k with a table index >= near_idx[k] clear
+    // everything within near_r of the origin and start their box tests at parameter near_r
+    const size_t cert = in_dom ? ((size_t)(i - p.row_begin) * p.dim_in_1 + j) : 0;
+    unsigned shortened = 0, violations = 0;        // COUNT only
+    bool verifying = false, first_result = false;  // COUNT + verify_near: second, full-length pass of a shortened ray
+    float tn = 0.0f;
 
     while (__ballot(!done) != 0ull) {
         // ---- refill: lanes without a ray take the next sample of their search -----------------
@@ -126,7 +135,10 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
                 dx = (r00 * rx + r01 * ry) + r02 * rz;
                 dy = (r10 * rx + r11 * ry) + r12 * rz;
                 dz = (r20 * rx + r21 * ry) + r22 * rz;
-                rb = hz_raybox(ocx, ocy, ocz, dx, dy, dz);
+                tn = 0.0f;
+                if (p.near_idx != nullptr && s.ind >= (int)p.near_idx[cert * (size_t)t.azim_num + s.k]) tn = p.near_r[cert];
+                if (COUNT && tn > 0.0f) shortened++;
+                rb = hz_raybox(ocx + tn * dx, ocy + tn * dy, ocz + tn * dz, dx, dy, dz);
                 hz_trav_reset(ts);
                 // a ray below the previous azimuth's horizon is expected to be blocked near the same ridge
                 second = p.hit_cache && (cache != 0) && (s.ind <= s.pazim) && (s.k > 0);
@@ -143,7 +155,13 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
                                                  dx, dy, dz, tfar, rb, ts, p.regroup, p.leaf_bias, tc, p.stack_cap, overflow);
             if (r == 0 && second) {                      // nothing in the cached subtree: full traversal
                 second = false; hz_trav_reset(ts);
+            } else if (COUNT && p.verify_near && r != 2 && tn > 0.0f && !verifying) {
+                // the shortened ray is done: trace it again over its full length and compare the decisions
+                verifying = true; first_result = (r == 1);
+                rb = hz_raybox(ocx, ocy, ocz, dx, dy, dz);
+                hz_trav_reset(ts);
             } else if (r != 2) {
+                if (COUNT && verifying) { if ((r == 1) != first_result) violations++; verifying = false; }
                 ray_active = false; last_hit = (r == 1);
                 if (r == 1) cache = p.sv.anc[~ts.lq0];   // ts.lq0 is the leaf that blocked the ray
             }
@@ -170,6 +188,11 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
             atomicAdd(&p.counters[2], nc); atomicAdd(&p.counters[3], tcn);
             atomicAdd(&p.counters[5], wn); atomicAdd(&p.counters[6], wl); atomicAdd(&p.counters[7], wa);
         }
+    }
+    if (COUNT) {
+        unsigned long long sh = shortened, vi = violations;
+        for (int off = 32; off > 0; off >>= 1) { sh += __shfl_xor(sh, off); vi += __shfl_xor(vi, off); }
+        if (lane == 0) { if (sh) atomicAdd(&p.counters[9], sh); if (vi) atomicAdd(&p.counters[10], vi); }
     }
 }
 
@@ -243,6 +266,7 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *c
     p.regroup = (a.regroup < 0) ? 40 : std::min(a.regroup & 0xff, 64);
     p.leaf_bias = (a.regroup >= 256) ? (a.regroup >> 8) : 20;
     p.hit_cache = (a.hit_cache != 0) ? 1 : 0;
+    p.near_idx = a.near_idx; p.near_r = a.near_r; p.verify_near = a.verify_near;
     p.counters = a.counters;
     const size_t lds = (size_t)p.stack_bytes + (size_t)p.stage_bytes + (size_t)top * sizeof(Node);
     const int grid = p.tm.per_xcd * 8;

@@ -45,6 +45,10 @@ struct Scene {
     // residency level of the LDS traversal stack that has worked for this scene so far (hz_api.hip);
     // mutable: kernels that hit the limit bump it through a const Scene
     mutable std::atomic<int> stack_level{0};
+    // scratch of the near-field certificates, grown on demand and kept with the scene (hz_api.hip); a scene is
+    // used by one call at a time per stream, like its stream
+    mutable void *near_buf = nullptr;
+    mutable size_t near_bytes = 0;
     BlobHeader hdr;
     const float *verts() const { return (const float *)((const char *)blob + hdr.off_verts); }
     const Node *nodes() const { return (const Node *)((const char *)blob + hdr.off_nodes); }
@@ -111,8 +115,12 @@ struct HorizonArgs {
     const int *mid_idx;
     int top_nodes, regroup, count_work, hit_cache;
     int stack_entries, stack_level;      // LDS stack entries per lane (0 = auto) and residency level 0 / 1 / 2
+    const unsigned short *near_idx;      // near-field certificates of rows [row_begin, row_end) (hz_near.hip) or null
+    const float *near_r;
+    int verify_near;                     // counting instantiation: re-trace every shortened ray from parameter 0
     unsigned long long *counters;        // device u64[16]: [0] rays, [1] guards, [2] nodes, [3] tris, [4] cells,
-                                         // [5..7] wave iterations, [8] waves with a stack overflow
+                                         // [5..7] wave iterations, [8] waves with a stack overflow,
+                                         // [9] rays shortened by a certificate, [10] certificate violations (verify)
 };
 int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *cap_is_full = nullptr);
 // entries per lane of the LDS traversal stack for residency level 0 / 1 / 2 (5 / 4 workgroups per CU /
@@ -122,6 +130,19 @@ int topo_launch(int kind, const float *azim, const float *hori, const float *vec
                 int len_2, float *out, hipStream_t st);
 int svf_launch(const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
                int len_2, float *svf, hipStream_t st);
+
+// hz_near.hip: near-field certificates (pre-pass of the horizon kernel)
+struct NearArgs {
+    const float *vec_norm, *vec_north;   // device
+    const uint8_t *mask;
+    const float *azim_sin, *azim_cos;    // device tables
+    int offset_0, offset_1, dim_in_1, row_begin, row_end, azim_num, elev_num;
+    float ray_org_elev, hori_acc, low, up;   // radians / metres
+    unsigned short *near_idx;            // out [rows * dim_in_1][azim_num]
+    float *near_r;                       // out [rows * dim_in_1]
+};
+int near_launch(const Scene *sc, const NearArgs &a, hipStream_t st);
+int near_max_azim();
 
 // hz_locations.hip
 struct LocationsArgs {

@@ -1,0 +1,217 @@
+// hz_near.hip -- near-field certificates for the horizon kernel (gfx950).
+//
+// Every ray of a cell starts a few centimetres above a grid vertex, i.e. INSIDE the padded boxes of the quads
+// around that vertex and of all their ancestors: it walks the root-to-leaf path(s) around its own origin and tests
+// the four adjacent quads before it sees any other terrain -- about 2/3 of the work of a ray, identical for the
+// ~780 rays of a cell ("origin neighbourhood").  Most rays do not need it: a ray that looks
+// above everything NEAR the cell can only be blocked by terrain further away.
+//
+// This pre-pass computes, once per cell and launch, a certificate for exactly that:
+//   window W  = the (2w)^2 quads around the cell's vertex (w = HZ_NEAR_W cells in each direction),
+//   near_idx[cell][k] = the smallest elevation-table index such that a ray of azimuth k with an index >= it
+//                       passes strictly above every triangle of W (with margins),
+//   near_r[cell]      = a distance r such that every triangle NOT in W lies further than r from the ray origin.
+// k_horizon then starts such a ray at parameter r instead of 0 (its box tests run from the shifted origin), so
+// the traversal never descends into the origin's neighbourhood.  Any triangle that is still reached gets the
+// unchanged exact test with the unchanged origin: hit decisions cannot change -- only boxes are culled, and only
+// boxes that contain nothing the ray can hit (`opts.verify_near` re-traces every shortened
+// ray from parameter 0 in the counting instantiation and counts disagreements: there must be none).
+//
+// Geometry (exact arithmetic; the float margins are listed with the code):
+//  * Local frame of the cell (east, north, norm), origin o.  A ray of azimuth phi_k lies in the vertical half-plane
+//    H_k = { r (sin phi_k, cos phi_k, 0) + z (0, 0, 1), r >= 0 }.  It can hit a triangle T only where T meets H_k,
+//    and T /\ H_k is a segment along which z / r (the tangent of the elevation seen from o) is monotone, so its
+//    maximum sits at an end point, and the end points are crossings of H_k with EDGES of T.  Hence
+//        tanE[k] = max over window edges crossing H_k of z / r at the crossing point
+//    bounds the elevation of everything in W along azimuth k.  (The six spokes from the cell's own vertex cross H_k
+//    only at the vertex itself, directly below o, and contribute nothing.)
+//  * The mesh is a height field over the world (x, y) plane, so every triangle outside W projects outside W's
+//    boundary polygon, and its 3-D distance from o is at least the horizontal distance from o to that polygon:
+//    near_r = that distance (shrunk).  Outer-domain TIN triangles do not obey this; with a TIN the certificates
+//    are switched off (near_r = 0).
+#include "hz_internal.h"
+
+namespace hz {
+
+#ifndef HZ_NEAR_W
+#define HZ_NEAR_W 3
+#endif
+
+struct NearParams {
+    const float *verts;
+    const float *vec_norm, *vec_north;
+    const uint8_t *mask;
+    const float *azim_sin, *azim_cos;
+    int d0, d1, offset_0, offset_1, dim_in_1;
+    int row_begin, n_cells;            // cells [row_begin * dim_in_1, +n_cells) of the inner domain
+    int azim_num, elev_num;
+    float ray_org_elev, low, step, up, pad;
+    unsigned short *near_idx;          // [n_cells][azim_num]
+    float *near_r;                     // [n_cells]
+};
+
+// order-preserving float <-> int so that LDS atomicMax works on floats
+__device__ __forceinline__ int f2o(float f) { const int i = __float_as_int(f); return i >= 0 ? i : (i ^ 0x7fffffff); }
+__device__ __forceinline__ float o2f(int i) { return __int_as_float(i >= 0 ? i : (i ^ 0x7fffffff)); }
+
+template <int W>
+__global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
+    constexpr int NV = 2 * W + 1, NVERT = NV * NV, CENTRE = W * NV + W;
+    constexpr int NHOR = NV * (NV - 1), NDIAG = (NV - 1) * (NV - 1), NEDGE = 2 * NHOR + NDIAG;
+    constexpr int NSEG = 8 * W;        // boundary segments of the window polygon
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_near[];
+    const int A = p.azim_num;
+    const int per_wave = NVERT * 5 + A + 4;                        // floats / ints of LDS per wave
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *q = reinterpret_cast<float *>(smem_near) + (size_t)wave * per_wave;   // [NVERT][5]: e, n, z, world dx, dy
+    int *E = reinterpret_cast<int *>(q + NVERT * 5);                // [A]
+    int *flags = E + A;                                             // [0]: certificate unusable
+    const int cl = blockIdx.x * 4 + wave;                           // cell of this wave (launch local)
+    const bool have = cl < p.n_cells;
+    const int i = have ? p.row_begin + cl / p.dim_in_1 : 0, j = have ? cl % p.dim_in_1 : 0;
+    const int gi = i + p.offset_0, gj = j + p.offset_1;
+    const size_t cell = (size_t)i * p.dim_in_1 + j;
+    bool valid = have && p.mask[cell] == 1 && gi - W >= 0 && gi + W <= p.d0 - 1 && gj - W >= 0 && gj + W <= p.d1 - 1;
+    // ---- window vertices in the local frame (the ray set-up of k_horizon, same operations) ------------------
+    if (valid && lane < NVERT) {
+        const float nx = p.vec_norm[3 * cell], ny = p.vec_norm[3 * cell + 1], nz = p.vec_norm[3 * cell + 2];
+        const float tx = p.vec_north[3 * cell], ty = p.vec_north[3 * cell + 1], tz = p.vec_north[3 * cell + 2];
+        const float ex = ty * nz - tz * ny, ey = tz * nx - tx * nz, ez = tx * ny - ty * nx;
+        const float *v = p.verts + 3 * ((size_t)gi * p.d1 + (size_t)gj);
+        const float ox = v[0] + nx * p.ray_org_elev, oy = v[1] + ny * p.ray_org_elev, oz = v[2] + nz * p.ray_org_elev;
+        const int a = lane / NV - W, b = lane % NV - W;
+        const float *w = p.verts + 3 * ((size_t)(gi + a) * p.d1 + (size_t)(gj + b));
+        const float rx = w[0] - ox, ry = w[1] - oy, rz = w[2] - oz;
+        q[5 * lane + 0] = (rx * ex + ry * ey) + rz * ez;
+        q[5 * lane + 1] = (rx * tx + ry * ty) + rz * tz;
+        q[5 * lane + 2] = (rx * nx + ry * ny) + rz * nz;
+        q[5 * lane + 3] = rx; q[5 * lane + 4] = ry;
+    }
+    for (int k = lane; k < A; k += 64) E[k] = f2o(-__builtin_inff());
+    if (lane == 0) flags[0] = 0;
+    __syncthreads();
+    // ---- edges: where does each one cross the vertical half-planes of the azimuths it spans? ---------------------
+    if (valid) {
+        const float dphi = 6.283185307179586f / (float)A;
+        for (int e = lane; e < NEDGE; e += 64) {
+            int ia, ib;                                            // end points (window vertex numbers)
+            if (e < NHOR) { const int r = e / (NV - 1), c = e % (NV - 1); ia = r * NV + c; ib = ia + 1; }
+            else if (e < 2 * NHOR) { const int f = e - NHOR, r = f / NV, c = f % NV; ia = r * NV + c; ib = ia + NV; }
+            else { const int f = e - 2 * NHOR, r = f / (NV - 1), c = f % (NV - 1); ia = r * NV + c + 1; ib = (r + 1) * NV + c; }   // (i, j+1) - (i+1, j)
+            if (ia == CENTRE || ib == CENTRE) continue;            // spokes: see the header
+            const float ae = q[5 * ia], an = q[5 * ia + 1], az = q[5 * ia + 2];
+            const float be = q[5 * ib], bn = q[5 * ib + 1], bz = q[5 * ib + 2];
+            const float ra = __builtin_sqrtf(ae * ae + an * an), rb = __builtin_sqrtf(be * be + bn * bn);
+            const float rmin = __builtin_fminf(ra, rb);
+            if (!(rmin > 1.0e-3f)) { flags[0] = 1; continue; }     // a vertex (almost) above / below the origin
+            const float pa = atan2f(ae, an), pb = atan2f(be, bn);  // azimuth clockwise from north
+            float dl = pb - pa;
+            if (dl > 3.14159265f) dl -= 6.2831853f;
+            if (dl < -3.14159265f) dl += 6.2831853f;
+            if (__builtin_fabsf(dl) > 2.9f) { flags[0] = 1; continue; }   // the edge passes (almost) over the origin
+            const float lo = dl >= 0.0f ? pa : pb, span = __builtin_fabsf(dl);
+            // margins: end points within tol of a plane count as lying in it
+            const float tol_a = 1.0e-3f * ra + 0.01f, tol_b = 1.0e-3f * rb + 0.01f;
+            const float m_az = 2.0e-3f + 0.02f / rmin;
+            const int k_lo = (int)__builtin_floorf((lo - m_az) / dphi), k_hi = (int)__builtin_ceilf((lo + span + m_az) / dphi);
+            for (int kk = k_lo; kk <= k_hi; kk++) {
+                const int k = ((kk % A) + A) % A;
+                const float sp = p.azim_sin[k], cp = p.azim_cos[k];
+                const float da = ae * cp - an * sp, db = be * cp - bn * sp;     // signed distances from the plane
+                float cand = -__builtin_inff();
+                const float fa = ae * sp + an * cp, fb = be * sp + bn * cp;     // along the azimuth (r of the end points)
+                if (__builtin_fabsf(da) <= tol_a && fa > 0.5f * ra) cand = __builtin_fmaxf(cand, az / fa);
+                if (__builtin_fabsf(db) <= tol_b && fb > 0.5f * rb) cand = __builtin_fmaxf(cand, bz / fb);
+                if ((da < 0.0f) != (db < 0.0f)) {
+                    const float t = da / (da - db);
+                    const float r = fa + t * (fb - fa), z = az + t * (bz - az);
+                    if (r > 0.0f) {
+                        if (r < 0.25f * rmin) flags[0] = 1;        // crossing close to the axis: not trusted
+                        cand = __builtin_fmaxf(cand, z / r);
+                    }
+                }
+                if (cand > -__builtin_inff()) atomicMax(&E[k], f2o(cand));
+            }
+        }
+    }
+    // a window triangle (other than the six at the cell's own vertex) that contains the local vertical axis would be
+    // seen at every azimuth, up to the zenith: its edges alone do not bound it -> no certificate for this cell
+    if (valid) {
+        for (int t = lane; t < 2 * NDIAG; t += 64) {
+            const int qd = t >> 1, r = qd / (NV - 1), c = qd % (NV - 1);
+            const int va = r * NV + c, vb = va + 1, vc = va + NV, vd = vc + 1;     // quad corners a, b / c, d
+            const int i0 = (t & 1) ? vb : va, i1 = (t & 1) ? vd : vb, i2 = vc;     // (a, b, c) and (b, d, c)
+            if (i0 == CENTRE || i1 == CENTRE || i2 == CENTRE) continue;
+            const float x0 = q[5 * i0], y0 = q[5 * i0 + 1], x1 = q[5 * i1], y1 = q[5 * i1 + 1], x2 = q[5 * i2], y2 = q[5 * i2 + 1];
+            const float c0 = x0 * y1 - x1 * y0, c1 = x1 * y2 - x2 * y1, c2 = x2 * y0 - x0 * y2;   // origin vs the three edges
+            const float tol = 1.0e-3f * (__builtin_fabsf(c0) + __builtin_fabsf(c1) + __builtin_fabsf(c2));
+            if ((c0 >= -tol && c1 >= -tol && c2 >= -tol) || (c0 <= tol && c1 <= tol && c2 <= tol)) flags[0] = 1;
+        }
+    }
+    __syncthreads();
+    // ---- distance to everything outside the window: the boundary polygon in the world (x, y) plane -----------------
+    float rin = __builtin_inff();
+    if (valid && lane < NSEG) {
+        // boundary vertex ring, clockwise from the top-left corner
+        int s0, s1;
+        const int side = lane / (2 * W), t = lane % (2 * W);
+        if (side == 0) { s0 = t; s1 = t + 1; }                                         // top row, left -> right
+        else if (side == 1) { s0 = t * NV + (NV - 1); s1 = (t + 1) * NV + (NV - 1); }  // right column, down
+        else if (side == 2) { s0 = (NV - 1) * NV + (NV - 1 - t); s1 = s0 - 1; }        // bottom row, right -> left
+        else { s0 = (NV - 1 - t) * NV; s1 = s0 - NV; }                                 // left column, up
+        const float ax = q[5 * s0 + 3], ay = q[5 * s0 + 4], bx = q[5 * s1 + 3], by = q[5 * s1 + 4];
+        const float ux = bx - ax, uy = by - ay;
+        const float uu = ux * ux + uy * uy;
+        float t01 = uu > 0.0f ? -(ax * ux + ay * uy) / uu : 0.0f;
+        t01 = __builtin_fminf(__builtin_fmaxf(t01, 0.0f), 1.0f);
+        const float cx = ax + t01 * ux, cy = ay + t01 * uy;
+        rin = __builtin_sqrtf(cx * cx + cy * cy);
+    }
+    for (int off = 32; off > 0; off >>= 1) rin = __builtin_fminf(rin, __shfl_xor(rin, off));
+    const bool ok = valid && flags[0] == 0 && rin < 1.0e30f;
+    // ---- table index per azimuth ---------------------------------------------------------------------------------
+    if (have) {
+        // elevation margin: two table steps, at least 2 mrad (a ray that clears the window by less is not shortened)
+        const float marg = __builtin_fmaxf(2.0f * p.step, 2.0e-3f);
+        for (int k = lane; k < A; k += 64) {
+            unsigned short out = 65535;
+            if (ok) {
+                const float t = o2f(E[k]);
+                if (t == -__builtin_inff()) out = 0;
+                else if (t == t && t < 1.0e30f) {
+                    // elev_ang[i] = up - step (elev_num - 1 - i)  (horizon_comp.cpp:723-730): first index at or above el, + 1
+                    const float el = atanf(t) + marg;
+                    const float fi = __builtin_ceilf((el - p.up) / p.step) + (float)(p.elev_num - 1) + 1.0f;
+                    out = (unsigned short)__builtin_fminf(__builtin_fmaxf(fi, 0.0f), 65535.0f);
+                }
+            }
+            p.near_idx[(size_t)cl * A + k] = out;
+        }
+        if (lane == 0) p.near_r[cl] = ok ? __builtin_fmaxf(0.97f * rin - 4.0f * p.pad, 0.0f) : 0.0f;
+    }
+}
+
+int near_launch(const Scene *sc, const NearArgs &a, hipStream_t st) {
+    NearParams p;
+    p.verts = sc->verts();
+    p.vec_norm = a.vec_norm; p.vec_north = a.vec_north; p.mask = a.mask;
+    p.azim_sin = a.azim_sin; p.azim_cos = a.azim_cos;
+    p.d0 = sc->hdr.d0; p.d1 = sc->hdr.d1; p.offset_0 = a.offset_0; p.offset_1 = a.offset_1; p.dim_in_1 = a.dim_in_1;
+    p.row_begin = a.row_begin; p.n_cells = (a.row_end - a.row_begin) * a.dim_in_1;
+    p.azim_num = a.azim_num; p.elev_num = a.elev_num;
+    p.ray_org_elev = a.ray_org_elev; p.low = a.low; p.step = (float)((double)a.hori_acc / 5.0); p.up = a.up;
+    p.pad = sc->hdr.pad;
+    p.near_idx = a.near_idx; p.near_r = a.near_r;
+    if (p.n_cells <= 0) return HZ_OK;
+    constexpr int NVERT = (2 * HZ_NEAR_W + 1) * (2 * HZ_NEAR_W + 1);
+    const size_t lds = (size_t)4 * (NVERT * 5 + a.azim_num + 4) * sizeof(float);
+    const int grid = (p.n_cells + 3) / 4;
+    hipLaunchKernelGGL(k_near_cert<HZ_NEAR_W>, dim3(grid), dim3(256), lds, st, p);
+    HZ_HIP(hipGetLastError());
+    return HZ_OK;
+}
+
+// largest azimuth count the certificates support (LDS of the pre-pass)
+int near_max_azim() { return 2048; }
+
+}  // namespace hz

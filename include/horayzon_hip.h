@@ -64,6 +64,10 @@ typedef struct hz_opts {
                            /*   -- the form for resident HBM slab buffers (the caller never forms an address        */
                            /*   outside its allocation).  Inputs (vec_norm, vec_north, mask, vec_tilt) always cover  */
                            /*   the whole inner domain                                                               */
+    int32_t no_near_skip;  /* 1: do not compute / use the near-field certificates (hz_near.hip): every ray starts at   */
+                           /*   parameter 0.  Results are the same either way; the default is faster                   */
+    int32_t verify_near;   /* 1 (with count_work): re-trace every shortened ray over its full length and count         */
+                           /*   disagreeing hit decisions in hz_stats.near_violations (must stay 0)                     */
 } hz_opts;
 
 /* Run-time self report (the quantities the reference prints,                  */
@@ -87,6 +91,9 @@ typedef struct hz_stats {
     uint64_t wave_refills;    /*   efficiency = lane count / (64 x wave count)) */
     double t_svf_s;        /* sky-view-factor kernel (when opts.svf is set)    */
     uint64_t stack_retries;/* calls repeated with the worst-case stack depth   */
+    uint64_t rays_shortened;  /* count_work: rays that started beyond the cell's neighbourhood (near-field certificate) */
+    uint64_t near_violations; /* count_work + verify_near: shortened rays whose full-length re-trace disagreed (0)      */
+    double t_near_s;       /* certificate pre-pass (hz_near.hip)                */
 } hz_stats;
 
 const char *hz_last_error(void);

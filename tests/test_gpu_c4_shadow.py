@@ -48,9 +48,9 @@ def test_c4_full_tile_144_sun_positions(hip, orc, refrac):
     assert bool((d_sh[:, ~d_mask] == 3).all().item()) and not bool((d_sh[:, d_mask] == 3).any().item())
     assert bool((d_sw[:, ~d_mask] == -7.0).all().item())
     assert not bool(torch.isnan(d_sw).any().item()) and float(d_sw[:, d_mask].min().item()) >= 0.0
-    night = np.flatnonzero(alt < np.deg2rad(-2.0))
-    assert len(night) > 20
-    for s in night[::7]:                                                       # sun below every tilt plane?  no light
+    night = np.flatnonzero(alt < np.deg2rad(-15.0))     # (a sun 2 deg below the horizontal still lights summits)
+    assert len(night) > 10
+    for s in night[::5]:                                                       # deep night: no cell sees the sun
         assert not bool((d_sh[int(s)][d_mask] == 0).any().item())
         assert float(d_sw[int(s)][d_mask].max().item()) == 0.0
     lit = (d_sh == 0)

@@ -16,9 +16,11 @@ def test_random_configurations(hip, orc):
     for it in range(n):
         kw, par, extra, tilt = cases.fuzz_case(rng)
         in0, in1 = kw["vec_norm"].shape[:2]
-        out = hip.horizon.horizon_gridded(**kw, **par, **extra)
+        verify = (it % 3 == 0)          # every third configuration re-traces its shortened rays (near-field certificates)
+        out = hip.horizon.horizon_gridded(**kw, **par, **extra, count_work=verify, _verify_near=verify)
         h_gpu, a_gpu = out[0], out[1]
         st = hip.horizon.last_stats
+        assert st["near_violations"] == 0, "config %d: a near-field certificate shortened a ray that hits nearby" % it
         ro = {"rows": extra["rows"]} if "rows" in extra else {}
         h_cpu, a_cpu, so = orc.horizon_gridded(**kw, **par, **ro, return_stats=True)
         desc = "config %d: dem %dx%d %s %s" % (it, kw["dem_dim_0"], kw["dem_dim_1"],

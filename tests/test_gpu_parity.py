@@ -480,3 +480,51 @@ def test_no_device_memory_leak(hip):
     torch.cuda.synchronize()
     free1 = torch.cuda.mem_get_info(0)[0]
     assert abs(free0 - free1) <= 32 << 20, (free0, free1)
+
+
+@pytest.mark.parametrize("case", ("rough", "tilted_large_coords", "steep_fine", "masked_coarse"))
+def test_near_field_certificates_are_transparent(hip, orc, case):
+    """hz_near.hip: rays that clear the cell's neighbourhood start beyond it.  Same horizon, same ray count as
+    with the certificates switched off and as the oracle; every shortened ray re-traced over its full length
+    takes the same decision (near_violations == 0); and a useful share of the rays is shortened."""
+    if case == "rough":
+        g = cases.rough_terrain(96, 110, seed=5, offset=6, relief=1200.0)
+        par = dict(dist_search=4.0, azim_num=72, elev_ang_low_lim=-30.0)
+    elif case == "tilted_large_coords":
+        g = cases.rough_terrain(80, 70, seed=8, offset=5, relief=700.0, tilt_frames=True, origin=(2.6e6, 1.2e6))
+        par = dict(dist_search=3.0, azim_num=45, hori_acc=0.1, elev_ang_low_lim=-45.0, ray_algorithm="binary_search")
+    elif case == "steep_fine":
+        g = cases.rough_terrain(70, 90, seed=12, dx=5.0, dy=8.0, offset=4, relief=900.0)
+        par = dict(dist_search=1.0, azim_num=120, hori_acc=0.25, elev_ang_low_lim=-89.98, ray_org_elev=2.0)
+    else:
+        g = cases.rough_terrain(64, 64, seed=3, dx=90.0, dy=60.0, offset=3, relief=300.0)
+        rng = np.random.default_rng(1)
+        par = dict(dist_search=8.0, azim_num=7, hori_acc=3.0, elev_ang_low_lim=-15.0, ray_algorithm="discrete_sampling",
+                   mask=(rng.random((58, 58)) < 0.7).astype(np.uint8), hori_fill=-1.0)
+    kw = cases.grid_kwargs(g)
+    h_on, _ = hip.horizon.horizon_gridded(**kw, **par, count_work=True, _verify_near=True)
+    st_on = dict(hip.horizon.last_stats)
+    h_off, _ = hip.horizon.horizon_gridded(**kw, **par, count_work=True, _near_skip=False)
+    st_off = dict(hip.horizon.last_stats)
+    h_cpu, _, so = orc.horizon_gridded(**kw, **par, return_stats=True)
+    assert np.array_equal(h_on, h_off) and np.array_equal(h_on, h_cpu)
+    assert st_on["num_rays"] == st_off["num_rays"] == so["rays"]
+    assert st_on["near_violations"] == 0 and st_off["rays_shortened"] == 0
+    assert st_on["rays_shortened"] > 0.3 * st_on["num_rays"], (st_on["rays_shortened"], st_on["num_rays"])
+    # (the verifying pass traces the shortened rays twice, so its node count is not the product's)
+    h_cnt, _ = hip.horizon.horizon_gridded(**kw, **par, count_work=True)
+    st_cnt = dict(hip.horizon.last_stats)
+    assert np.array_equal(h_cnt, h_on) and st_cnt["nodes_visited"] < st_off["nodes_visited"]
+
+
+def test_near_field_certificates_off_with_outer_tin(hip, orc):
+    """An outer-domain TIN is not part of the height field the certificates' distance bound relies on."""
+    g = cases.rough_terrain(40, 44, seed=2, offset=3)
+    kw = cases.grid_kwargs(g)
+    vs, nvs, ts, nts = cases.outer_tin(g)
+    h, _ = hip.horizon.horizon_gridded(**kw, dist_search=6.0, azim_num=24, vert_simp=vs, num_vert_simp=nvs,
+                                       tri_ind_simp=ts, num_tri_simp=nts, count_work=True)
+    assert hip.horizon.last_stats["rays_shortened"] == 0
+    h_cpu, _ = orc.horizon_gridded(**kw, dist_search=6.0, azim_num=24, vert_simp=vs, num_vert_simp=nvs,
+                                   tri_ind_simp=ts, num_tri_simp=nts)
+    assert np.array_equal(h, h_cpu)
