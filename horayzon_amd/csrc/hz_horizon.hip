@@ -52,7 +52,7 @@ struct HorizonParams {
 
 // LDS: [ per-lane stacks int[depth][256] | output staging float[4][256] | top-of-tree nodelet Node[top_nodes] ]
 template <int ALG, bool COUNT, bool STAGE, bool NODELET>
-__global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
+__global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *stack = reinterpret_cast<int *>(smem);
     const float4 *top = reinterpret_cast<const float4 *>(smem + p.stack_bytes + p.stage_bytes);
@@ -75,8 +75,12 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
     const Tables &t = p.tb;
     const size_t cell = in_dom ? ((size_t)i * p.dim_in_1 + j) : 0;
     bool done = !in_dom;
+    // launch-local cell number: the only per-cell address state kept across the traversal (the output pointer
+    // and the certificate row are rebuilt from it at every refill: 1 VGPR instead of 2 + 2)
+    const unsigned cert = in_dom ? (unsigned)(i - p.row_begin) * (unsigned)p.dim_in_1 + (unsigned)j : 0u;
+    float *const hori0 = p.hori + (size_t)p.row_begin * p.dim_in_1 * (size_t)t.azim_num;   // first cell of this launch
     Sink out;
-    out.hori = p.hori + cell * (size_t)t.azim_num;
+    out.hori = hori0 + (size_t)cert * (size_t)t.azim_num;
     out.dist = nullptr; out.dist_hit = 0.0f;
     out.stage = reinterpret_cast<float *>(smem + p.stack_bytes) + tid;   // only touched when STAGE
     out.stride = HZ_TPB;
@@ -119,7 +123,6 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
     unsigned overflow = 0;   // a ray needed more stack entries than this launch has (see hz_trace)
     // near-field certificate of this cell (hz_near.hip): rays of azimuth k with a table index >= near_idx[k] clear
     // everything within near_r of the origin and start their box tests at parameter near_r
-    const size_t cert = in_dom ? ((size_t)(i - p.row_begin) * p.dim_in_1 + j) : 0;
     unsigned shortened = 0, violations = 0;        // COUNT only
     bool verifying = false, first_result = false;  // COUNT + verify_near: second, full-length pass of a shortened ray
     float tn = 0.0f;
@@ -128,6 +131,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
         // ---- refill: lanes without a ray take the next sample of their search -----------------
         if (!done && !ray_active) {
             if (COUNT) HZ_WAVE_TICK(w_adv, lane);
+            out.hori = hori0 + (size_t)cert * (size_t)t.azim_num;
             if (advance<ALG, STAGE>(s, last_hit, t, out, guards)) {
                 // local direction (east, north, up) and rotation: horizon_comp.cpp:357-361, :55-62
                 const float ec = t.elev_cos[s.ind], es = t.elev_sin[s.ind];
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_horizon(HorizonParams p) {
                 dy = (r10 * rx + r11 * ry) + r12 * rz;
                 dz = (r20 * rx + r21 * ry) + r22 * rz;
                 tn = 0.0f;
-                if (p.near_idx != nullptr && s.ind >= (int)p.near_idx[cert * (size_t)t.azim_num + s.k]) tn = p.near_r[cert];
+                if (p.near_idx != nullptr && s.ind >= (int)p.near_idx[(size_t)cert * (size_t)t.azim_num + s.k]) tn = p.near_r[cert];
                 if (COUNT && tn > 0.0f) shortened++;
                 rb = hz_raybox(ocx + tn * dx, ocy + tn * dy, ocz + tn * dz, dx, dy, dz);
                 hz_trav_reset(ts);

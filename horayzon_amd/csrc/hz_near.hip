@@ -59,13 +59,20 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
     constexpr int NV = 2 * W + 1, NVERT = NV * NV, CENTRE = W * NV + W;
     constexpr int NHOR = NV * (NV - 1), NDIAG = (NV - 1) * (NV - 1), NEDGE = 2 * NHOR + NDIAG;
     constexpr int NSEG = 8 * W;        // boundary segments of the window polygon
+    constexpr int CH = 16;             // azimuths per task of the edge phase
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_near[];
     const int A = p.azim_num;
-    const int per_wave = NVERT * 5 + A + 4;                        // floats / ints of LDS per wave
+    // LDS: [ sin phi_k, cos phi_k : 2 A floats, shared ] then per wave
+    //      [ q: NVERT x 5 | E: A | flags: 4 | first azimuth bin, bins per edge: 2 NEDGE | task prefix: NEDGE + 1 ]
+    const int per_wave = NVERT * 5 + A + 4 + 2 * NEDGE + NEDGE + 1;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    float *q = reinterpret_cast<float *>(smem_near) + (size_t)wave * per_wave;   // [NVERT][5]: e, n, z, world dx, dy
+    float *tab = reinterpret_cast<float *>(smem_near);
+    float *q = tab + 2 * A + (size_t)wave * per_wave;               // [NVERT][5]: e, n, z, world dx, dy
     int *E = reinterpret_cast<int *>(q + NVERT * 5);                // [A]
     int *flags = E + A;                                             // [0]: certificate unusable
+    int *ek = flags + 4;                                            // [NEDGE][2]
+    int *pre = ek + 2 * NEDGE;                                      // [NEDGE + 1]
+    for (int k = threadIdx.x; k < A; k += 256) { tab[k] = p.azim_sin[k]; tab[A + k] = p.azim_cos[k]; }
     const int cl = blockIdx.x * 4 + wave;                           // cell of this wave (launch local)
     const bool have = cl < p.n_cells;
     const int i = have ? p.row_begin + cl / p.dim_in_1 : 0, j = have ? cl % p.dim_in_1 : 0;
@@ -90,33 +97,70 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
     for (int k = lane; k < A; k += 64) E[k] = f2o(-__builtin_inff());
     if (lane == 0) flags[0] = 0;
     __syncthreads();
-    // ---- edges: where does each one cross the vertical half-planes of the azimuths it spans? ---------------------
+    const float dphi = 6.283185307179586f / (float)A;
+    auto edge_ends = [&](int e, int &ia, int &ib) {                  // end points (window vertex numbers) of edge e
+        if (e < NHOR) { const int r = e / (NV - 1), c = e % (NV - 1); ia = r * NV + c; ib = ia + 1; }
+        else if (e < 2 * NHOR) { const int f = e - NHOR, r = f / NV, c = f % NV; ia = r * NV + c; ib = ia + NV; }
+        else { const int f = e - 2 * NHOR, r = f / (NV - 1), c = f % (NV - 1); ia = r * NV + c + 1; ib = (r + 1) * NV + c; }   // (i, j+1) - (i+1, j)
+    };
+    // ---- edges, phase 1: the azimuth bins each edge spans; tasks of CH bins, prefix-summed over the edges -----------
+    int carry = 0;
+    for (int e0 = 0; e0 < NEDGE; e0 += 64) {
+        const int e = e0 + lane;
+        int tasks = 0;
+        if (valid && e < NEDGE) {
+            int ia, ib;
+            edge_ends(e, ia, ib);
+            int k_lo = 0, bins = 0;
+            if (ia != CENTRE && ib != CENTRE) {                      // spokes: see the header
+                const float ae = q[5 * ia], an = q[5 * ia + 1], be = q[5 * ib], bn = q[5 * ib + 1];
+                const float ra = __builtin_sqrtf(ae * ae + an * an), rb = __builtin_sqrtf(be * be + bn * bn);
+                const float rmin = __builtin_fminf(ra, rb);
+                if (!(rmin > 1.0e-3f)) flags[0] = 1;                 // a vertex (almost) above / below the origin
+                else {
+                    const float pa = atan2f(ae, an), pb = atan2f(be, bn);   // azimuth clockwise from north
+                    float dl = pb - pa;
+                    if (dl > 3.14159265f) dl -= 6.2831853f;
+                    if (dl < -3.14159265f) dl += 6.2831853f;
+                    if (__builtin_fabsf(dl) > 2.9f) flags[0] = 1;    // the edge passes (almost) over the origin
+                    else {
+                        const float lo = dl >= 0.0f ? pa : pb, span = __builtin_fabsf(dl);
+                        const float m_az = 2.0e-3f + 0.02f / rmin;   // end points within the tolerance count as in the plane
+                        k_lo = (int)__builtin_floorf((lo - m_az) / dphi);
+                        bins = (int)__builtin_ceilf((lo + span + m_az) / dphi) - k_lo + 1;
+                        tasks = (bins + CH - 1) / CH;
+                    }
+                }
+            }
+            ek[2 * e] = k_lo; ek[2 * e + 1] = bins;
+        }
+        int inc = tasks;                                             // inclusive scan over the wave
+        for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+        if (e < NEDGE) pre[e] = carry + inc - tasks;
+        carry += __shfl(inc, 63);
+    }
+    if (lane == 0) pre[NEDGE] = carry;
+    __syncthreads();
+    // ---- edges, phase 2: one task = one edge x <= CH azimuths; where does the edge cross those vertical planes? ------
     if (valid) {
-        const float dphi = 6.283185307179586f / (float)A;
-        for (int e = lane; e < NEDGE; e += 64) {
-            int ia, ib;                                            // end points (window vertex numbers)
-            if (e < NHOR) { const int r = e / (NV - 1), c = e % (NV - 1); ia = r * NV + c; ib = ia + 1; }
-            else if (e < 2 * NHOR) { const int f = e - NHOR, r = f / NV, c = f % NV; ia = r * NV + c; ib = ia + NV; }
-            else { const int f = e - 2 * NHOR, r = f / (NV - 1), c = f % (NV - 1); ia = r * NV + c + 1; ib = (r + 1) * NV + c; }   // (i, j+1) - (i+1, j)
-            if (ia == CENTRE || ib == CENTRE) continue;            // spokes: see the header
+        const int n_task = pre[NEDGE];
+        for (int c = lane; c < n_task; c += 64) {
+            int lo_e = 0, hi_e = NEDGE;                              // last edge with pre[e] <= c
+            while (hi_e - lo_e > 1) { const int mid = (lo_e + hi_e) >> 1; if (pre[mid] <= c) lo_e = mid; else hi_e = mid; }
+            const int e = lo_e;
+            int ia, ib;
+            edge_ends(e, ia, ib);
             const float ae = q[5 * ia], an = q[5 * ia + 1], az = q[5 * ia + 2];
             const float be = q[5 * ib], bn = q[5 * ib + 1], bz = q[5 * ib + 2];
             const float ra = __builtin_sqrtf(ae * ae + an * an), rb = __builtin_sqrtf(be * be + bn * bn);
             const float rmin = __builtin_fminf(ra, rb);
-            if (!(rmin > 1.0e-3f)) { flags[0] = 1; continue; }     // a vertex (almost) above / below the origin
-            const float pa = atan2f(ae, an), pb = atan2f(be, bn);  // azimuth clockwise from north
-            float dl = pb - pa;
-            if (dl > 3.14159265f) dl -= 6.2831853f;
-            if (dl < -3.14159265f) dl += 6.2831853f;
-            if (__builtin_fabsf(dl) > 2.9f) { flags[0] = 1; continue; }   // the edge passes (almost) over the origin
-            const float lo = dl >= 0.0f ? pa : pb, span = __builtin_fabsf(dl);
-            // margins: end points within tol of a plane count as lying in it
             const float tol_a = 1.0e-3f * ra + 0.01f, tol_b = 1.0e-3f * rb + 0.01f;
-            const float m_az = 2.0e-3f + 0.02f / rmin;
-            const int k_lo = (int)__builtin_floorf((lo - m_az) / dphi), k_hi = (int)__builtin_ceilf((lo + span + m_az) / dphi);
-            for (int kk = k_lo; kk <= k_hi; kk++) {
-                const int k = ((kk % A) + A) % A;
-                const float sp = p.azim_sin[k], cp = p.azim_cos[k];
+            const int first = ek[2 * e] + (c - pre[e]) * CH, last = min(first + CH, ek[2 * e] + ek[2 * e + 1]);
+            for (int kk = first; kk < last; kk++) {
+                int k = kk;                                          // kk lies in (-A, 2 A)
+                if (k < 0) k += A;
+                if (k >= A) k -= A;
+                const float sp = tab[k], cp = tab[A + k];
                 const float da = ae * cp - an * sp, db = be * cp - bn * sp;     // signed distances from the plane
                 float cand = -__builtin_inff();
                 const float fa = ae * sp + an * cp, fb = be * sp + bn * cp;     // along the azimuth (r of the end points)
@@ -204,7 +248,8 @@ int near_launch(const Scene *sc, const NearArgs &a, hipStream_t st) {
     p.near_idx = a.near_idx; p.near_r = a.near_r;
     if (p.n_cells <= 0) return HZ_OK;
     constexpr int NVERT = (2 * HZ_NEAR_W + 1) * (2 * HZ_NEAR_W + 1);
-    const size_t lds = (size_t)4 * (NVERT * 5 + a.azim_num + 4) * sizeof(float);
+    constexpr int NV = 2 * HZ_NEAR_W + 1, NEDGE = 2 * NV * (NV - 1) + (NV - 1) * (NV - 1);
+    const size_t lds = ((size_t)2 * a.azim_num + (size_t)4 * (NVERT * 5 + a.azim_num + 4 + 3 * NEDGE + 1)) * sizeof(float);
     const int grid = (p.n_cells + 3) / 4;
     hipLaunchKernelGGL(k_near_cert<HZ_NEAR_W>, dim3(grid), dim3(256), lds, st, p);
     HZ_HIP(hipGetLastError());

@@ -510,7 +510,8 @@ def test_near_field_certificates_are_transparent(hip, orc, case):
     assert np.array_equal(h_on, h_off) and np.array_equal(h_on, h_cpu)
     assert st_on["num_rays"] == st_off["num_rays"] == so["rays"]
     assert st_on["near_violations"] == 0 and st_off["rays_shortened"] == 0
-    assert st_on["rays_shortened"] > 0.3 * st_on["num_rays"], (st_on["rays_shortened"], st_on["num_rays"])
+    # (coarse tables leave less room: the margin is two table steps, 1.2 deg at hori_acc = 3 deg)
+    assert st_on["rays_shortened"] > (0.15 if case == "masked_coarse" else 0.3) * st_on["num_rays"], (st_on["rays_shortened"], st_on["num_rays"])
     # (the verifying pass traces the shortened rays twice, so its node count is not the product's)
     h_cnt, _ = hip.horizon.horizon_gridded(**kw, **par, count_work=True)
     st_cnt = dict(hip.horizon.last_stats)
