@@ -34,7 +34,7 @@
 namespace hz {
 
 #ifndef HZ_NEAR_W
-#define HZ_NEAR_W 3
+#define HZ_NEAR_W 2   // measured on the 3601^2 tile: w = 2 and w = 3 give the same total (kernel 196 + 4.8 ms vs 192 + 8.4 ms)
 #endif
 
 struct NearParams {
@@ -59,6 +59,7 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
     constexpr int NV = 2 * W + 1, NVERT = NV * NV, CENTRE = W * NV + W;
     constexpr int NHOR = NV * (NV - 1), NDIAG = (NV - 1) * (NV - 1), NEDGE = 2 * NHOR + NDIAG;
     constexpr int NSEG = 8 * W;        // boundary segments of the window polygon
+    static_assert(NVERT <= 64 && NSEG <= 64, "one lane per window vertex / boundary segment");
     constexpr int CH = 16;             // azimuths per task of the edge phase
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_near[];
     const int A = p.azim_num;
