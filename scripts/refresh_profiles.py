@@ -1,26 +1,62 @@
-"""Copy the rocprofv3 summaries of a bench run from gpurun_out/ into profiles/<round>/ and
-recompute profiles/traffic.json (usage: refresh_profiles.py <prefix> <round>, e.g. prof5 r01)."""
-import csv, glob, json, shutil, sys
+"""Copy the rocprofv3 summaries of a bench run from gpurun_out/ into profiles/<round>/ and recompute
+profiles/traffic.json (HBM bytes of k_horizon per launch) and profiles/valu_model.json (wave-level VALU
+instructions per wave iteration, calibrated on SQ_INSTS_VALU), both stamped with the hash of the kernel sources
+they were measured for -- bench.py refuses them when the sources changed.
+usage: refresh_profiles.py <prefix> <round>, e.g. prof2 r02"""
+import csv, glob, json, os, shutil, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
 pre, rnd = sys.argv[1], sys.argv[2]
+os.makedirs("profiles/%s" % rnd, exist_ok=True)
+sha = bench.kernel_source_sha()
 shutil.copy(glob.glob("gpurun_out/%s_kt/*/*kernel_stats.csv" % pre)[0], "profiles/%s/bench_kernel_stats.csv" % rnd)
 shutil.copy("gpurun_out/%s_kt_bench.json" % pre, "profiles/%s/bench_under_rocprof.json" % rnd)
+KERNEL = "k_horizon<2, false, true, false"
+
+
+def per_kernel(d, names):
+    agg = {}
+    for f in glob.glob("gpurun_out/%s_%s/*/*counter_collection.csv" % (pre, d)):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] in names:
+                agg.setdefault((r["Kernel_Name"].split("(")[0], r["Counter_Name"]), []).append(float(r["Counter_Value"]))
+    return agg
+
+
 out = {}
 for name, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
-    agg = {}
-    for r in csv.DictReader(open(glob.glob("gpurun_out/%s_%s/*/*counter_collection.csv" % (pre, d))[0])):
-        agg.setdefault(r["Kernel_Name"].split("(")[0], []).append(float(r["Counter_Value"]))
-    out[name] = {k: {"dispatches": len(v), "mean_KiB": sum(v) / len(v)} for k, v in agg.items() if "hz::" in k}
+    agg = per_kernel(d, (name,))
+    out[name] = {k[0]: {"dispatches": len(v), "mean_KiB": sum(v) / len(v)} for k, v in agg.items() if "hz::" in k[0]}
 json.dump(out, open("profiles/%s/pmc_fetch_write_summary.json" % rnd, "w"), indent=1)
-k = [x for x in out["FETCH_SIZE"] if "k_horizon<2, false, true, false" in x][0]
+k = [x for x in out["FETCH_SIZE"] if KERNEL in x][0]
 f, w = out["FETCH_SIZE"][k]["mean_KiB"], out["WRITE_SIZE"][k]["mean_KiB"]
 cal_r = out["FETCH_SIZE"]["hz::k_bounds"]["mean_KiB"] * 1024 / (12 * 3601 * 3601)
 cal_w = out["WRITE_SIZE"]["hz::k_emit_prims"]["mean_KiB"] * 1024 / (48 * 3600 * 3600)
-b = json.load(open("gpurun_out/%s_kt_bench.json" % pre))
-rows = int(b["config"]["cells_per_step"]) // 3569
-t = {"tile": 3601, "azim": 360, "rows_per_step": rows, "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024,
-     "fetch_bytes": 2 * f * 1024, "write_bytes": w * 1024,
-     "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (profiles/%s/pmc_fetch_write_summary.json); "
-             "KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2); calibration on this run: "
-             "k_bounds read ratio %.3f, k_emit_prims write ratio %.3f; kernel %s" % (rnd, cal_r, cal_w, k)}
+b = json.loads(open("gpurun_out/%s_kt_bench.json" % pre).read().strip().splitlines()[-1])
+t = {"tile": 3601, "azim": 360, "rows_per_step": 512, "kernel_source_sha": sha,
+     "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024, "fetch_bytes": 2 * f * 1024, "write_bytes": w * 1024,
+     "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (profiles/%s/pmc_fetch_write_summary.json), mean "
+             "over the launches of 2 steps; KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2); calibration "
+             "on this run: k_bounds read ratio %.3f, k_emit_prims write ratio %.3f; kernel %s" % (rnd, cal_r, cal_w, k)}
 json.dump(t, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps(t))
+# ---- VALU model: scale the per-iteration constants so that they reproduce SQ_INSTS_VALU ------------------------
+sq = per_kernel("sq", ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES_VALU", "SQ_WAVES", "SQ_INSTS_SALU",
+                       "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS"))
+kk = [x for x in sq if KERNEL in x[0]]
+if kk:
+    m = {c: sum(v) / len(v) for (kn, c), v in sq.items() if KERNEL in kn}
+    bs = json.loads(open("gpurun_out/%s_sq_bench.json" % pre).read().strip().splitlines()[-1])
+    model_winst = bs["roofline"].get("valu_winst_per_launch")
+    d = dict(bench.VALU_MODEL_DEFAULT)
+    fac = m["SQ_INSTS_VALU"] / model_winst if model_winst else None
+    vm = {"kernel_source_sha": sha, "sq_counters_per_launch": m, "model_winst_default_constants": model_winst,
+          "scale": fac, "lane_utilisation_valu": m["SQ_THREAD_CYCLES_VALU"] / (64.0 * m["SQ_INSTS_VALU"]) if m.get("SQ_INSTS_VALU") else None,
+          "note": "per-iteration constants of bench.py scaled by SQ_INSTS_VALU / (default model) on the launches of 2 bench steps "
+                  "(the counter pass of the same run supplies the wave-iteration counts)"}
+    if fac:
+        for key in ("node_iter", "leaf_iter", "refill_iter"):
+            vm[key] = d[key] * fac
+    json.dump(vm, open("profiles/valu_model.json", "w"), indent=1)
+    json.dump(vm, open("profiles/%s/valu_model.json" % rnd, "w"), indent=1)
+    print(json.dumps(vm))
