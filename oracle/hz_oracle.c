@@ -45,6 +45,8 @@
 #include "../horayzon_amd/csrc/hz_crmath.h"
 static int g_platform_libm = 0;
 void orc_set_libm(int platform) { g_platform_libm = platform; }
+static int g_quad_order = 0;      /* 1: second triangle of a quad as Embree's quad / grid intersector orders it */
+void orc_set_quad_order(int embree_quad) { g_quad_order = embree_quad; }
 static inline float r_acosf(float x) { return g_platform_libm ? acosf(x) : hz_crm_acosf(x); }
 static inline float r_tanf(float x) { return g_platform_libm ? tanf(x) : hz_crm_tanf(x); }
 static inline float r_cosf(float x) { return g_platform_libm ? cosf(x) : hz_crm_cosf(x); }
@@ -253,6 +255,12 @@ static inline int quad_hit(const orc_scene *s, int i, int j, const float *o,
     const float *c = vtx(s, i + 1, j), *e = vtx(s, i + 1, j + 1);
     if (cnt) cnt->tris += 2;
     if (dbl) return tri_hit_d(o, d, tfar, a, b, c) || tri_hit_d(o, d, tfar, b, e, c);
+    /* geom_type "quad" / "grid" hand Embree the quad (v0, v1, v2, v3) = (a, b, e, c) (horizon_comp.cpp:165-172); its
+     * quad intersector tests the triangles (v0, v1, v3) and (v2, v3, v1) = (a, b, c) and (e, c, b): the same two
+     * triangles as the explicit "triangle" topology (:142-148), the second one with its vertices rotated.  The
+     * rotation permutes the edge functions and changes which edge pair forms the normal, i.e. only the rounding.
+     * orc_set_quad_order(1) evaluates that order (tests measure how many results it moves: none so far). */
+    if (g_quad_order) return tri_hit_f(o, d, tfar, a, b, c) || tri_hit_f(o, d, tfar, e, c, b);
     return tri_hit_f(o, d, tfar, a, b, c) || tri_hit_f(o, d, tfar, b, e, c);
 }
 

@@ -62,6 +62,7 @@ def lib():
         L.orc_sky_view_factor.argtypes = [fp, fp, fp, C.c_int, C.c_int, C.c_int, fp]
         L.orc_num_threads.restype = C.c_int
         L.orc_set_libm.argtypes = [C.c_int]
+        L.orc_set_quad_order.argtypes = [C.c_int]
         L.orc_crmath_sweep.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, u64p]
         _lib = L
     return _lib
@@ -90,6 +91,13 @@ def set_libm(platform):
     """False (default): the refraction branch uses the shared correctly rounded hz_crmath.h routines;
     True: the platform's acosf / tanf / powf / cosf / sinf (to measure how much depends on them)."""
     lib().orc_set_libm(int(bool(platform)))
+
+
+def set_quad_order(embree_quad):
+    """False (default): second triangle of a DEM quad as (b, d, c), the explicit "triangle" topology
+    (horizon_comp.cpp:142-148).  True: as (d, c, b), the order Embree's quad / grid intersector forms from the quad
+    (v0, v1, v2, v3) of horizon_comp.cpp:165-172 -- same triangle, rotated vertices, different rounding."""
+    lib().orc_set_quad_order(int(bool(embree_quad)))
 
 
 def crmath_sweep(which, lo, hi, y=0.0):

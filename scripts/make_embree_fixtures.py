@@ -1,0 +1,131 @@
+#!/usr/bin/env python
+"""Pin harness: run the INSTALLED reference (ChristianSteger/HORAYZON with Intel Embree 4 + oneTBB, e.g. from the
+conda environment of its README) on the parity configurations of this repository and write its outputs to
+tests/golden/embree_*.npz.  `pytest -m gpu tests/test_gpu_embree_pin.py` (HIP kernels) and
+`pytest tests/test_oracle.py -k embree` (CPU oracle) then compare against those files and report the mismatch
+fraction against the north-star bar (1e-4 rad horizon, 1e-5 SVF).
+
+The build environment of this repository has neither Embree nor a network, so the files cannot be produced here:
+until a maintainer runs this script once, parity stays "unpinned" for the ray-casting decisions.
+
+    conda activate horayzon            # environment with the reference installed
+    python scripts/make_embree_fixtures.py [--out tests/golden]
+
+The inputs are regenerated from seeds by tests/cases.py / horayzon_amd/synth.py (NumPy only; no GPU needed); only
+parameters and the reference's OUTPUTS are stored.
+"""
+import argparse
+import importlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def import_reference():
+    """The installed reference package -- not this repository's alias package of the same name."""
+    saved = list(sys.path)
+    sys.path = [p for p in sys.path if os.path.abspath(p or ".") != ROOT]
+    for name in [m for m in sys.modules if m == "horayzon" or m.startswith("horayzon.")]:
+        del sys.modules[name]
+    try:
+        ref = importlib.import_module("horayzon")
+        hz = importlib.import_module("horayzon.horizon")
+        sh = importlib.import_module("horayzon.shadow")
+        tp = importlib.import_module("horayzon.topo_param")
+    finally:
+        sys.path = saved
+    f = getattr(hz, "__file__", "") or ""
+    if os.path.abspath(f).startswith(ROOT) or not f.endswith((".so", ".pyd")):
+        raise SystemExit("the imported 'horayzon' (%s) is not the compiled reference package: install "
+                         "ChristianSteger/HORAYZON (Embree 4, TBB) and run this script from its environment" % f)
+    return ref, hz, sh, tp
+
+
+def pin_cases():
+    """(name, grid kwargs, parameters): the configurations tests/test_gpu_embree_pin.py replays.  Searches that the
+    reference cannot finish (guard events) are avoided by the choice of elev_ang_low_lim."""
+    sys.path.insert(0, ROOT)
+    from tests import cases
+    from horayzon_amd import synth
+    out = []
+    c2 = cases.grid_kwargs(cases.c2_hill())
+    for alg in cases.ALGS:
+        for geom in ("triangle", "quad", "grid"):
+            out.append(("c2_%s_%s" % (alg, geom), c2, dict(dist_search=10.0, azim_num=36, ray_algorithm=alg, geom_type=geom)))
+    g = cases.rough_terrain(96, 110, seed=5, offset=6, relief=1200.0)
+    out.append(("rough_grid", cases.grid_kwargs(g), dict(dist_search=4.0, azim_num=72, elev_ang_low_lim=-60.0)))
+    g = cases.rough_terrain(80, 70, seed=8, offset=5, relief=700.0, tilt_frames=True, origin=(2.6e6, 1.2e6))
+    out.append(("tilted_large_coords", cases.grid_kwargs(g), dict(dist_search=3.0, azim_num=45, hori_acc=0.1,
+                                                                elev_ang_low_lim=-89.98, ray_algorithm="binary_search")))
+
+    def dem(z, dx=30.0, dy=30.0, offset=4):
+        n0, n1 = z.shape
+        x = (np.arange(n1) * dx).astype(np.float32)
+        y = ((n0 - 1 - np.arange(n0)) * dy).astype(np.float32)
+        xx, yy = np.meshgrid(x, y)
+        vn, vo = synth.planar_frames(n0 - 2 * offset, n1 - 2 * offset)
+        return dict(vert_grid=synth.pack_vertices(xx, yy, z.astype(np.float32)), dem_dim_0=n0, dem_dim_1=n1,
+                    vec_norm=vn, vec_north=vo, offset_0=offset, offset_1=offset)
+    # the degenerate shapes of tests/test_gpu_parity.py::test_degenerate_terrain_shapes
+    out.append(("flat", dem(np.full((40, 44), 250.0)), dict(dist_search=2.0, azim_num=16, elev_ang_low_lim=-89.98)))
+    yy, xx = np.mgrid[0:48, 0:52]
+    out.append(("terraces", dem(100.0 * ((xx // 6) % 4) + 50.0 * ((yy // 5) % 3)), dict(dist_search=2.0, azim_num=24, elev_ang_low_lim=-89.98)))
+    spike = np.zeros((33, 35)); spike[16, 17] = 500.0
+    out.append(("spike", dem(spike), dict(dist_search=2.0, azim_num=32, elev_ang_low_lim=-89.98)))
+    strip = 200.0 * np.random.default_rng(5).random((3, 400))
+    out.append(("strip", dem(strip, offset=0), dict(dist_search=20.0, azim_num=12, elev_ang_low_lim=-89.98)))
+    return out
+
+
+def shadow_case():
+    sys.path.insert(0, ROOT)
+    from tests import cases
+    from horayzon_amd import synth
+    g = cases.c2_hill(height=1500.0)
+    vec_tilt, vec_norm, enl, elev, mask = cases.terrain_inputs(g)
+    mask[5:9, 5:20] = 0
+    suns, _, _ = synth.sun_positions(num=24)
+    suns = suns + np.array([5000.0, 5000.0, 0.0], np.float32)
+    return g, (vec_tilt, vec_norm, enl, elev, mask), suns
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    args = ap.parse_args()
+    ref, hz, sh, tp = import_reference()
+    os.makedirs(args.out, exist_ok=True)
+    store = {}
+    for name, kw, par in pin_cases():
+        print("reference horizon_gridded:", name, flush=True)
+        hori, azim = hz.horizon_gridded(kw["vert_grid"], kw["dem_dim_0"], kw["dem_dim_1"], kw["vec_norm"], kw["vec_north"],
+                                        kw["offset_0"], kw["offset_1"], **par)
+        store["hori__" + name] = hori
+        store["azim__" + name] = azim
+    # SVF of the first case through the reference's own topo_param (pins the fused SVF too)
+    name, kw, par = pin_cases()[0]
+    tilt = np.zeros(kw["vec_norm"].shape, np.float32); tilt[..., 2] = 1.0
+    store["svf__" + name] = tp.sky_view_factor(store["azim__" + name], store["hori__" + name], tilt)
+    np.savez_compressed(os.path.join(args.out, "embree_horizon.npz"), version=getattr(ref, "__version__", "unknown"), **store)
+    g, (vec_tilt, vec_norm, enl, elev, mask), suns = shadow_case()
+    sstore = {"suns": suns}
+    for refrac in (False, True):
+        for geom in ("triangle", "grid"):
+            t = sh.Terrain()
+            t.initialise(g["vert_grid"], 200, 200, 10, 10, vec_tilt, vec_norm, enl, elev, mask, geom_type=geom,
+                         refrac_cor=refrac, sw_dir_cor_fill=-9.0)
+            shm = np.empty((suns.shape[0],) + mask.shape, np.uint8)
+            swc = np.empty((suns.shape[0],) + mask.shape, np.float32)
+            for s in range(suns.shape[0]):
+                t.shadow(suns[s], shm[s]); t.sw_dir_cor(suns[s], swc[s])
+            sstore["shadow__%s_refrac%d" % (geom, int(refrac))] = shm
+            sstore["sw_dir_cor__%s_refrac%d" % (geom, int(refrac))] = swc
+    np.savez_compressed(os.path.join(args.out, "embree_shadow.npz"), **sstore)
+    print("wrote", os.path.join(args.out, "embree_horizon.npz"), "and embree_shadow.npz")
+
+
+if __name__ == "__main__":
+    main()

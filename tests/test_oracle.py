@@ -346,3 +346,85 @@ def test_refraction_depends_little_on_the_platform_libm(orc):
     finally:
         orc.set_libm(False)
     assert diff / tot <= 1.0e-4 and worst <= 2.0e-5, (diff, tot, worst)
+
+
+def test_embree_quad_vertex_order_changes_nothing(orc):
+    """geom_type "quad" / "grid" (the default) reach Embree as quads (v0, v1, v2, v3) = ((i,j), (i,j+1), (i+1,j+1),
+    (i+1,j)), which its intersector splits into (v0, v1, v3) and (v2, v3, v1): the triangles of the "triangle"
+    topology with the second one's vertices rotated.  The oracle evaluates both orders: on config 2 (all three
+    algorithms), on rough terrain with tilted frames and on the degenerate shapes no horizon value and no ray count
+    changes (the rotation only reorders roundings of a test whose tolerance is relative)."""
+    jobs = []
+    kw = cases.grid_kwargs(cases.c2_hill())
+    for alg in cases.ALGS:
+        jobs.append((kw, dict(dist_search=10.0, azim_num=36, ray_algorithm=alg)))
+    g = cases.rough_terrain(90, 84, seed=21, offset=5, relief=1800.0, tilt_frames=True, origin=(2.6e6, 1.2e6))
+    jobs.append((cases.grid_kwargs(g), dict(dist_search=3.0, azim_num=60, hori_acc=0.1, elev_ang_low_lim=-60.0)))
+    yy, xx = np.mgrid[0:48, 0:52]
+    terr = (100.0 * ((xx // 6) % 4) + 50.0 * ((yy // 5) % 3)).astype(np.float32)
+    from horayzon_amd import synth
+    x = (np.arange(52) * 30.0).astype(np.float32); y = ((47 - np.arange(48)) * 30.0).astype(np.float32)
+    vn, vo = synth.planar_frames(40, 44)
+    jobs.append((dict(vert_grid=synth.pack_vertices(*np.meshgrid(x, y), terr), dem_dim_0=48, dem_dim_1=52, vec_norm=vn,
+                      vec_north=vo, offset_0=4, offset_1=4), dict(dist_search=2.0, azim_num=24, elev_ang_low_lim=-80.0)))
+    changed = total = 0
+    try:
+        for kw, par in jobs:
+            orc.set_quad_order(False)
+            h0, _, s0 = orc.horizon_gridded(**kw, **par, return_stats=True)
+            orc.set_quad_order(True)
+            h1, _, s1 = orc.horizon_gridded(**kw, **par, return_stats=True)
+            changed += int((h0 != h1).sum()); total += h0.size
+            assert s0["rays"] == s1["rays"]
+    finally:
+        orc.set_quad_order(False)
+    assert total > 2.0e6 and changed == 0, (changed, total)
+
+
+# ---------------------------------------------------------------------------------------
+# pin against the Embree reference, when a maintainer has produced the fixtures (scripts/make_embree_fixtures.py)
+# ---------------------------------------------------------------------------------------
+from tests import embree_pin   # noqa: E402
+
+
+@pytest.mark.skipif(not os.path.exists(embree_pin.HORIZON), reason=embree_pin.MISSING)
+def test_oracle_horizon_against_embree_reference(orc):
+    embree_pin.compare_horizon(orc.horizon_gridded)
+
+
+@pytest.mark.skipif(not os.path.exists(embree_pin.SHADOW), reason=embree_pin.MISSING)
+def test_oracle_shadow_against_embree_reference(orc):
+    embree_pin.compare_shadow(orc.Terrain)
+
+
+def test_embree_pin_harness_is_consistent(orc):
+    """The harness replays seeded configurations: they must be reproducible (same bytes twice) and the comparison code
+    must accept the oracle against itself (run through a temporary fixture made from the oracle's own outputs)."""
+    import tempfile
+    h = embree_pin._harness()
+    a, b = h.pin_cases(), h.pin_cases()
+    assert [n for n, _, _ in a] == [n for n, _, _ in b] and len(a) == 15
+    for (_, kw0, _), (_, kw1, _) in zip(a, b):
+        assert np.array_equal(kw0["vert_grid"], kw1["vert_grid"])
+    store = {}
+    for name, kw, par in a[:2] + a[9:]:
+        hori, azim = orc.horizon_gridded(**kw, **par)
+        store["hori__" + name] = hori
+    saved = embree_pin.HORIZON
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "embree_horizon.npz")
+        # only the cases computed above: restrict the replay accordingly
+        np.savez_compressed(path, **store)
+        embree_pin.HORIZON = path
+        orig = h.pin_cases
+        try:
+            embree_pin._harness = lambda: type("H", (), {"pin_cases": staticmethod(lambda: a[:2] + a[9:]),
+                                                          "shadow_case": staticmethod(h.shadow_case)})
+            rep = embree_pin.compare_horizon(orc.horizon_gridded)
+        finally:
+            embree_pin.HORIZON = saved
+            embree_pin._harness = _orig_harness
+    assert all(v["mismatch_fraction"] == 0.0 and v["max_abs"] == 0.0 for v in rep.values())
+
+
+_orig_harness = embree_pin._harness
