@@ -250,7 +250,7 @@ def run_c3(ctx):
                    "parallelism": "weak scaling x%d: same slab sequence, rank r starts at step r K; scene broadcast once" % world,
                    "bvh_build_s": scene_stats["t_bvh_s"] if scene_stats else None,
                    "scene_bytes": int(blob_bytes), "scene_bcast_s": t_bcast, "scene_create_wall_s": t_build,
-                   "load_imbalance_max_over_mean": imbalance, "stack_retries": int(stats.stack_retries)},
+                   "load_imbalance_max_over_mean": imbalance, "near_prepass_ms_per_step": 1e3 * stats.t_near_s / max(steps, 1)},
         "roofline": roofline(args, stats, steps, cw, peaks, A, n, rps),
     }
     if world == 1 and not args.no_cpu_baseline:
@@ -402,7 +402,7 @@ def run_c5(ctx):
                    "load_imbalance_max_over_mean": res["imbalance"] if res else None,
                    "bvh_build_s": scene_stats["t_bvh_s"] if scene_stats else None, "scene_bytes": int(blob_bytes),
                    "scene_bcast_s": t_bcast, "scene_create_wall_s": t_build, "kernel_s_rank0": stats.t_kernel_s,
-                   "svf_kernel_s_rank0": stats.t_svf_s, "stack_retries_rank0": int(stats.stack_retries),
+                   "svf_kernel_s_rank0": stats.t_svf_s, "near_prepass_s_rank0": stats.t_near_s,
                    "gathered_svf_finite": svf_ok},
         "roofline": {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None,
                      "traffic": None, "note": "see the c3 line: same kernel; c5 reports scaling, not the kernel roofline"},

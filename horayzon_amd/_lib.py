@@ -26,7 +26,7 @@ class hz_opts(C.Structure):
                 ("count_work", C.c_int32), ("no_hit_cache", C.c_int32),
                 ("svf", C.c_void_p), ("vec_tilt", C.c_void_p),
                 ("skip_hori", C.c_int32), ("chunk_rows", C.c_int32),
-                ("stack_entries", C.c_int32), ("hori_is_slab", C.c_int32),
+                ("reserved0", C.c_int32), ("hori_is_slab", C.c_int32),
                 ("no_near_skip", C.c_int32), ("verify_near", C.c_int32)]
 
 
@@ -39,7 +39,7 @@ class hz_stats(C.Structure):
                 ("bvh_height", C.c_int32), ("elev_num", C.c_int32),
                 ("scene_bytes", C.c_uint64), ("wave_node_iters", C.c_uint64),
                 ("wave_leaf_iters", C.c_uint64), ("wave_refills", C.c_uint64),
-                ("t_svf_s", C.c_double), ("stack_retries", C.c_uint64),
+                ("t_svf_s", C.c_double),
                 ("rays_shortened", C.c_uint64), ("near_violations", C.c_uint64), ("t_near_s", C.c_double)]
 
     def as_dict(self):
@@ -55,9 +55,9 @@ SYMBOLS = (
     "hz_sky_view_factor", "hz_visible_sky_fraction", "hz_topographic_openness",
     "hz_slope_plane_meth", "hz_slope_vector_meth", "hz_lonlat2ecef", "hz_ecef2enu",
     "hz_ecef2enu_vector", "hz_surf_norm", "hz_north_dir", "hz_vert_grid_len", "hz_pack_vertices",
-    "hz_debug_sort_pairs", "hz_debug_exclusive_scan", "hz_debug_stack_cap",
+    "hz_debug_sort_pairs", "hz_debug_exclusive_scan",
     "hz_debug_valu_peak", "hz_debug_copy_peak",
-    "hz_terrain_create", "hz_terrain_set_stack_entries", "hz_terrain_initialise", "hz_terrain_initialise_scene",
+    "hz_terrain_create", "hz_terrain_initialise", "hz_terrain_initialise_scene",
     "hz_terrain_shadow", "hz_terrain_sw_dir_cor", "hz_terrain_shadow_batch",
     "hz_terrain_sw_dir_cor_batch", "hz_terrain_destroy",
 )
@@ -106,7 +106,6 @@ def lib():
     L.hz_scene_blob.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     L.hz_scene_adopt.argtypes = [vp, C.c_size_t, ip, C.POINTER(vp)]
     L.hz_scene_destroy.argtypes = [vp]
-    L.hz_terrain_set_stack_entries.argtypes = [vp, ip]
     L.hz_horizon_gridded.argtypes = [
         vp, ip, ip, vp, vp, ip, ip, vp, ip, ip, ip, C.c_float, C.c_float,
         C.c_char_p, C.c_char_p, vp, ip, vp, ip, C.c_float, vp, C.c_float,

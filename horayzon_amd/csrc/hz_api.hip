@@ -203,8 +203,6 @@ struct Terrain {
     float fill = 0, ang_max = 89.0f;
     int refrac = 0;
     unsigned long long *counters = nullptr;   // device u64[16]
-    int stack_entries = 0;                    // 0: default of shadow_launch
-    int stack_level = 0;                      // residency level that has worked so far (shadow_launch)
     hipStream_t stream = nullptr;
     bool initialised = false;
 };
@@ -337,7 +335,6 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     a.regroup = opts ? opts->regroup : -1;
     a.count_work = opts ? opts->count_work : 0;
     a.hit_cache = (opts && opts->no_hit_cache) ? 0 : 1;
-    a.stack_entries = opts ? opts->stack_entries : 0;
     a.counters = (unsigned long long *)cnt_dev;
     // near-field certificates (hz_near.hip): one pre-pass per chunk into a scratch buffer kept with the scene.
     // Off with an outer-domain TIN (its triangles are not part of the height field the distance bound relies on),
@@ -348,14 +345,8 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     a.verify_near = (opts && opts->verify_near) ? 1 : 0;
     float ms_near = 0.0f;
 
-    // The LDS traversal stack is sized for residency, not for the worst case (horizon_launch: levels 0, 1, 2
-    // = 5 / 4 workgroups per CU / worst-case depth).  A wave whose ray needed more entries raises
-    // counters[8]; the chunk is then repeated one level up and the scene remembers the level, so that a
-    // deep tree pays for one wasted chunk, once.
     unsigned long long cnt[16] = {0};
     float ms = 0.0f, ms_svf = 0.0f;
-    int retries = 0;
-    int level = sc->stack_level.load(std::memory_order_relaxed);
 
     // HIP events on the kernels' stream: horizon kernel and SVF kernel are timed separately
     struct Ev { hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr; };
@@ -426,8 +417,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             (void)hipEventDestroy(n0); (void)hipEventDestroy(n1);
             a.near_idx = na.near_idx; a.near_r = na.near_r;
         }
-        bool prev_copied = false;
-        for (;;) {                                     // attempts of this chunk
+        {
             Ev e;
             if (hipEventCreate(&e.a) != hipSuccess || hipEventCreate(&e.b) != hipSuccess || hipEventCreate(&e.c) != hipSuccess ||
                 hipEventCreate(&e.d) != hipSuccess) {
@@ -435,21 +425,19 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
                 return fail(set_error(HZ_ERR_HIP, "hipEventCreate failed"));
             }
             evs.push_back(e);
-            if (ev_of.size() <= (size_t)n_chunk) ev_of.push_back(evs.size() - 1); else ev_of[(size_t)n_chunk] = evs.size() - 1;
-            a.stack_level = level;
+            ev_of.push_back(evs.size() - 1);
             if (hipMemcpyAsync(cnt_dev, zeros, sizeof(zeros), hipMemcpyHostToDevice, st) != hipSuccess)
                 return fail(set_error(HZ_ERR_HIP, "counter reset failed"));
             // the buffer of chunk n is the one chunk n - 2 was copied out of
             if (stream_out && n_chunk >= 2) (void)hipStreamWaitEvent(st, evs[ev_of[(size_t)n_chunk - 2]].d, 0);
             (void)hipEventRecord(e.a, st);
-            int cap_is_full = 0;
-            rc = horizon_launch(sc, a, st, &cap_is_full);
+            rc = horizon_launch(sc, a, st);
             (void)hipEventRecord(e.b, st);
             if (!rc && want_svf)
                 rc = svf_launch(d_azim.dev, hori_chunk, d_tilt.dev + 3 * (size_t)rb * dim_in_1, re - rb, dim_in_1,
                                 azim_num, d_svf.dev + (size_t)(rb - row_begin) * dim_in_1, st);
             (void)hipEventRecord(e.c, st);
-            if (!rc && stream_out && n_chunk >= 1 && !prev_copied) { rc = copy_out(n_chunk - 1); prev_copied = true; }
+            if (!rc && stream_out && n_chunk >= 1) rc = copy_out(n_chunk - 1);
             if (rc) return fail(rc);
             unsigned long long c[16];
             if (hipMemcpyAsync(c, cnt_dev, sizeof(c), hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -459,14 +447,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             (void)hipEventElapsedTime(&m1, e.a, e.b);
             (void)hipEventElapsedTime(&m2, e.b, e.c);
             ms += m1; ms_svf += m2;
-            if (c[8] != 0 && !cap_is_full) {           // a ray ran out of stack: one level up, same chunk again
-                level++; retries++;
-                int seen = sc->stack_level.load(std::memory_order_relaxed);
-                while (seen < level && !sc->stack_level.compare_exchange_weak(seen, level, std::memory_order_relaxed)) {}
-                continue;
-            }
             for (int k = 0; k < 16; k++) cnt[k] += c[k];
-            break;
         }
     }
     Timer t_d2h; t_d2h.start();
@@ -491,7 +472,6 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         stats->t_d2h_s += d2h_s;
         stats->t_total_s += t_total.stop();
         stats->elev_num = tb.elev_num; stats->bvh_height = sc->hdr.height; stats->scene_bytes = sc->hdr.total_bytes;
-        stats->stack_retries += (uint64_t)retries;
         stats->rays_shortened += cnt[9]; stats->near_violations += cnt[10]; stats->t_near_s += (double)ms_near * 1e-3;
     }
     if (opts && opts->verbose) {   // the reference's report, horizon_comp.cpp:673-700, 805-810 (same lines, same order)
@@ -1122,35 +1102,25 @@ static int terrain_run(Terrain *t, const float *sun_positions, int num_sun, int 
     a.sw_dir_cor_fill = t->fill;
     a.dot_prod_min = cosf(deg2rad_f(t->ang_max));            // shadow_comp.cpp:498
     a.refrac_cor = t->refrac; a.which = which; a.top_nodes = -1; a.counters = t->counters;
-    a.stack_entries = t->stack_entries;
     float ms = 0.0f;
     unsigned long long cnt[16];
-    int retries = 0;
-    // LDS stack sized for residency (shadow_launch levels); a ray that needed more raises counters[8], the
-    // batch is repeated one level up and the terrain remembers the level
-    for (;;) {
-        a.stack_level = t->stack_level;
+    {
         HZ_HIP(hipMemsetAsync(t->counters, 0, 16 * sizeof(unsigned long long), st));
         hipEvent_t e0, e1;
         HZ_HIP(hipEventCreate(&e0)); HZ_HIP(hipEventCreate(&e1));
         HZ_HIP(hipEventRecord(e0, st));
-        int cap_is_full = 1;
         for (int s = 0; s < num_sun; s++) {
             a.sun[0] = sun[3 * (size_t)s]; a.sun[1] = sun[3 * (size_t)s + 1]; a.sun[2] = sun[3 * (size_t)s + 2];
             a.out_u8 = d_u8.dev ? d_u8.dev + nc * (size_t)s : nullptr;
             a.out_f32 = d_f32.dev ? d_f32.dev + nc * (size_t)s : nullptr;
-            if ((rc = shadow_launch(t->scene, a, st, &cap_is_full))) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
+            if ((rc = shadow_launch(t->scene, a, st))) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
         }
         HZ_HIP(hipEventRecord(e1, st));
         HZ_HIP(hipEventSynchronize(e1));
-        float m = 0.0f;
-        HZ_HIP(hipEventElapsedTime(&m, e0, e1));
-        ms += m;
+        HZ_HIP(hipEventElapsedTime(&ms, e0, e1));
         (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
         HZ_HIP(hipMemcpyAsync(cnt, t->counters, sizeof(cnt), hipMemcpyDeviceToHost, st));
         HZ_HIP(hipStreamSynchronize(st));
-        if (cnt[8] == 0 || cap_is_full) break;
-        t->stack_level++; retries++;
     }
     Timer t_d2h; t_d2h.start();
     if ((rc = d_u8.finish(st))) return rc;
@@ -1162,20 +1132,7 @@ static int terrain_run(Terrain *t, const float *sun_positions, int num_sun, int 
         stats->t_d2h_s += t_d2h.stop();
         stats->t_total_s += t_total.stop();
         stats->bvh_height = t->scene->hdr.height; stats->scene_bytes = t->scene->hdr.total_bytes;
-        stats->stack_retries += (uint64_t)retries;
     }
-    return HZ_OK;
-}
-
-int hz_debug_stack_cap(int height, int other_lds_bytes, int override_entries, int level) {
-    return stack_cap_for_level(height, other_lds_bytes, override_entries, level);
-}
-
-int hz_terrain_set_stack_entries(hz_terrain *terrain, int entries) {
-    Terrain *t = reinterpret_cast<Terrain *>(terrain);
-    if (!t || entries < 0) return set_error(HZ_ERR_ARG, "invalid terrain handle or entry count");
-    t->stack_entries = entries;
-    t->stack_level = 0;
     return HZ_OK;
 }
 

@@ -6,32 +6,30 @@
 //
 // vertices : the caller's vert_grid, untouched (ray origins read them;
 //            reference: shared vertex buffer, horizon_comp.cpp:126-127).
-// nodes    : flat LBVH collapsed to 4-wide nodes along the 2-bit digits of the
-//            Morton key (= a quadtree over the (x, y) centroids).  One node is
-//            64 B and holds the conservatively quantised AABBs (8 bit x/y,
-//            16 bit z, relative to the node's own box) and the links of up to 4
-//            children (the four Morton quadrants), stored tallest (largest z-max) first.
-//            The first `n_top` nodes are the top of the tree in breadth-first
-//            order (contiguous hot levels; the optional LDS nodelet stages them).  AABBs live in a frame
-//            centred on the scene (`center`) and are padded by `pad`, which
-//            makes the box test conservative with respect to the float32
-//            triangle test: hit decisions depend on the triangle test only,
-//            never on the tree.
+// nodes    : flat LBVH collapsed to 4-wide nodes along the 2-bit digits of the Morton key (= a quadtree over the
+//            (x, y) centroids).  One node is 64 B and holds the conservatively quantised AABBs (8 bit x/y, 16 bit z,
+//            relative to the node's own box) of up to 4 children, stored tallest (largest z-max) first.  ALL nodes
+//            are numbered breadth first and the children of a node are CONTIGUOUS: one index (`first`) addresses
+//            the block of 4 child slots -- 4 consecutive nodes, or 4 consecutive leaf records (a node whose children
+//            were mixed got its leaves wrapped into single-child nodes, so a block is of one kind).  A traversal
+//            therefore keeps ONE stack entry per tree level (block + 3-bit mask of the siblings still to visit): the
+//            stack is `height` entries deep, with no overflow case.  AABBs live in a frame centred on the scene
+//            (`center`) and are padded by `pad`, which makes the box test conservative with respect to the float32
+//            triangle test: hit decisions depend on the triangle test only, never on the tree.
 // anc      : per leaf the index of the node a few levels above it.  A ray that is expected to be
 //            blocked (it points below the horizon found for the previous azimuth) first walks the
 //            subtree above the leaf that blocked the previous ray of this cell -- the blocking
 //            ridge moves little between neighbouring azimuths -- and only falls back to the root
 //            when that finds nothing.  Any-hit results cannot change (section 4 of DESIGN.md).
-// prims    : one 48 B record per leaf in Morton order = the 4 corner vertices
-//            of a DEM quad (two triangles a,b,c / b,d,c -- the split of
-//            horizon_comp.cpp:139-151) or the 3 vertices of a TIN triangle
-//            (d.x = NaN), raw coordinates.
+// prims    : 48 B leaf records in blocks of 4 (the leaf children of one node, in that node's slot order; unused
+//            slots are zero) = the 4 corner vertices of a DEM quad (two triangles a,b,c / b,d,c -- the split of
+//            horizon_comp.cpp:139-151) or the 3 vertices of a TIN triangle (d.x = NaN), raw coordinates.
 #pragma once
 #include <stdint.h>
 #include <hip/hip_runtime.h>
 
 #define HZ_BLOB_MAGIC 0x485a4c42u /* "HZLB" */
-#define HZ_BLOB_VERSION 4u
+#define HZ_BLOB_VERSION 5u
 #define HZ_WAVE 64
 
 struct BlobHeader {
@@ -46,18 +44,21 @@ struct BlobHeader {
     uint64_t off_verts, off_nodes, off_prims, total_bytes;
     uint64_t off_anc;        // int32[P]: for every leaf the node `anc_levels` levels above it (hit cache)
     int32_t anc_levels;
-    uint8_t reserved[256 - 132];
+    int32_t n_prim_slots;    // leaf records incl. the unused slots of partly filled blocks (prims, anc are this long)
+    uint8_t reserved[256 - 136];
 };
 static_assert(sizeof(BlobHeader) == 256, "BlobHeader must be 256 bytes");
 
-// link >= 0: internal node index; link < 0: leaf, prim index = ~link; HZ_EMPTY: no child
+// traversal links: >= 0 node index; < 0 leaf, record index = ~link; HZ_EMPTY: nothing
 #define HZ_EMPTY ((int)0x80000000)
 struct __attribute__((aligned(64))) Node {
     float org[3];        // lower corner of the node's box (centred frame)
-    uint32_t scale;      // biased float exponents of the x | y<<8 | z<<16 quantisation steps
+    int32_t first;       // >= 0: children are nodes first .. first + 3;  < 0: children are leaf records ~first .. ~first + 3
+                         // (both 4-aligned; child slot k exists iff bit k of `valid`)
     uint32_t qxy[4];     // per child slot: xlo | xhi<<8 | ylo<<16 | yhi<<24   (8 bit, 0..255)
     uint32_t qz[4];      // per child slot: zlo | zhi<<16                      (16 bit)
-    int32_t link[4];
+    float step[3];       // quantisation steps of x, y, z (powers of two)
+    uint32_t valid;
 };
 static_assert(sizeof(Node) == 64, "Node must be 64 bytes");
 
@@ -254,11 +255,8 @@ __device__ __forceinline__ RayBox hz_raybox(float ocx, float ocy, float ocz,
 // per-node constants: t = q * a + b maps a quantised coordinate to a ray parameter
 struct NodeRay { float ax, bx, ay, by, az, bz; };
 
-__device__ __forceinline__ NodeRay hz_node_ray(const RayBox &r, float ox, float oy, float oz, uint32_t scale) {
+__device__ __forceinline__ NodeRay hz_node_ray(const RayBox &r, float ox, float oy, float oz, float sx, float sy, float sz) {
     NodeRay n;
-    const float sx = __uint_as_float((scale & 0xffu) << 23);
-    const float sy = __uint_as_float(((scale >> 8) & 0xffu) << 23);
-    const float sz = __uint_as_float(((scale >> 16) & 0xffu) << 23);
     n.ax = sx * r.rdx; n.bx = __builtin_fmaf(ox, r.rdx, -r.ordx);
     n.ay = sy * r.rdy; n.by = __builtin_fmaf(oy, r.rdy, -r.ordy);
     n.az = sz * r.rdz; n.bz = __builtin_fmaf(oz, r.rdz, -r.ordz);
@@ -284,7 +282,7 @@ __device__ __forceinline__ bool hz_qbox_hit(const NodeRay &n, const RayBox &r, f
 
 // One 64 B node = 4 x 16 B global loads issued back to back and waited for once.
 // (hipcc was seen to put an s_waitcnt between the halves of the plain C++ form.)
-__device__ __forceinline__ void hz_load_node(const Node *n, float4 &n0, uint4 &n1, uint4 &n2, int4 &n3) {
+__device__ __forceinline__ void hz_load_node(const Node *n, float4 &n0, uint4 &n1, uint4 &n2, float4 &n3) {
     asm volatile("global_load_dwordx4 %0, %4, off\n\t"
                  "global_load_dwordx4 %1, %4, off offset:16\n\t"
                  "global_load_dwordx4 %2, %4, off offset:32\n\t"
@@ -296,7 +294,7 @@ __device__ __forceinline__ void hz_load_node(const Node *n, float4 &n0, uint4 &n
 }
 
 // The same node from the LDS nodelet (4 x ds_read_b128, one wait).
-__device__ __forceinline__ void hz_load_node_lds(const float4 *q, float4 &n0, uint4 &n1, uint4 &n2, int4 &n3) {
+__device__ __forceinline__ void hz_load_node_lds(const float4 *q, float4 &n0, uint4 &n1, uint4 &n2, float4 &n3) {
     const unsigned addr = (unsigned)(size_t)reinterpret_cast<const __attribute__((address_space(3))) char *>(
         (const __attribute__((address_space(3))) float4 *)q);
     asm volatile("ds_read_b128 %0, %4\n\t"
@@ -322,12 +320,15 @@ __device__ __forceinline__ void hz_load_prim(const Prim *q, float4 &q0, float4 &
 
 // ---------------------------------------------------------------------------
 // any-hit traversal of one ray, resumable.
-//   TravState : node (current link), sp (stack pointer), up to 4 queued leaves
-//   stack     : per-lane LDS stack, entry k of lane tid at stack[k * TPB + tid]
+//   TravState : node (current link), sp (LDS stack pointer), top (the pending-siblings entry of the level being
+//               descended, kept in a register; 0 = none), up to 2 queued leaves
+//   stack     : per-lane LDS stack, entry k of lane tid at stack[k * TPB + tid]; one entry per tree level:
+//               entry = type << 31 | (block >> 2) << 4 | mask   -- block = the node's `first` (nodes) or ~first
+//               (leaves), mask = child slots 1..3 still to visit (slot 0 is never pending: the first hit child is
+//               entered at once).  At most one entry per level is alive, so `height` entries can never overflow.
 //   top       : LDS copy of the first ntop nodes, read only by the NODELET instantiation (else null / 0)
 //   regroup   : leave when fewer than `regroup` lanes of the wave are still traversing (and at least one
 //               lane finished in this call, so the caller can refill it)
-//   stack_cap : entries per lane the LDS stack holds (>= 3); `overflow` is set when a ray needed more
 //   leaf_bias : the wave takes the node step when 16 * (lanes with a node) >= leaf_bias * (lanes with a leaf)
 // Scheduling inside the wave: every lane sets leaves aside (up to QLEN) and keeps descending;
 // each iteration the wave executes ONE kind of step -- the node step or the leaf step --
@@ -336,10 +337,24 @@ __device__ __forceinline__ void hz_load_prim(const Prim *q, float4 &q0, float4 &
 // returns 0 = miss, 1 = hit (t.lq0 is the blocking leaf), 2 = suspended (state is valid, call again)
 // ---------------------------------------------------------------------------
 struct TravCounters { unsigned nodes, tris, w_nodes, w_leaves; };
-struct TravState { int node, sp, lq0, lq1, lq2, lq3; };
+struct TravState { int node, sp, top, lq0, lq1; };
 
 __device__ __forceinline__ void hz_trav_reset(TravState &t) {
-    t.node = 0; t.sp = 0; t.lq0 = HZ_EMPTY; t.lq1 = HZ_EMPTY; t.lq2 = HZ_EMPTY; t.lq3 = HZ_EMPTY;
+    t.node = 0; t.sp = 0; t.top = 0; t.lq0 = HZ_EMPTY; t.lq1 = HZ_EMPTY;
+}
+
+// pending-siblings entry of a node whose children block starts at `first`, for the hit mask `rest` (bits 1..3)
+__device__ __forceinline__ int hz_entry(int first, int rest) {
+    const int sgn = first >> 31;                       // 0 nodes, -1 leaves
+    return (int)(((unsigned)(first ^ sgn) << 2) | (unsigned)rest | ((unsigned)sgn & 0x80000000u));
+}
+// next pending child of entry `e` (e != 0); clears it from the entry's mask (the entry may become exhausted: mask 0)
+__device__ __forceinline__ int hz_entry_next(int &e) {
+    const int m = e & 15;
+    const int slot = __builtin_ctz((unsigned)m);
+    const int child = (int)(((unsigned)e & 0x7ffffff0u) >> 2) + slot;
+    e &= ~(1 << slot);
+    return (e < 0) ? ~child : child;
 }
 
 #define HZ_WAVE_TICK(c, lane_) do { const unsigned long long m_ = __ballot(1); if ((lane_) == __ffsll((long long)m_) - 1) (c)++; } while (0)
@@ -349,21 +364,20 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
                                         const float4 *top, int ntop, int *stack, int tid,
                                         float ox, float oy, float oz, float dx, float dy, float dz, float tfar,
                                         const RayBox &rb, TravState &t, int regroup, int leaf_bias,
-                                        TravCounters &cnt, int stack_cap, unsigned &overflow) {
+                                        TravCounters &cnt) {
     const int lane = tid & 63;
-    int node = t.node, sp = t.sp, lq0 = t.lq0, lq1 = t.lq1, lq2 = t.lq2, lq3 = t.lq3;
+    int node = t.node, sp = t.sp, pend = t.top, lq0 = t.lq0, lq1 = t.lq1;
     const int n_entry = __popcll(__ballot(1));   // lanes that entered with a ray
-// branch-free pop: read the (clamped) top entry, keep it only if the stack was not empty
-#define HZ_POP() do { const bool ne = sp > 0; sp = ne ? sp - 1 : 0; const int pv = stack[sp * TPB + tid]; \
-                      node = ne ? pv : HZ_EMPTY; } while (0)
-#define HZ_SAVE() do { t.node = node; t.sp = sp; t.lq0 = lq0; t.lq1 = lq1; t.lq2 = lq2; t.lq3 = lq3; } while (0)
+// next link: the pending entry of the current level first, then the levels above (LDS), else nothing
+#define HZ_POP() do { if (pend != 0 && (pend & 15) == 0) { const bool ne = sp > 0; sp = ne ? sp - 1 : 0; \
+                          const int pv = stack[sp * TPB + tid]; pend = ne ? pv : 0; } \
+                      if (pend != 0) node = hz_entry_next(pend); else node = HZ_EMPTY; } while (0)
+#define HZ_SAVE() do { t.node = node; t.sp = sp; t.top = pend; t.lq0 = lq0; t.lq1 = lq1; } while (0)
     int res = -1;                 // single exit: lanes leave the loop through `res`, state is saved once
     while (res < 0) {
         // set leaves aside while the leaf queue (QLEN entries, filled front to back) has room
         if (node < 0 && node != HZ_EMPTY && lq0 == HZ_EMPTY) { lq0 = node; HZ_POP(); }
         if (node < 0 && node != HZ_EMPTY && lq1 == HZ_EMPTY) { lq1 = node; HZ_POP(); }
-        if (QLEN > 2 && node < 0 && node != HZ_EMPTY && lq2 == HZ_EMPTY) { lq2 = node; HZ_POP(); }
-        if (QLEN > 3 && node < 0 && node != HZ_EMPTY && lq3 == HZ_EMPTY) { lq3 = node; HZ_POP(); }
         const bool can_node = node >= 0;
         const bool can_leaf = lq0 != HZ_EMPTY;
         // votes taken before any lane leaves: a lane that is finished contributes to neither mask, so the
@@ -379,35 +393,34 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
         if (n_node * 16 >= n_leaf * leaf_bias) {
             // ---------------- node step ------------------------------------------------------
             if (can_node) {
-                float4 n0; uint4 n1, n2; int4 n3;
+                float4 n0, n3; uint4 n1, n2;
                 // NODELET: top-of-tree nodes from LDS, the rest from global memory (two separate asm paths:
                 // a per-lane pointer select would be compiled into slow flat loads).  Measured 2 % slower
                 // than plain global loads -- the top of the tree is L1 resident -- so it is opt-in.
                 if (NODELET && node < ntop) hz_load_node_lds(top + 4 * node, n0, n1, n2, n3);
                 else hz_load_node(nodes + node, n0, n1, n2, n3);
                 if (COUNT) { cnt.nodes++; HZ_WAVE_TICK(cnt.w_nodes, lane); }
-                const NodeRay nr = hz_node_ray(rb, n0.x, n0.y, n0.z, __float_as_uint(n0.w));
-                const bool h0 = hz_qbox_hit(nr, rb, tfar, n1.x, n2.x);
-                const bool h1 = hz_qbox_hit(nr, rb, tfar, n1.y, n2.y);
-                const bool h2 = hz_qbox_hit(nr, rb, tfar, n1.z, n2.z);
-                const bool h3 = hz_qbox_hit(nr, rb, tfar, n1.w, n2.w);
-                // children are visited in slot order.  A front-to-back order (slot r ^ direction signs,
-                // ~45 VALU per step) was measured to be a net loss: these are any-hit rays, a blocked ray
+                const NodeRay nr = hz_node_ray(rb, n0.x, n0.y, n0.z, n3.x, n3.y, n3.z);
+                // children are visited in slot order (tallest first).  A front-to-back order (slot r ^ direction
+                // signs, ~45 VALU per step) was measured to be a net loss: these are any-hit rays, a blocked ray
                 // is blocked over a long stretch behind the first ridge, and near-horizon rays that only
                 // nick a crest are served by the hit cache.
-                // the LDS stack holds `stack_cap` entries, usually fewer than the worst case of 3 per level
-                // (more workgroups per CU).  A node step stores at most 3: if they would not fit, entries are
-                // dropped -- never written out of bounds -- and the launch is flagged; the host repeats it with
-                // the full-depth stack (hz_api.hip).  With stack_cap = 3 * height this never triggers.
-                if (sp > stack_cap - 3) { overflow = 1u; sp = stack_cap - 3; }
-                int next = HZ_EMPTY;
-                // branch-free pushes: the candidate is always stored at the stack top and only kept
-                // (sp advanced) when it was a real link; a node at level L writes at most index 3 L - 1
-                if (h3) next = n3.w;
-                if (h2) { stack[sp * TPB + tid] = next; sp += (next != HZ_EMPTY) ? 1 : 0; next = n3.z; }
-                if (h1) { stack[sp * TPB + tid] = next; sp += (next != HZ_EMPTY) ? 1 : 0; next = n3.y; }
-                if (h0) { stack[sp * TPB + tid] = next; sp += (next != HZ_EMPTY) ? 1 : 0; next = n3.x; }
-                if (next != HZ_EMPTY) node = next; else HZ_POP();
+                int h = hz_qbox_hit(nr, rb, tfar, n1.x, n2.x) ? 1 : 0;
+                h |= hz_qbox_hit(nr, rb, tfar, n1.y, n2.y) ? 2 : 0;
+                h |= hz_qbox_hit(nr, rb, tfar, n1.z, n2.z) ? 4 : 0;
+                h |= hz_qbox_hit(nr, rb, tfar, n1.w, n2.w) ? 8 : 0;
+                if (h != 0) {
+                    const int first = __float_as_int(n0.w);
+                    const int slot = __builtin_ctz((unsigned)h);
+                    const int rest = h & (h - 1);
+                    if (rest != 0) {             // siblings to come back to: one entry for this level
+                        if (pend != 0 && (pend & 15) != 0) { stack[sp * TPB + tid] = pend; sp++; }
+                        pend = hz_entry(first, rest);
+                    }
+                    node = (first < 0) ? first - slot : first + slot;        // ~(~first + slot) == first - slot
+                } else {
+                    HZ_POP();
+                }
             }
         } else {
             // ---------------- leaf step: the two triangles of a DEM quad (or one TIN triangle) ---
@@ -419,7 +432,7 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
                 const bool hit = hz_quad_hit(ox, oy, oz, dx, dy, dz, tfar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
                                              q2.x, q2.y, q2.z, q2.w, q2.y == q2.y);
                 if (hit) res = 1;                       // lq0 stays: the caller reads the blocking leaf
-                else { lq0 = lq1; lq1 = lq2; lq2 = lq3; lq3 = HZ_EMPTY; }
+                else { lq0 = lq1; lq1 = HZ_EMPTY; }
             }
         }
     }
@@ -434,6 +447,7 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
 // with the caller's tfar, so the result does not depend on the visiting order; boxes are pruned
 // conservatively against the best t so far.  Plain per-lane loop (used for a handful of rays
 // per location, not the throughput path).  Returns true and *dist when anything was hit.
+// The stack holds individual child links here: up to 3 per level.
 // ---------------------------------------------------------------------------
 template <int TPB>
 __device__ __forceinline__ bool hz_closest(const Node *__restrict__ nodes, const Prim *__restrict__ prims,
@@ -444,17 +458,20 @@ __device__ __forceinline__ bool hz_closest(const Node *__restrict__ nodes, const
     bool any = false;
     while (node != HZ_EMPTY) {
         if (node >= 0) {
-            float4 n0; uint4 n1, n2; int4 n3;
+            float4 n0, n3; uint4 n1, n2;
             hz_load_node(nodes + node, n0, n1, n2, n3);
             const float tf = any ? __builtin_fminf(tfar, best * 1.0001f) : tfar;
-            const NodeRay nr = hz_node_ray(rb, n0.x, n0.y, n0.z, __float_as_uint(n0.w));
+            const NodeRay nr = hz_node_ray(rb, n0.x, n0.y, n0.z, n3.x, n3.y, n3.z);
             const bool h0 = hz_qbox_hit(nr, rb, tf, n1.x, n2.x), h1 = hz_qbox_hit(nr, rb, tf, n1.y, n2.y);
             const bool h2 = hz_qbox_hit(nr, rb, tf, n1.z, n2.z), h3 = hz_qbox_hit(nr, rb, tf, n1.w, n2.w);
+            const int first = __float_as_int(n0.w);
+            const int c0 = first, c1 = first < 0 ? first - 1 : first + 1, c2 = first < 0 ? first - 2 : first + 2,
+                      c3 = first < 0 ? first - 3 : first + 3;
             int next = HZ_EMPTY;
-            if (h3) next = n3.w;
-            if (h2) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = n3.z; }
-            if (h1) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = n3.y; }
-            if (h0) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = n3.x; }
+            if (h3) next = c3;
+            if (h2) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = c2; }
+            if (h1) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = c1; }
+            if (h0) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = c0; }
             if (next != HZ_EMPTY) { node = next; continue; }
         } else {
             float4 q0, q1, q2;

@@ -43,7 +43,7 @@ struct HorizonParams {
     int row_begin, row_end;
     TileMap tm;                    // tile grid of the slab -> workgroups (XCD aware)
     float dist, hori_fill, ray_org_elev;
-    int top_nodes, regroup, stack_bytes, leaf_bias, stage_bytes, hit_cache, stack_cap;
+    int top_nodes, regroup, stack_bytes, leaf_bias, stage_bytes, hit_cache;
     const unsigned short *near_idx;   // near-field certificates of this launch's rows (hz_near.hip) or null
     const float *near_r;
     int verify_near;
@@ -131,7 +131,6 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
     TravState ts; hz_trav_reset(ts);
     int cache = 0;           // hit cache: subtree above the leaf that blocked this cell's last blocked ray
     bool second = false;     // the cache walk found nothing: the root traversal is still due
-    unsigned overflow = 0;   // a ray needed more stack entries than this launch has (see hz_trace)
     // near-field certificate of this cell (hz_near.hip): rays of azimuth k with a table index >= near_idx[k] clear
     // everything within near_r of the origin and start their box tests at parameter near_r
     unsigned shortened = 0, violations = 0;        // COUNT only
@@ -167,7 +166,7 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
         // ---- traversal (hz_common.h: speculative while-while, one postponed leaf per lane) ------
         if (ray_active) {
             const int r = hz_trace<HZ_TPB, COUNT, HZ_QLEN, NODELET>(p.sv.nodes, p.sv.prims, top, ntop, stack, tid, ox, oy, oz,
-                                                 dx, dy, dz, tfar, rb, ts, p.regroup, p.leaf_bias, tc, p.stack_cap, overflow);
+                                                 dx, dy, dz, tfar, rb, ts, p.regroup, p.leaf_bias, tc);
             if (r == 0 && second) {                      // nothing in the cached subtree: full traversal
                 second = false; hz_trav_reset(ts);
             } else if (COUNT && p.verify_near && r != 2 && tn > 0.0f && !verifying) {
@@ -193,9 +192,7 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
             wn += __shfl_xor(wn, off); wl += __shfl_xor(wl, off); wa += __shfl_xor(wa, off);
         }
     }
-    const bool any_overflow = __ballot(overflow != 0u) != 0ull;
     if (lane == 0) {
-        if (any_overflow) atomicAdd(&p.counters[8], 1ull);
         if (r) atomicAdd(&p.counters[0], r);
         if (g) atomicAdd(&p.counters[1], g);
         if (cc) atomicAdd(&p.counters[4], cc);
@@ -230,17 +227,7 @@ static int launch_alg(const HorizonParams &p, int grid, size_t lds, bool count, 
     return stage ? launch_one<ALG, false, true>(p, grid, lds, st) : launch_one<ALG, false, false>(p, grid, lds, st);
 }
 
-// Measured on MI355X (workgroups of 256 lanes): <= 31 KiB of LDS per workgroup -> 5 resident per CU, <= 40 KiB
-// -> 4 (32 KiB does not give 5).
-int stack_cap_for_level(int height, int other_lds, int override_entries, int level) {
-    const int full = 3 * std::max(height, 1);
-    if (level >= 2) return full;
-    if (override_entries > 0) return level == 0 ? std::min(full, std::max(override_entries, 3)) : full;
-    const int budget = (level == 0 ? 31 : 40) * 1024 - other_lds;
-    return std::min(full, std::max(budget / (HZ_TPB * 4), 3));
-}
-
-int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *cap_is_full) {
+int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
     HorizonParams p;
     p.sv = scene_view(sc);
     p.tb.azim_sin = a.azim_sin; p.tb.azim_cos = a.azim_cos;
@@ -257,16 +244,11 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *c
     const int tiles_i = (rows + 15) / 16;
     p.tm = make_tile_map(tiles_i, (a.dim_in_1 + 15) / 16);
     p.dist = a.dist; p.hori_fill = a.hori_fill; p.ray_org_elev = a.ray_org_elev;
-    // stack: at most 3 pending siblings per 4-wide level -- the worst case.  Rays use far less (<= 20 of 36
-    // entries on the 3601^2 tile), and at 1 KiB per entry and workgroup the worst case caps residency at 4
-    // workgroups per CU (3 for the 14401^2 mosaic).  stack_cap_for_level picks the entries that allow 5
-    // (level 0; the kernel needs 94 VGPRs = 5 waves per SIMD), 4 (level 1) or the worst case (level 2);
-    // the kernel flags rays that would need more and horizon_run repeats the chunk one level up.
-    const int full = 3 * std::max(sc->hdr.height, 1);
+    // stack: one entry per tree level (siblings are contiguous: an entry is a block + the mask of children still to
+    // visit, hz_common.h), so `height` entries can never overflow: 12 KB per workgroup for the 3601^2 tile, 14 KB for
+    // the 14401^2 mosaic -- the kernel's 96 VGPRs (5 workgroups per CU), not LDS, bound the residency
     const int stage = ((a.azim_num & 3) == 0 && (reinterpret_cast<size_t>(a.hori) & 15) == 0) ? 4 * HZ_TPB * 4 : 0;
-    const int depth = stack_cap_for_level(sc->hdr.height, stage, a.stack_entries, a.stack_level);
-    if (cap_is_full) *cap_is_full = (depth >= full) ? 1 : 0;
-    p.stack_cap = depth;
+    const int depth = std::max(sc->hdr.height, 1);
     p.stack_bytes = depth * HZ_TPB * 4;
     // output staging (4 azimuths per lane) when the 16 B stores are aligned: azim_num % 4 == 0
     p.stage_bytes = stage;

@@ -10,7 +10,7 @@
 #include <atomic>
 
 #define HZ_MAX_TOP_NODES 2047   // upper bound of BFS-ordered top nodes (LDS staging)
-#define HZ_MAX_STACK 96         // LDS stack entries per lane the traversal kernels accept (3 per 4-wide level)
+#define HZ_MAX_STACK 40         // tree levels (= LDS stack entries per lane) the traversal kernels accept
 // hit cache: levels between a leaf and its cached ancestor (measured 1..9 on the 3601^2 tile: 5-6 best)
 #ifndef HZ_ANC_LEVELS
 #define HZ_ANC_LEVELS 5
@@ -42,9 +42,6 @@ struct Scene {
     void *blob = nullptr;
     size_t blob_bytes = 0;
     bool owns_blob = false;
-    // residency level of the LDS traversal stack that has worked for this scene so far (hz_api.hip);
-    // mutable: kernels that hit the limit bump it through a const Scene
-    mutable std::atomic<int> stack_level{0};
     // scratch of the near-field certificates, grown on demand and kept with the scene (hz_api.hip); a scene is
     // used by one call at a time per stream, like its stream
     mutable void *near_buf = nullptr;
@@ -114,18 +111,14 @@ struct HorizonArgs {
     const float *azim_sin, *azim_cos, *elev_ang, *elev_sin, *elev_cos;  // device tables
     const int *mid_idx;
     int top_nodes, regroup, count_work, hit_cache;
-    int stack_entries, stack_level;      // LDS stack entries per lane (0 = auto) and residency level 0 / 1 / 2
     const unsigned short *near_idx;      // near-field certificates of rows [row_begin, row_end) (hz_near.hip) or null
     const float *near_r;
     int verify_near;                     // counting instantiation: re-trace every shortened ray from parameter 0
     unsigned long long *counters;        // device u64[16]: [0] rays, [1] guards, [2] nodes, [3] tris, [4] cells,
-                                         // [5..7] wave iterations, [8] waves with a stack overflow,
+                                         // [5..7] wave iterations,
                                          // [9] rays shortened by a certificate, [10] certificate violations (verify)
 };
-int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *cap_is_full = nullptr);
-// entries per lane of the LDS traversal stack for residency level 0 / 1 / 2 (5 / 4 workgroups per CU /
-// worst case 3 per tree level); `other_lds` = bytes of LDS the kernel uses besides the stack
-int stack_cap_for_level(int height, int other_lds, int override_entries, int level);
+int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st);
 int topo_launch(int kind, const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
                 int len_2, float *out, hipStream_t st);
 int svf_launch(const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
@@ -167,10 +160,9 @@ struct ShadowArgs {
     int which;                           // 0 shadow (u8), 1 sw_dir_cor (f32)
     uint8_t *out_u8; float *out_f32;
     int top_nodes;
-    int stack_entries, stack_level;      // as in HorizonArgs
-    unsigned long long *counters;        // device u64[16]: [0] rays, [8] waves with a stack overflow
+    unsigned long long *counters;        // device u64[16]: [0] rays
 };
-int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st, int *cap_is_full = nullptr);
+int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st);
 
 // hz_sort.hip: hand-written stable LSD radix sort (pairs) and exclusive scan, uint32
 size_t sort_temp_elems(size_t n);

@@ -12,11 +12,11 @@
 //   5. k_leaf_boxes / k_refit_pass  leaf AABBs; bottom-up union, level synchronous with work lists
 //   6. k_roots/scan  collapse along the 2-bit Morton digits: a binary node starts a 4-wide
 //                    node when its common-prefix length enters a new digit (quadtree level)
-//   7. k_emit4       64 B nodes with conservatively quantised child AABBs (8 bit x/y, 16 bit z),
+//   7. k_emit4       temp 4-wide nodes with conservatively quantised child AABBs (8 bit x/y, 16 bit z),
 //                    children sorted tallest first
-//   8. k_top/k_permute  breadth-first relabel of the top of the tree (hot levels contiguous)
-//      k_parents4/k_ancestors  per leaf the node HZ_ANC_LEVELS above it (hit cache)
-//   9. k_emit_prims  48 B leaf records in Morton order
+//   8. k_bfs_*       breadth-first numbering of ALL nodes, level by level, with the children of every node in one
+//                    contiguous block of 4 slots (nodes or 48 B leaf records); emits the final nodes and leaves
+//      k_anc_bfs     per leaf the node HZ_ANC_LEVELS above it (hit cache)
 #include <cstring>
 #include <cstdlib>
 #include "hz_internal.h"
@@ -236,6 +236,15 @@ __global__ __launch_bounds__(256) void k_roots(int n_nodes, const int *__restric
     flag[i] = (par < 0 || (plen[par] >> 1) != (plen[i] >> 1)) ? 1u : 0u;
 }
 
+// 4-wide node as k_emit4 produces it (children addressed by individual links, numbered in compaction order);
+// the breadth-first pass below turns these into the final `Node`s with contiguous children
+struct NodeTmp {
+    float org[3];
+    uint32_t scale;      // biased float exponents of the x | y<<8 | z<<16 quantisation steps
+    uint32_t qxy[4], qz[4];
+    int32_t link[4];     // >= 0 temp node, < 0 leaf (~sorted position), HZ_EMPTY none
+};
+
 struct Emit4 {
     const int2 *child; const uint8_t *plen; const int *first;
     const uint32_t *keys; const uint32_t *flag; const uint32_t *idx;
@@ -270,7 +279,7 @@ __device__ __forceinline__ uint32_t step_exponent(float extent, float qmax) {
     return (uint32_t)biased;
 }
 
-__global__ __launch_bounds__(256) void k_emit4(Emit4 e, Node *__restrict__ nodes) {
+__global__ __launch_bounds__(256) void k_emit4(Emit4 e, NodeTmp *__restrict__ nodes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= e.n_nodes || !e.flag[i]) return;
     const int dg = e.plen[i] >> 1;
@@ -329,7 +338,7 @@ __global__ __launch_bounds__(256) void k_emit4(Emit4 e, Node *__restrict__ nodes
     const uint32_t ex = step_exponent(ext[0], 255.0f), ey = step_exponent(ext[1], 255.0f);
     const uint32_t ez = step_exponent(ext[2], 65535.0f);
     const float sx = __uint_as_float(ex << 23), sy = __uint_as_float(ey << 23), sz = __uint_as_float(ez << 23);
-    Node n;
+    NodeTmp n;
     n.org[0] = org[0]; n.org[1] = org[1]; n.org[2] = org[2];
     n.scale = ex | (ey << 8) | (ez << 16);
 #pragma unroll
@@ -345,92 +354,142 @@ __global__ __launch_bounds__(256) void k_emit4(Emit4 e, Node *__restrict__ nodes
     nodes[e.idx[i]] = n;
 }
 
-// --- breadth-first relabel of the top of the tree -----------------------------------------
-// perm[old] = new.  Single lane: n_top <= a few thousand nodes.
-__global__ void k_top(const Node *__restrict__ nodes, int n_nodes, int n_top,
-                      int *__restrict__ perm, int *__restrict__ top, uint8_t *__restrict__ in_top) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int head = 0, tail = 0;
-    top[tail++] = 0;
-    while (head < tail && tail < n_top) {
-        const Node &nd = nodes[top[head++]];
-        for (int k = 0; k < 4; k++)
-            if (nd.link[k] >= 0 && tail < n_top) top[tail++] = nd.link[k];
-    }
-    const int k = tail;
-    for (int r = 0; r < k; r++) if (top[r] < k) in_top[top[r]] = 1;
-    for (int r = 0; r < k; r++) perm[top[r]] = r;
-    int x = 0;
-    for (int r = 0; r < k; r++) {
-        if (top[r] >= k) {
-            while (in_top[x]) x++;
-            perm[x++] = top[r];
-        }
-    }
-    (void)n_nodes;
-}
-
-__global__ __launch_bounds__(256) void k_iota(int *__restrict__ perm, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) perm[i] = i;
-}
-
-__global__ __launch_bounds__(256) void k_permute(int n_nodes, const int *__restrict__ perm,
-                                                const Node *__restrict__ src, Node *__restrict__ dst) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_nodes) return;
-    Node n = src[i];
+// --- breadth-first numbering with contiguous children ---------------------------------------------
+// The temp nodes are renumbered level by level.  A frontier holds, for every node slot of a level, what sits
+// there: >= 0 a temp node, <= -2 a single leaf that needs a wrapper node (sorted position -2 - v), -1 nothing.
+// Every entry asks for one block of 4 child slots: a NODE block when the temp node has internal children (its
+// leaf children are then wrapped: they go to the next frontier as <= -2 entries), else a LEAF block.  Blocks are
+// handed out by an exclusive scan over the frontier, so children are contiguous, siblings keep their slot order
+// (tallest first) and the numbering is breadth first.
+__device__ __forceinline__ void bfs_kinds(const NodeTmp &t, int &n_int, int &n_leaf) {
+    n_int = 0; n_leaf = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) if (n.link[k] >= 0) n.link[k] = perm[n.link[k]];
-    dst[perm[i]] = n;
+    for (int k = 0; k < 4; k++) {
+        if (t.link[k] >= 0) n_int++;
+        else if (t.link[k] != HZ_EMPTY) n_leaf++;
+    }
 }
 
-__global__ __launch_bounds__(256) void k_emit_prims(BuildParams b, const uint32_t *__restrict__ vals,
-                                                   Prim *__restrict__ prims) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= b.n_prims) return;
+// exact sizes of the final arrays: node blocks = temp nodes with an internal child (+ the root's own block),
+// leaf blocks = temp nodes without one + one per wrapped leaf
+__global__ __launch_bounds__(256) void k_bfs_sizes(int n4, const NodeTmp *__restrict__ tmp, unsigned int *__restrict__ sizes) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned nb = 0, lb = 0;
+    if (i < n4) {
+        int ni, nl;
+        bfs_kinds(tmp[i], ni, nl);
+        if (ni > 0) { nb = 1; lb = (unsigned)nl; } else lb = 1;
+    }
+    for (int off = 32; off > 0; off >>= 1) { nb += __shfl_xor(nb, off); lb += __shfl_xor(lb, off); }
+    if ((threadIdx.x & 63) == 0) { if (nb) atomicAdd(&sizes[0], nb); if (lb) atomicAdd(&sizes[1], lb); }
+}
+
+__global__ __launch_bounds__(256) void k_bfs_need(int cnt, const int *__restrict__ frontier, const NodeTmp *__restrict__ tmp,
+                                                 uint32_t *__restrict__ need_node, uint32_t *__restrict__ need_leaf) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= cnt) return;
+    const int v = frontier[pos];
+    uint32_t nn = 0, nl = 0;
+    if (v >= 0) { int ni, nlf; bfs_kinds(tmp[v], ni, nlf); if (ni > 0) nn = 1; else nl = 1; }
+    else if (v <= -2) nl = 1;
+    need_node[pos] = nn; need_leaf[pos] = nl;
+}
+
+struct BfsEmit {
+    const int *frontier; int cnt, level_start;         // node slots [level_start, level_start + cnt)
+    const NodeTmp *tmp;
+    const uint32_t *scan_node, *scan_leaf;             // exclusive scans of the needs over this frontier
+    int node_blocks_before, leaf_blocks_before;        // blocks handed out on the levels above
+    int *next_frontier;                                // 4 entries per node block of this level
+    Node *nodes; Prim *prims; int *parent; int *leaf_parent;   // parent[node slot], leaf_parent[leaf block]
+    const uint32_t *vals;                              // sorted position -> primitive id
+};
+
+__device__ __forceinline__ void write_prim(const BuildParams &b, const uint32_t *__restrict__ vals, int sorted_pos, Prim *dst) {
     float a[3], bb[3], c[3], d[3];
-    const bool quad = prim_vertices(b, (int)vals[s], a, bb, c, d);
+    const bool quad = prim_vertices(b, (int)vals[sorted_pos], a, bb, c, d);
     Prim p;
 #pragma unroll
     for (int k = 0; k < 3; k++) { p.a[k] = a[k]; p.b[k] = bb[k]; p.c[k] = c[k]; p.d[k] = d[k]; }
     if (!quad) p.d[0] = __int_as_float(0x7fc00000);   // NaN: TIN triangle, single test
-    prims[s] = p;
+    *dst = p;
 }
 
-// --- hit-cache ancestors: for every leaf the node `levels` levels above it --------------------------
-__global__ __launch_bounds__(256) void k_parents4(int n4, const Node *__restrict__ nodes, int *__restrict__ parent4,
-                                                 int *__restrict__ leaf_parent) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    if (i == 0) parent4[0] = -1;
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int l = nodes[i].link[k];
-        if (l >= 0) parent4[l] = i;
-        else if (l != HZ_EMPTY) leaf_parent[~l] = i;
+__global__ __launch_bounds__(256) void k_bfs_emit(BfsEmit e, BuildParams b) {
+    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= e.cnt) return;
+    const int v = e.frontier[pos];
+    if (v == -1) return;                                  // unused slot of a block (zero-filled, never referenced)
+    const int self = e.level_start + pos;
+    if (v <= -2) {                                        // wrapper node (header written by its parent): its one leaf
+        const int lb = e.leaf_blocks_before + (int)e.scan_leaf[pos];
+        e.nodes[self].first = ~(4 * lb);
+        write_prim(b, e.vals, -2 - v, &e.prims[(size_t)4 * lb]);
+        e.leaf_parent[lb] = self;
+        return;
     }
+    const NodeTmp t = e.tmp[v];
+    int ni, nl;
+    bfs_kinds(t, ni, nl);
+    Node n;
+    n.org[0] = t.org[0]; n.org[1] = t.org[1]; n.org[2] = t.org[2];
+    n.step[0] = __uint_as_float((t.scale & 0xffu) << 23);
+    n.step[1] = __uint_as_float(((t.scale >> 8) & 0xffu) << 23);
+    n.step[2] = __uint_as_float(((t.scale >> 16) & 0xffu) << 23);
+    n.valid = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) { n.qxy[k] = t.qxy[k]; n.qz[k] = t.qz[k]; if (t.link[k] != HZ_EMPTY) n.valid |= 1u << k; }
+    if (ni == 0) {                                        // all children are leaves: one leaf block
+        const int lb = e.leaf_blocks_before + (int)e.scan_leaf[pos];
+        n.first = ~(4 * lb);
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (t.link[k] != HZ_EMPTY) write_prim(b, e.vals, ~t.link[k], &e.prims[(size_t)4 * lb + k]);
+        e.leaf_parent[lb] = self;
+    } else {                                              // a node block; leaf children get wrapper nodes
+        const int rel = (int)e.scan_node[pos];
+        const int first = 4 * (e.node_blocks_before + rel);
+        n.first = first;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int f = -1;
+            if (t.link[k] >= 0) f = t.link[k];
+            else if (t.link[k] != HZ_EMPTY) {
+                f = -2 - (~t.link[k]);
+                Node w;                                    // single-child node: this slot's box in this node's frame
+                w.org[0] = n.org[0]; w.org[1] = n.org[1]; w.org[2] = n.org[2];
+                w.step[0] = n.step[0]; w.step[1] = n.step[1]; w.step[2] = n.step[2];
+                w.first = 0; w.valid = 1u;
+                for (int q = 0; q < 4; q++) { w.qxy[q] = 0x00ff00ffu; w.qz[q] = 0x0000ffffu; }
+                w.qxy[0] = t.qxy[k]; w.qz[0] = t.qz[k];
+                e.nodes[first + k] = w;
+            }
+            e.next_frontier[4 * rel + k] = f;
+            if (f != -1) e.parent[first + k] = self;
+        }
+    }
+    e.nodes[self] = n;
 }
 
-__global__ __launch_bounds__(256) void k_ancestors(int n_prims, int levels, const int *__restrict__ parent4,
-                                                  const int *__restrict__ leaf_parent, int *__restrict__ anc) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_prims) return;
-    int n = leaf_parent[s];
+// hit-cache ancestors: for every leaf slot the node `levels` levels above it (the leaf block's parent counts as 1)
+__global__ __launch_bounds__(256) void k_anc_bfs(int n_leaf_blocks, int levels, const int *__restrict__ parent,
+                                                const int *__restrict__ leaf_parent, int *__restrict__ anc) {
+    const int lb = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lb >= n_leaf_blocks) return;
+    int n = leaf_parent[lb];
     for (int r = 1; r < levels; r++) {
-        const int p = parent4[n];
+        const int p = parent[n];
         if (p < 0) break;
         n = p;
     }
-    anc[s] = n;
+    reinterpret_cast<int4 *>(anc)[lb] = make_int4(n, n, n, n);
 }
 
-// single primitive: a root whose slot 0 is the leaf, quantised against its own box
-__global__ void k_single_node(const float4 *leaf_lo, const float4 *leaf_hi, Node *nodes) {
+// single primitive: a temp root whose slot 0 is the leaf, quantised against its own box
+__global__ void k_single_tmp(const float4 *leaf_lo, const float4 *leaf_hi, NodeTmp *nodes) {
     const float4 l = leaf_lo[0], h = leaf_hi[0];
     const uint32_t ex = step_exponent(h.x - l.x, 255.0f), ey = step_exponent(h.y - l.y, 255.0f);
     const uint32_t ez = step_exponent(h.z - l.z, 65535.0f);
-    Node n;
+    NodeTmp n;
     n.org[0] = l.x; n.org[1] = l.y; n.org[2] = l.z;
     n.scale = ex | (ey << 8) | (ez << 16);
     for (int k = 0; k < 4; k++) { n.link[k] = HZ_EMPTY; n.qxy[k] = 0x00ff00ffu; n.qz[k] = 0x0000ffffu; }
@@ -492,7 +551,7 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     hipStream_t st = sc->stream;
 
     // ---- one arena for all temporaries whose size is known up front ------------------------
-    Arena arena1, arena2;
+    Arena arena1, arena2, arena3;
     {
         const size_t P = (size_t)n_prims, B = (size_t)n_bin;
         const size_t list_cap0 = B / 2 + 2;
@@ -652,14 +711,47 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
         n4 = (int)(last_idx + last_flag);
     }
 
+    // ---- 7. 4-wide temp nodes (compaction order, individual child links) -------------------------------------
+    TempBuf b_tmp4, b_sizes;
+    g_arena = nullptr;                                   // what follows is sized by n4: own allocations / arena2
+    HZ_HIP(arena2.reserve(Arena::pad((size_t)n4 * sizeof(NodeTmp)) + 64 * 4096));
+    g_arena = &arena2;
+    HZ_HIP(b_tmp4.alloc((size_t)n4 * sizeof(NodeTmp)));
+    if (n_prims > 1) {
+        Emit4 e;
+        e.child = (const int2 *)b_child.p; e.plen = (const uint8_t *)b_plen.p; e.first = (const int *)b_first.p;
+        e.keys = keys; e.flag = (const uint32_t *)b_flag.p; e.idx = (const uint32_t *)b_idx.p;
+        e.leaf_lo = (const float4 *)b_llo.p; e.leaf_hi = (const float4 *)b_lhi.p;
+        e.node_lo = (const float4 *)b_nlo.p; e.node_hi = (const float4 *)b_nhi.p;
+        e.n_nodes = n_bin;
+        hipLaunchKernelGGL(k_emit4, dim3(gn), dim3(256), 0, st, e, (NodeTmp *)b_tmp4.p);
+    } else {
+        hipLaunchKernelGGL(k_single_tmp, dim3(1), dim3(1), 0, st, (const float4 *)b_llo.p, (const float4 *)b_lhi.p,
+                           (NodeTmp *)b_tmp4.p);
+    }
+    // exact sizes of the final arrays
+    HZ_HIP(b_sizes.alloc(16));
+    HZ_HIP(hipMemsetAsync(b_sizes.p, 0, 16, st));
+    hipLaunchKernelGGL(k_bfs_sizes, dim3((n4 + 255) / 256), dim3(256), 0, st, n4, (const NodeTmp *)b_tmp4.p,
+                       (unsigned int *)b_sizes.p);
+    unsigned int sizes[2] = {0, 0};
+    HZ_HIP(hipMemcpyAsync(sizes, b_sizes.p, 8, hipMemcpyDeviceToHost, st));
+    HZ_HIP(hipStreamSynchronize(st));
+    const size_t n_node_blocks = (size_t)sizes[0] + 1;                 // + the root's own block
+    const size_t n_leaf_blocks = sizes[1];
+    const size_t n_nodes = 4 * n_node_blocks, n_prim_slots = 4 * n_leaf_blocks;
+    if (n_nodes > 0x7ffffff0u / 4 || n_prim_slots > 0x1ffffff0u)
+        return set_error(HZ_ERR_DEPTH, "scene too large for the 32-bit traversal links");
+
     // ---- blob allocation (exact size now known) ------------------------------------------------
-    h.n_nodes = n4;
+    h.n_nodes = (int32_t)n_nodes;
+    h.n_prim_slots = (int32_t)n_prim_slots;
     h.off_verts = sizeof(BlobHeader);
     h.off_nodes = align_up(h.off_verts + nvert * 12, 256);
-    h.off_prims = align_up(h.off_nodes + (size_t)n4 * sizeof(Node), 256);
-    h.off_anc = align_up(h.off_prims + (size_t)n_prims * sizeof(Prim), 256);
+    h.off_prims = align_up(h.off_nodes + n_nodes * sizeof(Node), 256);
+    h.off_anc = align_up(h.off_prims + n_prim_slots * sizeof(Prim), 256);
     h.anc_levels = HZ_ANC_LEVELS;
-    h.total_bytes = align_up(h.off_anc + (size_t)n_prims * 4, 256);
+    h.total_bytes = align_up(h.off_anc + n_prim_slots * 4, 256);
     HZ_HIP(hipMalloc(&sc->blob, h.total_bytes));
     sc->owns_blob = true;
     sc->blob_bytes = h.total_bytes;
@@ -669,65 +761,73 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     Prim *d_prims = (Prim *)(blob + h.off_prims);
     int *d_anc = (int *)(blob + h.off_anc);
     HZ_HIP(hipMemcpyAsync(d_verts, d_verts_src, nvert * 12, hipMemcpyDeviceToDevice, st));
+    // unused slots of partly filled blocks stay zero (never referenced: their boxes cannot be hit)
+    HZ_HIP(hipMemsetAsync(blob + h.off_nodes, 0, h.total_bytes - h.off_nodes, st));
 
-    // ---- 7./8. emit 4-wide nodes, relabel the top breadth first ----------------------------------
-    int n_top = 1;
-    TempBuf b_tmp4, b_perm, b_top, b_intop;
-    if (n_prims > 1) {
-        HZ_HIP(arena2.reserve(Arena::pad((size_t)n4 * sizeof(Node)) + 2 * Arena::pad((size_t)n4 * 4) + 4 * 4096 +
-                              Arena::pad((size_t)HZ_MAX_TOP_NODES * 8) + Arena::pad((size_t)n_prims * 4)));
-        g_arena = &arena2;
-        HZ_HIP(b_tmp4.alloc((size_t)n4 * sizeof(Node)));
-        Emit4 e;
-        e.child = (const int2 *)b_child.p; e.plen = (const uint8_t *)b_plen.p; e.first = (const int *)b_first.p;
-        e.keys = keys; e.flag = (const uint32_t *)b_flag.p; e.idx = (const uint32_t *)b_idx.p;
-        e.leaf_lo = (const float4 *)b_llo.p; e.leaf_hi = (const float4 *)b_lhi.p;
-        e.node_lo = (const float4 *)b_nlo.p; e.node_hi = (const float4 *)b_nhi.p;
-        e.n_nodes = n_bin;
-        hipLaunchKernelGGL(k_emit4, dim3(gn), dim3(256), 0, st, e, (Node *)b_tmp4.p);
-        n_top = std::min(n4, HZ_MAX_TOP_NODES);
-        HZ_HIP(b_perm.alloc((size_t)n4 * 4));
-        HZ_HIP(b_top.alloc((size_t)n_top * 4));
-        HZ_HIP(b_intop.alloc((size_t)n_top));
-        HZ_HIP(hipMemsetAsync(b_intop.p, 0, (size_t)n_top, st));
-        const int g4 = (n4 + 255) / 256;
-        hipLaunchKernelGGL(k_iota, dim3(g4), dim3(256), 0, st, (int *)b_perm.p, n4);
-        hipLaunchKernelGGL(k_top, dim3(1), dim3(64), 0, st, (const Node *)b_tmp4.p, n4, n_top,
-                           (int *)b_perm.p, (int *)b_top.p, (uint8_t *)b_intop.p);
-        hipLaunchKernelGGL(k_permute, dim3(g4), dim3(256), 0, st, n4, (const int *)b_perm.p,
-                           (const Node *)b_tmp4.p, d_nodes);
-    } else {
-        hipLaunchKernelGGL(k_single_node, dim3(1), dim3(1), 0, st, (const float4 *)b_llo.p,
-                           (const float4 *)b_lhi.p, d_nodes);
+    // ---- 8. breadth-first numbering, level by level ---------------------------------------------------------
+    TempBuf b_fr0, b_fr1, b_need_n, b_need_l, b_scan_n, b_scan_l, b_scan_tmp, b_parent, b_lparent;
+    HZ_HIP(arena3.reserve(7 * Arena::pad(n_nodes * 4) + Arena::pad(scan_temp_elems(n_nodes) * 4 + 16) +
+                          Arena::pad((n_leaf_blocks ? n_leaf_blocks : 1) * 4) + 4096));
+    g_arena = &arena3;
+    HZ_HIP(b_fr0.alloc(n_nodes * 4)); HZ_HIP(b_fr1.alloc(n_nodes * 4));
+    HZ_HIP(b_need_n.alloc(n_nodes * 4)); HZ_HIP(b_need_l.alloc(n_nodes * 4));
+    HZ_HIP(b_scan_n.alloc(n_nodes * 4)); HZ_HIP(b_scan_l.alloc(n_nodes * 4));
+    HZ_HIP(b_scan_tmp.alloc(scan_temp_elems(n_nodes) * 4 + 16));
+    HZ_HIP(b_parent.alloc(n_nodes * 4)); HZ_HIP(b_lparent.alloc((n_leaf_blocks ? n_leaf_blocks : 1) * 4));
+    HZ_HIP(hipMemsetAsync(b_parent.p, 0xff, n_nodes * 4, st));       // -1: the root has no parent
+    int *fr[2] = {(int *)b_fr0.p, (int *)b_fr1.p};
+    {
+        const int first_frontier[4] = {0, -1, -1, -1};                 // block 0: the root and three unused slots
+        HZ_HIP(hipMemcpyAsync(fr[0], first_frontier, sizeof(first_frontier), hipMemcpyHostToDevice, st));
     }
-    // ---- hit-cache ancestors (from the final node numbering) ---------------------------------------
-    if (n_prims > 1) {
-        TempBuf b_par4, b_lpar;
-        HZ_HIP(b_par4.alloc((size_t)n4 * 4));
-        HZ_HIP(b_lpar.alloc((size_t)n_prims * 4));
-        hipLaunchKernelGGL(k_parents4, dim3((n4 + 255) / 256), dim3(256), 0, st, n4, (const Node *)d_nodes,
-                           (int *)b_par4.p, (int *)b_lpar.p);
-        hipLaunchKernelGGL(k_ancestors, dim3(gp), dim3(256), 0, st, n_prims, std::max(1, h.anc_levels),
-                           (const int *)b_par4.p, (const int *)b_lpar.p, d_anc);
-        HZ_HIP(hipStreamSynchronize(st));      // b_par4 / b_lpar leave scope (arena memory stays valid anyway)
-    } else {
-        HZ_HIP(hipMemsetAsync(d_anc, 0, 4, st));
+    int cur = 0, cnt = 4, level_start = 0, levels = 0;
+    size_t node_blocks_done = 1, leaf_blocks_done = 0;
+    while (cnt > 0) {
+        levels++;
+        if (levels > HZ_MAX_STACK) return set_error(HZ_ERR_DEPTH, "BVH deeper than %d levels", HZ_MAX_STACK);
+        const int g = (cnt + 255) / 256;
+        hipLaunchKernelGGL(k_bfs_need, dim3(g), dim3(256), 0, st, cnt, (const int *)fr[cur], (const NodeTmp *)b_tmp4.p,
+                           (uint32_t *)b_need_n.p, (uint32_t *)b_need_l.p);
+        int rc = exclusive_scan_u32((const uint32_t *)b_need_n.p, (uint32_t *)b_scan_n.p, (size_t)cnt, (uint32_t *)b_scan_tmp.p, st);
+        if (rc) return rc;
+        rc = exclusive_scan_u32((const uint32_t *)b_need_l.p, (uint32_t *)b_scan_l.p, (size_t)cnt, (uint32_t *)b_scan_tmp.p, st);
+        if (rc) return rc;
+        uint32_t last[4] = {0, 0, 0, 0};                               // scan and need of the last entry, both kinds
+        HZ_HIP(hipMemcpyAsync(&last[0], (uint32_t *)b_scan_n.p + (cnt - 1), 4, hipMemcpyDeviceToHost, st));
+        HZ_HIP(hipMemcpyAsync(&last[1], (uint32_t *)b_need_n.p + (cnt - 1), 4, hipMemcpyDeviceToHost, st));
+        HZ_HIP(hipMemcpyAsync(&last[2], (uint32_t *)b_scan_l.p + (cnt - 1), 4, hipMemcpyDeviceToHost, st));
+        HZ_HIP(hipMemcpyAsync(&last[3], (uint32_t *)b_need_l.p + (cnt - 1), 4, hipMemcpyDeviceToHost, st));
+        HZ_HIP(hipStreamSynchronize(st));
+        const size_t nb = (size_t)last[0] + last[1], lb = (size_t)last[2] + last[3];
+        if (node_blocks_done + nb > n_node_blocks || leaf_blocks_done + lb > n_leaf_blocks)
+            return set_error(HZ_ERR_HIP, "BVH numbering ran past its arrays (internal error)");
+        BfsEmit e;
+        e.frontier = fr[cur]; e.cnt = cnt; e.level_start = level_start;
+        e.tmp = (const NodeTmp *)b_tmp4.p;
+        e.scan_node = (const uint32_t *)b_scan_n.p; e.scan_leaf = (const uint32_t *)b_scan_l.p;
+        e.node_blocks_before = (int)node_blocks_done; e.leaf_blocks_before = (int)leaf_blocks_done;
+        e.next_frontier = fr[cur ^ 1];
+        e.nodes = d_nodes; e.prims = d_prims; e.parent = (int *)b_parent.p; e.leaf_parent = (int *)b_lparent.p;
+        e.vals = vals;
+        hipLaunchKernelGGL(k_bfs_emit, dim3(g), dim3(256), 0, st, e, bp);
+        level_start = (int)(4 * node_blocks_done);
+        node_blocks_done += nb; leaf_blocks_done += lb;
+        cnt = (int)(4 * nb);
+        cur ^= 1;
     }
-    // ---- 9. leaf records ------------------------------------------------------------------------
-    hipLaunchKernelGGL(k_emit_prims, dim3(gp), dim3(256), 0, st, bp, vals, d_prims);
-    // height in 4-wide levels = 1 + levels below the root's digit group (stored with the root box)
-    float4 root_lo = make_float4(0, 0, 0, 0);
-    if (n_prims > 1) HZ_HIP(hipMemcpyAsync(&root_lo, b_nlo.p, 16, hipMemcpyDeviceToHost, st));
+    if (node_blocks_done != n_node_blocks || leaf_blocks_done != n_leaf_blocks)
+        return set_error(HZ_ERR_HIP, "BVH numbering did not fill its arrays (internal error)");
+    // ---- hit-cache ancestors (from the final numbering) ------------------------------------------------------
+    if (n_leaf_blocks)
+        hipLaunchKernelGGL(k_anc_bfs, dim3((unsigned)((n_leaf_blocks + 255) / 256)), dim3(256), 0, st, (int)n_leaf_blocks,
+                           std::max(1, h.anc_levels), (const int *)b_parent.p, (const int *)b_lparent.p, d_anc);
     HZ_HIP(hipStreamSynchronize(st));
     HZ_HIP(hipGetLastError());
-    int below = 0;
-    if (n_prims > 1) memcpy(&below, &root_lo.w, 4);
-    const int height = below + 1;
+    // height = node levels of the numbering (wrapper levels included): the traversal stack holds one entry per level
+    const int height = levels;
+    const int n_top = (int)std::min<size_t>(n_nodes, HZ_MAX_TOP_NODES);
     h.height = height;
     h.n_top = n_top;
-    if (3 * height > HZ_MAX_STACK)
-        return set_error(HZ_ERR_DEPTH, "BVH height %d (4-wide levels) exceeds the traversal stack (%d entries)",
-                         height, HZ_MAX_STACK);
     HZ_HIP(hipMemcpyAsync(blob, &h, sizeof(h), hipMemcpyHostToDevice, st));
     HZ_HIP(hipStreamSynchronize(st));
     sc->hdr = h;

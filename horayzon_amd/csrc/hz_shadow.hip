@@ -25,7 +25,7 @@ struct ShadowParams {
     float fill, dot_prod_min;
     int refrac, which;
     uint8_t *out_u8; float *out_f32;
-    int top_nodes, stack_bytes, stack_cap;
+    int top_nodes, stack_bytes;
     unsigned long long *counters;
 };
 
@@ -60,12 +60,12 @@ __device__ __forceinline__ float atmos_refrac(float elev_ang_true, float temp, f
 // any-hit traversal to completion (regroup = 0: never suspends; no LDS nodelet: top = null)
 __device__ __forceinline__ bool occluded(const SceneView &sv, int *stack, int tid,
                                          float ox, float oy, float oz, float dx, float dy, float dz,
-                                         float tfar, int stack_cap, unsigned &overflow) {
+                                         float tfar) {
     const RayBox rb = hz_raybox(ox - sv.cx, oy - sv.cy, oz - sv.cz, dx, dy, dz);
     TravState ts; hz_trav_reset(ts);
     TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.w_nodes = 0; tc.w_leaves = 0;
     return hz_trace<HZ_TPB, false>(sv.nodes, sv.prims, nullptr, 0, stack, tid, ox, oy, oz, dx, dy, dz, tfar, rb,
-                                   ts, 0, HZ_SHADOW_LEAF_BIAS, tc, stack_cap, overflow) == 1;
+                                   ts, 0, HZ_SHADOW_LEAF_BIAS, tc) == 1;
 }
 
 __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
     const int j = tj * 16 + (wave & 1) * 8 + (lane & 7);
     const bool in_dom = has_tile && (i < p.dim_in_0) && (j < p.dim_in_1);
     const size_t cell = in_dom ? ((size_t)i * p.dim_in_1 + j) : 0;
-    unsigned rays = 0, overflow = 0;
+    unsigned rays = 0;
     if (in_dom) {
         if (p.mask[cell] != 1) {                                   // shadow_comp.cpp:480-484 / :594-598
             if (p.which == 0) p.out_u8[cell] = 3; else p.out_f32[cell] = p.fill;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
             if (p.which == 0) {                                    // :451-478
                 if (dot_prod_ts > 0.0f) {
                     rays = 1;
-                    const bool h = occluded(p.sv, stack, tid, ox, oy, oz, sun_x, sun_y, sun_z, inf, p.stack_cap, overflow);
+                    const bool h = occluded(p.sv, stack, tid, ox, oy, oz, sun_x, sun_y, sun_z, inf);
                     p.out_u8[cell] = h ? 2 : 0;
                 } else {
                     p.out_u8[cell] = 1;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
             } else {                                               // :561-592
                 if (dot_prod_ts > p.dot_prod_min) {
                     rays = 1;
-                    const bool h = occluded(p.sv, stack, tid, ox, oy, oz, sun_x, sun_y, sun_z, inf, p.stack_cap, overflow);
+                    const bool h = occluded(p.sv, stack, tid, ox, oy, oz, sun_x, sun_y, sun_z, inf);
                     if (h) p.out_f32[cell] = 0.0f;
                     else {
                         if (dot_prod_ns < p.dot_prod_min) dot_prod_ns = p.dot_prod_min;
@@ -143,10 +143,9 @@ __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
     unsigned long long r = rays;
     for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off);
     if (lane == 0 && r) atomicAdd(&p.counters[0], r);
-    if (__ballot(overflow != 0u) != 0ull && lane == 0) atomicAdd(&p.counters[8], 1ull);   // see hz_trace: stack_cap
 }
 
-int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st, int *cap_is_full) {
+int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st) {
     ShadowParams p;
     p.sv = scene_view(sc);
     p.vec_tilt = a.vec_tilt; p.vec_norm = a.vec_norm; p.surf_enl_fac = a.surf_enl_fac; p.elevation = a.elevation;
@@ -159,15 +158,9 @@ int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st, int *cap
     p.fill = a.sw_dir_cor_fill; p.dot_prod_min = a.dot_prod_min;
     p.refrac = a.refrac_cor; p.which = a.which;
     p.out_u8 = a.out_u8; p.out_f32 = a.out_f32;
-    // LDS stack: worst case 3 entries per level.  Level 0: 26 entries = 6 workgroups per CU (the kernel needs 59
-    // VGPRs; 22 entries = 7 workgroups gains 2 % more but sits too close to the 20 entries rays on the
-    // 3601^2 tile actually use), level 1: 4 workgroups, level 2: worst case.  Rays that would need more are
-    // flagged; terrain_run repeats the batch one level up (same scheme as horizon_launch).
-    const int full = 3 * std::max(sc->hdr.height, 1);
-    p.stack_cap = (a.stack_level == 0 && a.stack_entries <= 0) ? std::min(full, 26)
-                                                               : stack_cap_for_level(sc->hdr.height, 0, a.stack_entries, a.stack_level);
-    if (cap_is_full) *cap_is_full = (p.stack_cap >= full) ? 1 : 0;
-    p.stack_bytes = p.stack_cap * HZ_TPB * 4;
+    // LDS stack: one entry per tree level (hz_common.h): 12 - 14 KB per workgroup, so the kernel's 59 VGPRs decide
+    // the residency (8 waves per SIMD)
+    p.stack_bytes = std::max(sc->hdr.height, 1) * HZ_TPB * 4;
     p.top_nodes = 0;
     p.counters = a.counters;
     const size_t lds = (size_t)p.stack_bytes;

@@ -35,7 +35,7 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
                     num_tri_simp=1, elev_ang_low_lim=-15.0, mask=None,
                     hori_fill=0.0, ray_org_elev=0.01, *, device=0, verbose=False,
                     scene=None, svf_vec_tilt=None, svf_only=False, rows=None, count_work=False, devices=None,
-                    _top_nodes=-1, _regroup=-1, _hit_cache=True, _chunk_rows=0, _stack_entries=0, _near_skip=True,
+                    _top_nodes=-1, _regroup=-1, _hit_cache=True, _chunk_rows=0, _near_skip=True,
                     _verify_near=False):
     """Horizon computation for gridded domain.
 
@@ -138,7 +138,6 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
     opts.regroup = _regroup
     opts.no_hit_cache = 0 if _hit_cache else 1
     opts.chunk_rows = _chunk_rows
-    opts.stack_entries = _stack_entries
     opts.no_near_skip = 0 if _near_skip else 1
     opts.verify_near = int(bool(_verify_near))
     opts.skip_hori = 1 if svf_only else 0

@@ -162,10 +162,6 @@ class Terrain:
                                                     ptr(sw_dir_cor_buffer), C.byref(st)))
         self.last_stats = st.as_dict()
 
-    def _set_stack_entries(self, entries):
-        """LDS traversal-stack entries per lane (0: default); results never depend on it (tests)."""
-        _lib.check(_lib.lib().hz_terrain_set_stack_entries(self._h, int(entries)))
-
     # --- additive batch API (not in the reference): many sun positions, one call ------
     @staticmethod
     def _batch_out(buf, np_dtype, name):

@@ -55,10 +55,7 @@ typedef struct hz_opts {
     int32_t chunk_rows;    /* rows per launch when hori is host memory or skipped (chunks are      */
                            /*   double buffered and copied out while the next one is traced);      */
                            /*   <= 0: as many rows as fit 4 GiB                                     */
-    int32_t stack_entries; /* LDS traversal-stack entries per lane; 0: as many as still allow 5     */
-                           /*   workgroups per CU.  Rays that need more are detected and the call  */
-                           /*   is repeated with the worst case (3 per tree level): results never  */
-                           /*   depend on it                                                       */
+    int32_t reserved0;     /* (was stack_entries: the traversal stack now holds one entry per tree level and cannot overflow) */
     int32_t hori_is_slab;  /* 0: hori_buffer (and svf) address inner-domain row 0 (reference layout, [dim_in_0][..]); */
                            /*   1: they address row_begin, i.e. hold only the slab [row_end - row_begin][dim_in_1].. */
                            /*   -- the form for resident HBM slab buffers (the caller never forms an address        */
@@ -90,7 +87,6 @@ typedef struct hz_stats {
     uint64_t wave_leaf_iters; /*   step / leaf step / ray refill section (SIMT  */
     uint64_t wave_refills;    /*   efficiency = lane count / (64 x wave count)) */
     double t_svf_s;        /* sky-view-factor kernel (when opts.svf is set)    */
-    uint64_t stack_retries;/* calls repeated with the worst-case stack depth   */
     uint64_t rays_shortened;  /* count_work: rays that started beyond the cell's neighbourhood (near-field certificate) */
     uint64_t near_violations; /* count_work + verify_near: shortened rays whose full-length re-trace disagreed (0)      */
     double t_near_s;       /* certificate pre-pass (hz_near.hip)                */
@@ -196,8 +192,6 @@ int hz_topographic_openness(const float *azim, const float *hori, int len_0, int
 /* Test hooks for the hand-written build primitives (stable radix sort of uint32 pairs by key,   */
 /* exclusive prefix sum); host arrays, in place / in -> out.  Not needed by a binding.            */
 int hz_debug_sort_pairs(uint32_t *keys, uint32_t *vals, size_t n, int device);
-/* entries per lane of the LDS traversal stack for a tree of `height` 4-wide levels at residency level 0 / 1 / 2 */
-int hz_debug_stack_cap(int height, int other_lds_bytes, int override_entries, int level);
 int hz_debug_exclusive_scan(const uint32_t *in, uint32_t *out, size_t n, int device);
 /* Machine calibration for the roofline (bench.py, untimed section).  hz_debug_valu_peak: chains of      */
 /* independent v_fma_f32 (packed = 1: v_pk_fma_f32) with `waves_per_simd` resident waves -> wave-level    */
@@ -280,8 +274,6 @@ int hz_terrain_shadow_batch(hz_terrain *terrain, const float *sun_positions,
 int hz_terrain_sw_dir_cor_batch(hz_terrain *terrain, const float *sun_positions,
                                 int num_sun, float *sw_dir_cor_buffers, hz_stats *stats);
 /* CppTerrain::~CppTerrain, shadow_comp.cpp:310-316 */
-/* LDS traversal-stack entries per lane for this terrain's kernels (0: default, see hz_opts.stack_entries). */
-int hz_terrain_set_stack_entries(hz_terrain *terrain, int entries);
 int hz_terrain_destroy(hz_terrain *terrain);
 
 #ifdef __cplusplus

@@ -18,6 +18,6 @@ cells = svf.size
 print(json.dumps({"tile": n, "cells": cells, "synth_s": t_synth, "wall_s": wall, "t_bvh_s": st["t_bvh_s"],
                   "t_h2d_s": st["t_h2d_s"], "t_kernel_s": st["t_kernel_s"], "t_svf_s": st["t_svf_s"],
                   "t_d2h_s": st["t_d2h_s"], "scene_bytes": st["scene_bytes"], "bvh_height": st["bvh_height"],
-                  "rays": st["num_rays"], "stack_retries": st["stack_retries"], "cells_per_s_kernel": cells / st["t_kernel_s"],
+                  "rays": st["num_rays"], "cells_per_s_kernel": cells / st["t_kernel_s"],
                   "mray_per_s_kernel": st["num_rays"] / st["t_kernel_s"] / 1e6, "cells_per_s_wall": cells / wall,
                   "svf_min_max_nan": [float(np.nanmin(svf)), float(np.nanmax(svf)), int(np.isnan(svf).sum())]}))

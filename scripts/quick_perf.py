@@ -41,7 +41,7 @@ for rep in range(args.reps):
     t = time.time()
     hori, azim = hz.horizon.horizon_gridded(g["vert_grid"], n, n, vec_norm, vec_north, off, off,
                                             args.dist, azim_num=args.azim, ray_algorithm=args.alg,
-                                            scene=sc, _top_nodes=args.top, _regroup=args.regroup, _hit_cache=args.hit_cache, _stack_entries=args.stack, _near_skip=not args.no_near, _verify_near=args.verify_near, count_work=args.count_all or (args.count and rep == args.reps - 1))
+                                            scene=sc, _top_nodes=args.top, _regroup=args.regroup, _hit_cache=args.hit_cache, _near_skip=not args.no_near, _verify_near=args.verify_near, count_work=args.count_all or (args.count and rep == args.reps - 1))
     st = hz.horizon.last_stats
     print("rep %d wall %.2fs kernel %.3fs rays %d rays/(cell*az) %.2f Mray/s %.1f cells/s %.0f nodes/ray %.1f tris/ray %.1f"
           % (rep, time.time() - t, st["t_kernel_s"], st["num_rays"], st["num_rays"] / (w * w * args.azim),

@@ -271,24 +271,6 @@ def test_row_slabs_balanced():
     assert row_slabs(3, 8)[-1][1] == 3
 
 
-def test_stack_residency_levels():
-    """LDS traversal-stack sizing (host logic): level 0 leaves room for 5 workgroups per CU (<= 31 KiB with
-    the other LDS users), level 1 for 4 (<= 40 KiB), level 2 is the worst case of 3 entries per tree level;
-    a tree shallower than the budget always gets its worst case, an explicit override applies to level 0 only."""
-    L = _lib.lib()
-    cap = lambda h, other, ov, lvl: L.hz_debug_stack_cap(h, other, ov, lvl)
-    assert cap(12, 4096, 0, 0) == 27 and cap(12, 4096, 0, 1) == 36 and cap(12, 4096, 0, 2) == 36
-    assert cap(14, 4096, 0, 0) == 27 and cap(14, 4096, 0, 1) == 36 and cap(14, 4096, 0, 2) == 42
-    assert cap(12, 0, 0, 0) == 31                              # no output staging: 4 more entries
-    assert cap(5, 4096, 0, 0) == 15 == cap(5, 4096, 0, 2)      # shallow tree: worst case fits
-    assert cap(12, 4096, 9, 0) == 9 and cap(12, 4096, 9, 1) == 36 and cap(12, 4096, 1, 0) == 3
-    for h in range(1, 30):
-        for lvl in (0, 1, 2):
-            c = cap(h, 4096, 0, lvl)
-            assert 3 <= c <= 3 * h or h == 0
-            assert (c + 4) * 1024 <= (31, 40, 10 ** 9)[lvl] * 1024 or c == 3 * h or c == 3
-
-
 def test_library_never_destroys_a_stream():
     """hipStreamDestroy of the ROCm 7.0 HIP runtime can free a stream object that a pending completion callback
     still writes to: the library pools streams instead, so the symbol must not even be

@@ -253,40 +253,40 @@ def test_svf_only_matches_full_path(hip, chunk):
         hip.horizon.horizon_gridded(**kw, dist_search=2.0, azim_num=36, svf_only=True)
 
 
-def test_stack_overflow_falls_back_to_full_depth(hip, orc):
-    """The LDS traversal stack is sized for residency, not for the worst case; a ray that needs more
-    entries is detected and the call repeated with 3 entries per level.  Forced here with tiny stacks."""
+def test_traversal_stack_is_one_entry_per_level(hip, orc):
+    """Siblings are contiguous in the breadth-first node numbering, so the traversal keeps one stack entry per tree
+    level (block + mask of the children still to visit): `height` LDS entries can never overflow -- there is no
+    retry machinery.  Deep, irregular trees (a long thin DEM, an outer TIN: mixed node / leaf children get wrapper
+    nodes) must give the oracle's result."""
     g = cases.rough_terrain(140, 150, seed=33, offset=8, relief=1200.0)
     kw = cases.grid_kwargs(g)
     par = dict(dist_search=4.0, azim_num=48, elev_ang_low_lim=-70.0)
     ref, _, so = orc.horizon_gridded(**kw, **par, return_stats=True)
-    seen = set()
-    for entries in (0, 3, 4, 6, 9, 64):
-        h, _ = hip.horizon.horizon_gridded(**kw, **par, _stack_entries=entries)
-        st = dict(hip.horizon.last_stats)
-        assert np.array_equal(h, ref), entries
-        assert st["num_rays"] == so["rays"], entries
-        seen.add(st["stack_retries"])
-    assert seen == {0, 1}                       # tiny stacks had to retry, the default did not
-    hip.horizon.horizon_gridded(**kw, **par)
-    assert hip.horizon.last_stats["stack_retries"] == 0
-    # same scheme in the shadow kernels
+    sc = hip.Scene.create(kw["vert_grid"], 140, 150)
+    assert 7 <= sc.stats["bvh_height"] <= 10                  # ~ log4(140 x 150 quads) + 1
+    h, _ = hip.horizon.horizon_gridded(**kw, **par, scene=sc)
+    assert np.array_equal(h, ref) and hip.horizon.last_stats["num_rays"] == so["rays"]
+    # a 3 x 1500 strip: a very unbalanced quadtree over (x, y)
+    rng = np.random.default_rng(9)
+    strip = cases.rough_terrain(3, 1500, seed=4, offset=0, relief=300.0)
+    kws = cases.grid_kwargs(strip)
+    hs, _ = hip.horizon.horizon_gridded(**kws, dist_search=8.0, azim_num=12, elev_ang_low_lim=-89.98)
+    rs, _ = orc.horizon_gridded(**kws, dist_search=8.0, azim_num=12, elev_ang_low_lim=-89.98)
+    assert np.array_equal(hs, rs)
+    # grid + TIN triangles interleave in Morton order: nodes with both leaf and internal children
+    vs, nvs, ts, nts = cases.outer_tin(g, margin=200.0, zval=1500.0)
+    ht, _ = hip.horizon.horizon_gridded(**kw, **par, vert_simp=vs, num_vert_simp=nvs, tri_ind_simp=ts, num_tri_simp=nts)
+    rt, _ = orc.horizon_gridded(**kw, **par, vert_simp=vs, num_vert_simp=nvs, tri_ind_simp=ts, num_tri_simp=nts)
+    assert np.array_equal(ht, rt)
+    # same traversal in the shadow kernels
     vec_tilt, vec_norm, enl, elev, mask = cases.terrain_inputs(g)
     tg, tc = hip.shadow.Terrain(), orc.Terrain()
     for t in (tg, tc):
         t.initialise(g["vert_grid"], 140, 150, 8, 8, vec_tilt, vec_norm, enl, elev, mask)
     sun = np.array([2000.0 + 1.0e7 * np.cos(0.12), 2000.0, 1.0e7 * np.sin(0.12)], np.float32)
     want = np.empty(mask.shape, np.uint8); tc.shadow(sun, want)
-    retried = set()
-    for entries in (0, 3, 5, 100):
-        tg._set_stack_entries(entries)
-        got = np.empty(mask.shape, np.uint8); tg.shadow(sun, got)
-        assert np.array_equal(got, want), entries
-        retried.add(tg.last_stats["stack_retries"])
-        f = np.empty(mask.shape, np.float32); tg.sw_dir_cor(sun, f)
-        fc = np.empty(mask.shape, np.float32); tc.sw_dir_cor(sun, fc)
-        assert np.array_equal(f, fc), entries
-    assert retried == {0, 1} and (want == 2).any()
+    got = np.empty(mask.shape, np.uint8); tg.shadow(sun, got)
+    assert np.array_equal(got, want) and (want == 2).any()
 
 
 def test_devices_threads_match_single_call(hip):
