@@ -49,12 +49,15 @@ struct BlobHeader {
 };
 static_assert(sizeof(BlobHeader) == 256, "BlobHeader must be 256 bytes");
 
-// traversal links: >= 0 node index; < 0 leaf, record index = ~link; HZ_EMPTY: nothing
-#define HZ_EMPTY ((int)0x80000000)
+// traversal links: >= 0 node index; < 0 leaf, record index = link & 0x7fffffff (sign + magnitude, so that child k of
+// a block is `first + k` for both kinds); HZ_EMPTY: nothing
+#define HZ_EMPTY ((int)0xffffffff)
+#define HZ_LEAF_BIT 0x80000000u
+#define HZ_LEAF_ID(link) ((int)((unsigned)(link) & 0x7fffffffu))
 struct __attribute__((aligned(64))) Node {
     float org[3];        // lower corner of the node's box (centred frame)
-    int32_t first;       // >= 0: children are nodes first .. first + 3;  < 0: children are leaf records ~first .. ~first + 3
-                         // (both 4-aligned; child slot k exists iff bit k of `valid`)
+    int32_t first;       // link of child slot 0; slots 1..3 are first + 1 .. first + 3: 4 consecutive nodes or 4
+                         // consecutive leaf records (blocks are 4-aligned; slot k exists iff bit k of `valid`)
     uint32_t qxy[4];     // per child slot: xlo | xhi<<8 | ylo<<16 | yhi<<24   (8 bit, 0..255)
     uint32_t qz[4];      // per child slot: zlo | zhi<<16                      (16 bit)
     float step[3];       // quantisation steps of x, y, z (powers of two)
@@ -320,12 +323,13 @@ __device__ __forceinline__ void hz_load_prim(const Prim *q, float4 &q0, float4 &
 
 // ---------------------------------------------------------------------------
 // any-hit traversal of one ray, resumable.
-//   TravState : node (current link), sp (LDS stack pointer), top (the pending-siblings entry of the level being
-//               descended, kept in a register; 0 = none), up to 2 queued leaves
-//   stack     : per-lane LDS stack, entry k of lane tid at stack[k * TPB + tid]; one entry per tree level:
-//               entry = type << 31 | (block >> 2) << 4 | mask   -- block = the node's `first` (nodes) or ~first
-//               (leaves), mask = child slots 1..3 still to visit (slot 0 is never pending: the first hit child is
-//               entered at once).  At most one entry per level is alive, so `height` entries can never overflow.
+//   TravState : node (current link), sp (LDS stack pointer), pf / pm (the pending siblings of the level being
+//               descended, kept in registers: link of slot 0 of their block and the mask of slots still to visit;
+//               pm = 0: none), up to 2 queued leaves
+//   stack     : per-lane LDS stack, entry k of lane tid at stack[k * TPB + tid]; one entry per tree level = the
+//               (pf, pm) pair of that level packed into 32 bits (blocks are 4-aligned and links use 30 bits, so the
+//               three mask bits of slots 1..3 -- slot 0 is never pending: the first hit child is entered at once --
+//               live in bits 0, 1 and 30).  At most one entry per level is alive: `height` entries cannot overflow.
 //   top       : LDS copy of the first ntop nodes, read only by the NODELET instantiation (else null / 0)
 //   regroup   : leave when fewer than `regroup` lanes of the wave are still traversing (and at least one
 //               lane finished in this call, so the caller can refill it)
@@ -337,24 +341,19 @@ __device__ __forceinline__ void hz_load_prim(const Prim *q, float4 &q0, float4 &
 // returns 0 = miss, 1 = hit (t.lq0 is the blocking leaf), 2 = suspended (state is valid, call again)
 // ---------------------------------------------------------------------------
 struct TravCounters { unsigned nodes, tris, w_nodes, w_leaves; };
-struct TravState { int node, sp, top, lq0, lq1; };
+struct TravState { int node, sp, pf, pm, lq0, lq1; };
 
 __device__ __forceinline__ void hz_trav_reset(TravState &t) {
-    t.node = 0; t.sp = 0; t.top = 0; t.lq0 = HZ_EMPTY; t.lq1 = HZ_EMPTY;
+    t.node = 0; t.sp = 0; t.pf = 0; t.pm = 0; t.lq0 = HZ_EMPTY; t.lq1 = HZ_EMPTY;
 }
 
-// pending-siblings entry of a node whose children block starts at `first`, for the hit mask `rest` (bits 1..3)
-__device__ __forceinline__ int hz_entry(int first, int rest) {
-    const int sgn = first >> 31;                       // 0 nodes, -1 leaves
-    return (int)(((unsigned)(first ^ sgn) << 2) | (unsigned)rest | ((unsigned)sgn & 0x80000000u));
+// (pf, pm) <-> one LDS word
+__device__ __forceinline__ int hz_entry_pack(int pf, int pm) {
+    return (int)((unsigned)pf | (((unsigned)pm >> 1) & 3u) | (((unsigned)pm & 8u) << 27));
 }
-// next pending child of entry `e` (e != 0); clears it from the entry's mask (the entry may become exhausted: mask 0)
-__device__ __forceinline__ int hz_entry_next(int &e) {
-    const int m = e & 15;
-    const int slot = __builtin_ctz((unsigned)m);
-    const int child = (int)(((unsigned)e & 0x7ffffff0u) >> 2) + slot;
-    e &= ~(1 << slot);
-    return (e < 0) ? ~child : child;
+__device__ __forceinline__ void hz_entry_unpack(int e, int &pf, int &pm) {
+    pm = (int)((((unsigned)e & 3u) << 1) | (((unsigned)e >> 27) & 8u));
+    pf = (int)((unsigned)e & 0xbffffffcu);
 }
 
 #define HZ_WAVE_TICK(c, lane_) do { const unsigned long long m_ = __ballot(1); if ((lane_) == __ffsll((long long)m_) - 1) (c)++; } while (0)
@@ -366,13 +365,14 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
                                         const RayBox &rb, TravState &t, int regroup, int leaf_bias,
                                         TravCounters &cnt) {
     const int lane = tid & 63;
-    int node = t.node, sp = t.sp, pend = t.top, lq0 = t.lq0, lq1 = t.lq1;
+    int node = t.node, sp = t.sp, pf = t.pf, pm = t.pm, lq0 = t.lq0, lq1 = t.lq1;
     const int n_entry = __popcll(__ballot(1));   // lanes that entered with a ray
-// next link: the pending entry of the current level first, then the levels above (LDS), else nothing
-#define HZ_POP() do { if (pend != 0 && (pend & 15) == 0) { const bool ne = sp > 0; sp = ne ? sp - 1 : 0; \
-                          const int pv = stack[sp * TPB + tid]; pend = ne ? pv : 0; } \
-                      if (pend != 0) node = hz_entry_next(pend); else node = HZ_EMPTY; } while (0)
-#define HZ_SAVE() do { t.node = node; t.sp = sp; t.top = pend; t.lq0 = lq0; t.lq1 = lq1; } while (0)
+// next link: a pending sibling of the current level, else of the closest level above that has one (LDS), else nothing
+#define HZ_POP() do { if (pm == 0) { const bool ne = sp > 0; sp = ne ? sp - 1 : 0; const int pv = stack[sp * TPB + tid]; \
+                          hz_entry_unpack(ne ? pv : 0, pf, pm); } \
+                      const int slot_ = __builtin_ctz((unsigned)pm | 16u); \
+                      node = (pm != 0) ? pf + slot_ : HZ_EMPTY; pm &= pm - 1; } while (0)
+#define HZ_SAVE() do { t.node = node; t.sp = sp; t.pf = pf; t.pm = pm; t.lq0 = lq0; t.lq1 = lq1; } while (0)
     int res = -1;                 // single exit: lanes leave the loop through `res`, state is saved once
     while (res < 0) {
         // set leaves aside while the leaf queue (QLEN entries, filled front to back) has room
@@ -411,13 +411,12 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
                 h |= hz_qbox_hit(nr, rb, tfar, n1.w, n2.w) ? 8 : 0;
                 if (h != 0) {
                     const int first = __float_as_int(n0.w);
-                    const int slot = __builtin_ctz((unsigned)h);
                     const int rest = h & (h - 1);
-                    if (rest != 0) {             // siblings to come back to: one entry for this level
-                        if (pend != 0 && (pend & 15) != 0) { stack[sp * TPB + tid] = pend; sp++; }
-                        pend = hz_entry(first, rest);
+                    if (rest != 0) {             // siblings to come back to: they become the pending set of this level
+                        if (pm != 0) { stack[sp * TPB + tid] = hz_entry_pack(pf, pm); sp++; }
+                        pf = first; pm = rest;
                     }
-                    node = (first < 0) ? first - slot : first + slot;        // ~(~first + slot) == first - slot
+                    node = first + __builtin_ctz((unsigned)h);
                 } else {
                     HZ_POP();
                 }
@@ -426,7 +425,7 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
             // ---------------- leaf step: the two triangles of a DEM quad (or one TIN triangle) ---
             if (can_leaf) {
                 float4 q0, q1, q2;
-                hz_load_prim(prims + (~lq0), q0, q1, q2);
+                hz_load_prim(prims + HZ_LEAF_ID(lq0), q0, q1, q2);
                 // a = (q0.x q0.y q0.z) b = (q0.w q1.x q1.y) c = (q1.z q1.w q2.x) d = (q2.y q2.z q2.w)
                 if (COUNT) { cnt.tris += (q2.y == q2.y) ? 2 : 1; HZ_WAVE_TICK(cnt.w_leaves, lane); }
                 const bool hit = hz_quad_hit(ox, oy, oz, dx, dy, dz, tfar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
@@ -465,8 +464,7 @@ __device__ __forceinline__ bool hz_closest(const Node *__restrict__ nodes, const
             const bool h0 = hz_qbox_hit(nr, rb, tf, n1.x, n2.x), h1 = hz_qbox_hit(nr, rb, tf, n1.y, n2.y);
             const bool h2 = hz_qbox_hit(nr, rb, tf, n1.z, n2.z), h3 = hz_qbox_hit(nr, rb, tf, n1.w, n2.w);
             const int first = __float_as_int(n0.w);
-            const int c0 = first, c1 = first < 0 ? first - 1 : first + 1, c2 = first < 0 ? first - 2 : first + 2,
-                      c3 = first < 0 ? first - 3 : first + 3;
+            const int c0 = first, c1 = first + 1, c2 = first + 2, c3 = first + 3;
             int next = HZ_EMPTY;
             if (h3) next = c3;
             if (h2) { if (next != HZ_EMPTY) { stack[sp * TPB + tid] = next; sp++; } next = c2; }
@@ -475,7 +473,7 @@ __device__ __forceinline__ bool hz_closest(const Node *__restrict__ nodes, const
             if (next != HZ_EMPTY) { node = next; continue; }
         } else {
             float4 q0, q1, q2;
-            hz_load_prim(prims + (~node), q0, q1, q2);
+            hz_load_prim(prims + HZ_LEAF_ID(node), q0, q1, q2);
             float t;
             if (hz_tri_hit_t(ox, oy, oz, dx, dy, dz, tfar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, &t)) {
                 any = true; best = __builtin_fminf(best, t);

@@ -177,7 +177,7 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
             } else if (r != 2) {
                 if (COUNT && verifying) { if ((r == 1) != first_result) violations++; verifying = false; }
                 ray_active = false; last_hit = (r == 1);
-                if (r == 1) cache = p.sv.anc[~ts.lq0];   // ts.lq0 is the leaf that blocked the ray
+                if (r == 1) cache = p.sv.anc[HZ_LEAF_ID(ts.lq0)];   // ts.lq0 is the leaf that blocked the ray
             }
         }
     }

@@ -238,11 +238,12 @@ __global__ __launch_bounds__(256) void k_roots(int n_nodes, const int *__restric
 
 // 4-wide node as k_emit4 produces it (children addressed by individual links, numbered in compaction order);
 // the breadth-first pass below turns these into the final `Node`s with contiguous children
+#define HZ_TMP_EMPTY ((int)0x80000000)   // "no child" among the temp links (>= 0 temp node, < 0 leaf = ~sorted position)
 struct NodeTmp {
     float org[3];
     uint32_t scale;      // biased float exponents of the x | y<<8 | z<<16 quantisation steps
     uint32_t qxy[4], qz[4];
-    int32_t link[4];     // >= 0 temp node, < 0 leaf (~sorted position), HZ_EMPTY none
+    int32_t link[4];     // >= 0 temp node, < 0 leaf (~sorted position), HZ_TMP_EMPTY none
 };
 
 struct Emit4 {
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void k_emit4(Emit4 e, NodeTmp *__restrict__ no
     int link[4]; float lo[4][3], hi[4][3];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        link[k] = HZ_EMPTY;
+        link[k] = HZ_TMP_EMPTY;
 #pragma unroll
         for (int a = 0; a < 3; a++) { lo[k][a] = 0.0f; hi[k][a] = 0.0f; }
     }
@@ -319,7 +320,7 @@ __global__ __launch_bounds__(256) void k_emit4(Emit4 e, NodeTmp *__restrict__ no
     // the traversal visits slot 0 first: put the tallest child there (a blocked ray is most likely
     // blocked by the child that reaches highest), empty slots last
     {
-        auto key = [&](int k) { return link[k] == HZ_EMPTY ? -INFINITY : hi[k][2]; };
+        auto key = [&](int k) { return link[k] == HZ_TMP_EMPTY ? -INFINITY : hi[k][2]; };
         auto cswap = [&](int x, int y) {
             if (key(x) < key(y)) {
                 const int t = link[x]; link[x] = link[y]; link[y] = t;
@@ -344,7 +345,7 @@ __global__ __launch_bounds__(256) void k_emit4(Emit4 e, NodeTmp *__restrict__ no
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         n.link[k] = link[k];
-        if (link[k] == HZ_EMPTY) { n.qxy[k] = 0x00ff00ffu; n.qz[k] = 0x0000ffffu; continue; }   // lo > hi: never hit
+        if (link[k] == HZ_TMP_EMPTY) { n.qxy[k] = 0x00ff00ffu; n.qz[k] = 0x0000ffffu; continue; }   // lo > hi: never hit
         const uint32_t xl = quant_lo(lo[k][0], org[0], sx, 255.0f), xh = quant_hi(hi[k][0], org[0], sx, 255.0f);
         const uint32_t yl = quant_lo(lo[k][1], org[1], sy, 255.0f), yh = quant_hi(hi[k][1], org[1], sy, 255.0f);
         const uint32_t zl = quant_lo(lo[k][2], org[2], sz, 65535.0f), zh = quant_hi(hi[k][2], org[2], sz, 65535.0f);
@@ -366,7 +367,7 @@ __device__ __forceinline__ void bfs_kinds(const NodeTmp &t, int &n_int, int &n_l
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if (t.link[k] >= 0) n_int++;
-        else if (t.link[k] != HZ_EMPTY) n_leaf++;
+        else if (t.link[k] != HZ_TMP_EMPTY) n_leaf++;
     }
 }
 
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(256) void k_bfs_emit(BfsEmit e, BuildParams b) {
     const int self = e.level_start + pos;
     if (v <= -2) {                                        // wrapper node (header written by its parent): its one leaf
         const int lb = e.leaf_blocks_before + (int)e.scan_leaf[pos];
-        e.nodes[self].first = ~(4 * lb);
+        e.nodes[self].first = (int)(HZ_LEAF_BIT | (unsigned)(4 * lb));
         write_prim(b, e.vals, -2 - v, &e.prims[(size_t)4 * lb]);
         e.leaf_parent[lb] = self;
         return;
@@ -438,12 +439,12 @@ __global__ __launch_bounds__(256) void k_bfs_emit(BfsEmit e, BuildParams b) {
     n.step[2] = __uint_as_float(((t.scale >> 16) & 0xffu) << 23);
     n.valid = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { n.qxy[k] = t.qxy[k]; n.qz[k] = t.qz[k]; if (t.link[k] != HZ_EMPTY) n.valid |= 1u << k; }
+    for (int k = 0; k < 4; k++) { n.qxy[k] = t.qxy[k]; n.qz[k] = t.qz[k]; if (t.link[k] != HZ_TMP_EMPTY) n.valid |= 1u << k; }
     if (ni == 0) {                                        // all children are leaves: one leaf block
         const int lb = e.leaf_blocks_before + (int)e.scan_leaf[pos];
-        n.first = ~(4 * lb);
+        n.first = (int)(HZ_LEAF_BIT | (unsigned)(4 * lb));
 #pragma unroll
-        for (int k = 0; k < 4; k++) if (t.link[k] != HZ_EMPTY) write_prim(b, e.vals, ~t.link[k], &e.prims[(size_t)4 * lb + k]);
+        for (int k = 0; k < 4; k++) if (t.link[k] != HZ_TMP_EMPTY) write_prim(b, e.vals, ~t.link[k], &e.prims[(size_t)4 * lb + k]);
         e.leaf_parent[lb] = self;
     } else {                                              // a node block; leaf children get wrapper nodes
         const int rel = (int)e.scan_node[pos];
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(256) void k_bfs_emit(BfsEmit e, BuildParams b) {
         for (int k = 0; k < 4; k++) {
             int f = -1;
             if (t.link[k] >= 0) f = t.link[k];
-            else if (t.link[k] != HZ_EMPTY) {
+            else if (t.link[k] != HZ_TMP_EMPTY) {
                 f = -2 - (~t.link[k]);
                 Node w;                                    // single-child node: this slot's box in this node's frame
                 w.org[0] = n.org[0]; w.org[1] = n.org[1]; w.org[2] = n.org[2];
@@ -492,7 +493,7 @@ __global__ void k_single_tmp(const float4 *leaf_lo, const float4 *leaf_hi, NodeT
     NodeTmp n;
     n.org[0] = l.x; n.org[1] = l.y; n.org[2] = l.z;
     n.scale = ex | (ey << 8) | (ez << 16);
-    for (int k = 0; k < 4; k++) { n.link[k] = HZ_EMPTY; n.qxy[k] = 0x00ff00ffu; n.qz[k] = 0x0000ffffu; }
+    for (int k = 0; k < 4; k++) { n.link[k] = HZ_TMP_EMPTY; n.qxy[k] = 0x00ff00ffu; n.qz[k] = 0x0000ffffu; }
     n.link[0] = ~0;
     n.qxy[0] = 0u | (quant_hi(h.x, l.x, __uint_as_float(ex << 23), 255.0f) << 8)
              | (quant_hi(h.y, l.y, __uint_as_float(ey << 23), 255.0f) << 24);
@@ -740,7 +741,7 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     const size_t n_node_blocks = (size_t)sizes[0] + 1;                 // + the root's own block
     const size_t n_leaf_blocks = sizes[1];
     const size_t n_nodes = 4 * n_node_blocks, n_prim_slots = 4 * n_leaf_blocks;
-    if (n_nodes > 0x7ffffff0u / 4 || n_prim_slots > 0x1ffffff0u)
+    if (n_nodes > 0x3ffffff0u || n_prim_slots > 0x3ffffff0u)     // links use 30 bits (hz_common.h: stack entries)
         return set_error(HZ_ERR_DEPTH, "scene too large for the 32-bit traversal links");
 
     // ---- blob allocation (exact size now known) ------------------------------------------------
