@@ -106,11 +106,17 @@ def main():
     ctx = dict(args=args, world=world, rank=rank, local_rank=local_rank, use_dist=use_dist,
                dev="cuda:%d" % local_rank)
     out = run_c5(ctx) if args.workload == "c5" else run_c3(ctx)
-    if rank == 0:
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio: flush that first so that the JSON line is the last line
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 def make_scene(ctx, g, n):
