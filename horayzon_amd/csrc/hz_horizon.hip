@@ -43,7 +43,7 @@ struct HorizonParams {
     int row_begin, row_end;
     TileMap tm;                    // tile grid of the slab -> workgroups (XCD aware)
     float dist, hori_fill, ray_org_elev;
-    int top_nodes, regroup, stack_bytes, leaf_bias, stage_bytes, hit_cache, az_slack;
+    int top_nodes, regroup, stack_bytes, leaf_bias, stage_bytes, hit_cache;
     const unsigned short *near_idx;   // near-field certificates of this launch's rows (hz_near.hip) or null
     const float *near_r;
     int verify_near;
@@ -139,15 +139,7 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
 
     while (__ballot(!done) != 0ull) {
         // ---- refill: lanes without a ray take the next sample of their search -----------------
-        // soft azimuth lockstep (az_slack > 0): a lane may run at most az_slack azimuths ahead of the slowest lane of
-        // its wave, so that the rays in flight stay nearly parallel (same nodes, similar lengths)
-        bool hold = false;
-        if (p.az_slack > 0) {
-            int kmin = done ? 0x7fffffff : s.k;
-            for (int off = 32; off > 0; off >>= 1) kmin = min(kmin, __shfl_xor(kmin, off));
-            hold = s.k > kmin + p.az_slack;
-        }
-        if (!done && !ray_active && !hold) {
+        if (!done && !ray_active) {
             if (COUNT) HZ_WAVE_TICK(w_adv, lane);
             out.hori = hori0 + (size_t)cert * (size_t)t.azim_num;
             if (advance<ALG, STAGE>(s, last_hit, t, out, guards)) {
@@ -269,8 +261,7 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
     // defaults from the sweep on the 3601^2 tile: refill when fewer than 40 lanes
     // are traversing; leaf step when 20 n_leaf > 16 n_node.  opts.regroup = threshold | bias << 8.
     p.regroup = (a.regroup < 0) ? 40 : std::min(a.regroup & 0xff, 64);
-    p.leaf_bias = (a.regroup >= 256 && ((a.regroup >> 8) & 0xff)) ? ((a.regroup >> 8) & 0xff) : 20;
-    p.az_slack = (a.regroup >= 65536) ? (a.regroup >> 16) : 0;      // opts.regroup = threshold | bias << 8 | slack << 16
+    p.leaf_bias = (a.regroup >= 256) ? (a.regroup >> 8) : 20;
     p.hit_cache = (a.hit_cache != 0) ? 1 : 0;
     p.near_idx = a.near_idx; p.near_r = a.near_r; p.verify_near = a.verify_near;
     p.counters = a.counters;
