@@ -142,7 +142,7 @@ __device__ __forceinline__ int delta(const uint32_t *__restrict__ keys, int n, i
 __global__ __launch_bounds__(256) void k_karras(const uint32_t *__restrict__ keys, int n,
                                                int2 *__restrict__ child, int *__restrict__ parent_int,
                                                int *__restrict__ parent_leaf, uint8_t *__restrict__ plen,
-                                               int *__restrict__ first, int *__restrict__ last) {
+                                               int *__restrict__ first) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n - 1) return;
     const int d = (delta(keys, n, i, i + 1) - delta(keys, n, i, i - 1)) >= 0 ? 1 : -1;
@@ -166,8 +166,7 @@ __global__ __launch_bounds__(256) void k_karras(const uint32_t *__restrict__ key
     const int right = (hi == gamma + 1) ? ~(gamma + 1) : gamma + 1;
     child[i] = make_int2(left, right);
     plen[i] = (uint8_t)dnode;      // common prefix length of the node's key range (0..63)
-    first[i] = lo;                 // first / last sorted leaf of the range (i is one of the two)
-    last[i] = hi;
+    first[i] = lo;                 // first sorted leaf of the range
     if (left >= 0) parent_int[left] = i; else parent_leaf[~left] = i;
     if (right >= 0) parent_int[right] = i; else parent_leaf[~right] = i;
     if (i == 0) parent_int[0] = -1;
@@ -257,8 +256,7 @@ struct NodeTmp {
 };
 
 struct Emit4 {
-    const int2 *child; const uint8_t *plen; const int *first; const int *last;
-    int2 *trange;          // out, per temp node: temp ids [x, y) of its subtree (itself included)
+    const int2 *child; const uint8_t *plen; const int *first;
     const uint32_t *keys; const uint32_t *flag; const uint32_t *idx;
     const float4 *leaf_lo, *leaf_hi, *node_lo, *node_hi;
     int n_nodes;
@@ -364,33 +362,15 @@ __global__ __launch_bounds__(256) void k_emit4(Emit4 e, NodeTmp *__restrict__ no
         n.qz[k] = zl | (zh << 16);
     }
     nodes[e.idx[i]] = n;
-    // The internal nodes below binary node i (range [lo, hi], i at one end) have the ids [lo, hi - 1] (i == lo) or
-    // [lo + 1, hi] (i == hi); temp ids are the exclusive scan of the 4-wide flags over the binary ids, so the temp
-    // nodes of this subtree are one contiguous range too.
-    const int leaf_lo_i = e.first[i], leaf_hi_i = e.last[i];
-    const int id_lo = (i == leaf_lo_i) ? leaf_lo_i : leaf_lo_i + 1, id_hi = (i == leaf_lo_i) ? leaf_hi_i - 1 : leaf_hi_i;
-    e.trange[e.idx[i]] = make_int2((int)e.idx[id_lo], (int)(e.idx[id_hi] + e.flag[id_hi]));
 }
 
-// --- final numbering: contiguous children, breadth first at the top, depth first below ----------------------
-// Every node's children occupy ONE 4-aligned block of 4 slots -- nodes, or 48 B leaf records (a node with internal
-// AND leaf children gets its leaves wrapped into single-child nodes, so a block is of one kind).  Where the blocks
-// go decides the memory behaviour of the traversal:
-//   * the first HZ_TOP_LEVELS levels are numbered breadth first (the hot top of the tree is one small contiguous
-//     range -- the optional LDS nodelet stages it);
-//   * below, a subtree is laid out depth first: [children block of N][everything below child 0][... child 1] ...
-//     so a ray's descent into the first (tallest) child continues in adjacent memory, a whole subtree is one
-//     address range (TLB, DRAM pages), and parent and child often share a 128 B line.  (All levels breadth first
-//     cost 3.5 % on the 3601^2 tile against round 1's depth-first-like order, measured on one box.)
-// The depth-first addresses need no serial pass: the temp nodes of a subtree are a contiguous range of temp ids
-// (k_emit4), so "node / leaf blocks inside a subtree" are differences of two prefix sums over the temp ids, and a
-// node hands each child its block address = own block + 4 + the sizes of the subtrees of the children before it.
-// The frontier of a level holds, per node of that level: what sits there (>= 0 temp node, <= -2 one leaf that needs
-// a wrapper: sorted position -2 - v), its own slot, the address of its children block and its first leaf block.
-#ifndef HZ_TOP_LEVELS
-#define HZ_TOP_LEVELS 5
-#endif
-
+// --- breadth-first numbering with contiguous children ---------------------------------------------
+// The temp nodes are renumbered level by level.  A frontier holds, for every node slot of a level, what sits
+// there: >= 0 a temp node, <= -2 a single leaf that needs a wrapper node (sorted position -2 - v), -1 nothing.
+// Every entry asks for one block of 4 child slots: a NODE block when the temp node has internal children (its
+// leaf children are then wrapped: they go to the next frontier as <= -2 entries), else a LEAF block.  Blocks are
+// handed out by an exclusive scan over the frontier, so children are contiguous, siblings keep their slot order
+// (tallest first) and the numbering is breadth first.
 __device__ __forceinline__ void bfs_kinds(const NodeTmp &t, int &n_int, int &n_leaf) {
     n_int = 0; n_leaf = 0;
 #pragma unroll
@@ -400,69 +380,39 @@ __device__ __forceinline__ void bfs_kinds(const NodeTmp &t, int &n_int, int &n_l
     }
 }
 
-// per temp node: does it own a node block (internal children), how many leaf blocks (one of its own, or one per
-// wrapped leaf).  Their prefix sums over the temp ids give subtree sizes; their totals the array sizes.
-__global__ __launch_bounds__(256) void k_tmp_counts(int n4, const NodeTmp *__restrict__ tmp, uint32_t *__restrict__ nb,
-                                                   uint32_t *__restrict__ lb) {
+// exact sizes of the final arrays: node blocks = temp nodes with an internal child (+ the root's own block),
+// leaf blocks = temp nodes without one + one per wrapped leaf
+__global__ __launch_bounds__(256) void k_bfs_sizes(int n4, const NodeTmp *__restrict__ tmp, unsigned int *__restrict__ sizes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n4) return;
-    int ni, nl;
-    bfs_kinds(tmp[i], ni, nl);
-    nb[i] = ni > 0 ? 1u : 0u;
-    lb[i] = ni > 0 ? (uint32_t)nl : 1u;
+    unsigned nb = 0, lb = 0;
+    if (i < n4) {
+        int ni, nl;
+        bfs_kinds(tmp[i], ni, nl);
+        if (ni > 0) { nb = 1; lb = (unsigned)nl; } else lb = 1;
+    }
+    for (int off = 32; off > 0; off >>= 1) { nb += __shfl_xor(nb, off); lb += __shfl_xor(lb, off); }
+    if ((threadIdx.x & 63) == 0) { if (nb) atomicAdd(&sizes[0], nb); if (lb) atomicAdd(&sizes[1], lb); }
 }
 
-struct Frontier { int *v, *self, *cha, *lbb; };   // what, own slot, children block (slot index), first leaf block
-
-// breadth-first levels: needs of every frontier entry (-> scans -> k_assign_bfs)
-__global__ __launch_bounds__(256) void k_need(int cnt, Frontier f, const NodeTmp *__restrict__ tmp,
-                                             uint32_t *__restrict__ need_node, uint32_t *__restrict__ need_leaf) {
+__global__ __launch_bounds__(256) void k_bfs_need(int cnt, const int *__restrict__ frontier, const NodeTmp *__restrict__ tmp,
+                                                 uint32_t *__restrict__ need_node, uint32_t *__restrict__ need_leaf) {
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= cnt) return;
-    const int v = f.v[pos];
+    const int v = frontier[pos];
     uint32_t nn = 0, nl = 0;
     if (v >= 0) { int ni, nlf; bfs_kinds(tmp[v], ni, nlf); if (ni > 0) nn = 1; else nl = 1; }
-    else nl = 1;
+    else if (v <= -2) nl = 1;
     need_node[pos] = nn; need_leaf[pos] = nl;
 }
-__global__ __launch_bounds__(256) void k_assign_bfs(int cnt, Frontier f, const uint32_t *__restrict__ scan_node,
-                                                   const uint32_t *__restrict__ scan_leaf, int node_blocks_before,
-                                                   int leaf_blocks_before) {
-    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos >= cnt) return;
-    f.cha[pos] = 4 * (node_blocks_before + (int)scan_node[pos]);
-    f.lbb[pos] = leaf_blocks_before + (int)scan_leaf[pos];
-}
-// first depth-first level: every entry becomes the root of a contiguous region; region sizes from the temp-id ranges
-__global__ __launch_bounds__(256) void k_region_sizes(int cnt, Frontier f, const int2 *__restrict__ trange,
-                                                     const uint32_t *__restrict__ nb_scan, const uint32_t *__restrict__ lb_scan,
-                                                     uint32_t *__restrict__ size_node, uint32_t *__restrict__ size_leaf) {
-    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos >= cnt) return;
-    const int v = f.v[pos];
-    uint32_t sn = 0, sl = 1;                                   // a wrapper: no node block, one leaf block
-    if (v >= 0) { const int2 r = trange[v]; sn = nb_scan[r.y] - nb_scan[r.x]; sl = lb_scan[r.y] - lb_scan[r.x]; }
-    size_node[pos] = sn; size_leaf[pos] = sl;
-}
-// entries the next level gets from each entry (frontier compaction)
-__global__ __launch_bounds__(256) void k_child_counts(int cnt, Frontier f, const NodeTmp *__restrict__ tmp,
-                                                     uint32_t *__restrict__ cc) {
-    const int pos = blockIdx.x * blockDim.x + threadIdx.x;
-    if (pos >= cnt) return;
-    const int v = f.v[pos];
-    uint32_t c = 0;
-    if (v >= 0) { int ni, nl; bfs_kinds(tmp[v], ni, nl); if (ni > 0) c = (uint32_t)(ni + nl); }
-    cc[pos] = c;
-}
 
-struct EmitArgs {
-    Frontier cur, next; int cnt;
-    const uint32_t *child_off;                             // exclusive scan of k_child_counts
-    const NodeTmp *tmp; const int2 *trange;
-    const uint32_t *nb_scan, *lb_scan;                     // [n4 + 1] prefix sums over temp ids
-    int depth_first;                                       // 1: hand the children their block addresses (subtree sizes)
+struct BfsEmit {
+    const int *frontier; int cnt, level_start;         // node slots [level_start, level_start + cnt)
+    const NodeTmp *tmp;
+    const uint32_t *scan_node, *scan_leaf;             // exclusive scans of the needs over this frontier
+    int node_blocks_before, leaf_blocks_before;        // blocks handed out on the levels above
+    int *next_frontier;                                // 4 entries per node block of this level
     Node *nodes; Prim *prims; int *parent; int *leaf_parent;   // parent[node slot], leaf_parent[leaf block]
-    const uint32_t *vals;                                  // sorted position -> primitive id
+    const uint32_t *vals;                              // sorted position -> primitive id
 };
 
 __device__ __forceinline__ void write_prim(const BuildParams &b, const uint32_t *__restrict__ vals, int sorted_pos, Prim *dst) {
@@ -475,12 +425,14 @@ __device__ __forceinline__ void write_prim(const BuildParams &b, const uint32_t 
     *dst = p;
 }
 
-__global__ __launch_bounds__(256) void k_emit_level(EmitArgs e, BuildParams b) {
+__global__ __launch_bounds__(256) void k_bfs_emit(BfsEmit e, BuildParams b) {
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= e.cnt) return;
-    const int v = e.cur.v[pos], self = e.cur.self[pos];
+    const int v = e.frontier[pos];
+    if (v == -1) return;                                  // unused slot of a block (zero-filled, never referenced)
+    const int self = e.level_start + pos;
     if (v <= -2) {                                        // wrapper node (header written by its parent): its one leaf
-        const int lb = e.cur.lbb[pos];
+        const int lb = e.leaf_blocks_before + (int)e.scan_leaf[pos];
         e.nodes[self].first = (int)(HZ_LEAF_BIT | (unsigned)(4 * lb));
         write_prim(b, e.vals, -2 - v, &e.prims[(size_t)4 * lb]);
         e.leaf_parent[lb] = self;
@@ -498,27 +450,20 @@ __global__ __launch_bounds__(256) void k_emit_level(EmitArgs e, BuildParams b) {
 #pragma unroll
     for (int k = 0; k < 4; k++) { n.qxy[k] = t.qxy[k]; n.qz[k] = t.qz[k]; if (t.link[k] != HZ_TMP_EMPTY) n.valid |= 1u << k; }
     if (ni == 0) {                                        // all children are leaves: one leaf block
-        const int lb = e.cur.lbb[pos];
+        const int lb = e.leaf_blocks_before + (int)e.scan_leaf[pos];
         n.first = (int)(HZ_LEAF_BIT | (unsigned)(4 * lb));
 #pragma unroll
         for (int k = 0; k < 4; k++) if (t.link[k] != HZ_TMP_EMPTY) write_prim(b, e.vals, ~t.link[k], &e.prims[(size_t)4 * lb + k]);
         e.leaf_parent[lb] = self;
     } else {                                              // a node block; leaf children get wrapper nodes
-        const int first = e.cur.cha[pos];
+        const int rel = (int)e.scan_node[pos];
+        const int first = 4 * (e.node_blocks_before + rel);
         n.first = first;
-        int out = (int)e.child_off[pos];
-        int next_block = first + 4, next_lb = e.cur.lbb[pos];     // depth first: what follows this node's children block
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            if (t.link[k] == HZ_TMP_EMPTY) continue;
-            int f, sn = 0, sl = 1;
-            if (t.link[k] >= 0) {
-                f = t.link[k];
-                if (e.depth_first) {
-                    const int2 r = e.trange[f];
-                    sn = 4 * (int)(e.nb_scan[r.y] - e.nb_scan[r.x]); sl = (int)(e.lb_scan[r.y] - e.lb_scan[r.x]);
-                }
-            } else {
+            int f = -1;
+            if (t.link[k] >= 0) f = t.link[k];
+            else if (t.link[k] != HZ_TMP_EMPTY) {
                 f = -2 - (~t.link[k]);
                 Node w;                                    // single-child node: this slot's box in this node's frame
                 w.org[0] = n.org[0]; w.org[1] = n.org[1]; w.org[2] = n.org[2];
@@ -528,10 +473,8 @@ __global__ __launch_bounds__(256) void k_emit_level(EmitArgs e, BuildParams b) {
                 w.qxy[0] = t.qxy[k]; w.qz[0] = t.qz[k];
                 e.nodes[first + k] = w;
             }
-            e.next.v[out] = f; e.next.self[out] = first + k;
-            if (e.depth_first) { e.next.cha[out] = next_block; e.next.lbb[out] = next_lb; next_block += sn; next_lb += sl; }
-            e.parent[first + k] = self;
-            out++;
+            e.next_frontier[4 * rel + k] = f;
+            if (f != -1) e.parent[first + k] = self;
         }
     }
     e.nodes[self] = n;
@@ -624,7 +567,7 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
         const size_t list_cap0 = B / 2 + 2;
         const size_t sizes[] = {is_device_ptr(vert_grid) ? 0 : nvert * 12, has_tin ? (size_t)nvs * 12 : 0,
                                 has_tin ? (size_t)nts * 12 : 0, 24, P * 4, P * 4, P * 4, P * 4,
-                                sort_temp_elems(P) * 4, B * 8, B * 4, P * 4, B, B * 4, B * 4, P * 16, P * 16, B * 16, B * 16,
+                                sort_temp_elems(P) * 4, B * 8, B * 4, P * 4, B, B * 4, P * 16, P * 16, B * 16, B * 16,
                                 (B + 2 * list_cap0 + 4) * 4, B * 4, B * 4, scan_temp_elems(B) * 4};
         size_t total = 0;
         for (size_t x : sizes) total += Arena::pad(x ? x : 16);
@@ -713,13 +656,12 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     const uint32_t *vals = (const uint32_t *)b_v0.p;
 
     // ---- 4./5. binary hierarchy + refit -------------------------------------------------
-    TempBuf b_child, b_pint, b_pleaf, b_plen, b_first, b_last, b_llo, b_lhi, b_nlo, b_nhi, b_cnt;
+    TempBuf b_child, b_pint, b_pleaf, b_plen, b_first, b_llo, b_lhi, b_nlo, b_nhi, b_cnt;
     HZ_HIP(b_child.alloc((size_t)n_bin * 8));
     HZ_HIP(b_pint.alloc((size_t)n_bin * 4));
     HZ_HIP(b_pleaf.alloc((size_t)n_prims * 4));
     HZ_HIP(b_plen.alloc((size_t)n_bin));
     HZ_HIP(b_first.alloc((size_t)n_bin * 4));
-    HZ_HIP(b_last.alloc((size_t)n_bin * 4));
     HZ_HIP(b_llo.alloc((size_t)n_prims * 16)); HZ_HIP(b_lhi.alloc((size_t)n_prims * 16));
     HZ_HIP(b_nlo.alloc((size_t)n_bin * 16)); HZ_HIP(b_nhi.alloc((size_t)n_bin * 16));
     // arrivals[n_bin] | two work lists [n_bin/2 + 1 each, a node enters a list once] | 2 list counters
@@ -734,7 +676,7 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     if (n_prims > 1)
         hipLaunchKernelGGL(k_karras, dim3((n_prims - 1 + 255) / 256), dim3(256), 0, st, keys, n_prims,
                            (int2 *)b_child.p, (int *)b_pint.p, (int *)b_pleaf.p, (uint8_t *)b_plen.p,
-                           (int *)b_first.p, (int *)b_last.p);
+                           (int *)b_first.p);
     hipLaunchKernelGGL(k_leaf_boxes, dim3(gp), dim3(256), 0, st, bp, vals, (const int *)b_pleaf.p,
                        (float4 *)b_llo.p, (float4 *)b_lhi.p, arrivals, lists[0], &counts[0]);
     if (n_prims > 1) {
@@ -780,20 +722,14 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     }
 
     // ---- 7. 4-wide temp nodes (compaction order, individual child links) -------------------------------------
-    TempBuf b_tmp4, b_trange, b_nb, b_lb, b_nbs, b_lbs, b_scan7;
-    g_arena = nullptr;                                   // what follows is sized by n4: arena2
-    {
-        const size_t N4 = (size_t)n4 + 1;
-        HZ_HIP(arena2.reserve(Arena::pad((size_t)n4 * sizeof(NodeTmp)) + Arena::pad((size_t)n4 * 8) + 4 * Arena::pad(N4 * 4) +
-                              Arena::pad(scan_temp_elems(N4) * 4 + 16) + 4096));
-    }
+    TempBuf b_tmp4, b_sizes;
+    g_arena = nullptr;                                   // what follows is sized by n4: own allocations / arena2
+    HZ_HIP(arena2.reserve(Arena::pad((size_t)n4 * sizeof(NodeTmp)) + 64 * 4096));
     g_arena = &arena2;
     HZ_HIP(b_tmp4.alloc((size_t)n4 * sizeof(NodeTmp)));
-    HZ_HIP(b_trange.alloc((size_t)n4 * 8));
     if (n_prims > 1) {
         Emit4 e;
         e.child = (const int2 *)b_child.p; e.plen = (const uint8_t *)b_plen.p; e.first = (const int *)b_first.p;
-        e.last = (const int *)b_last.p; e.trange = (int2 *)b_trange.p;
         e.keys = keys; e.flag = (const uint32_t *)b_flag.p; e.idx = (const uint32_t *)b_idx.p;
         e.leaf_lo = (const float4 *)b_llo.p; e.leaf_hi = (const float4 *)b_lhi.p;
         e.node_lo = (const float4 *)b_nlo.p; e.node_hi = (const float4 *)b_nhi.p;
@@ -802,26 +738,14 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     } else {
         hipLaunchKernelGGL(k_single_tmp, dim3(1), dim3(1), 0, st, (const float4 *)b_llo.p, (const float4 *)b_lhi.p,
                            (NodeTmp *)b_tmp4.p);
-        const int2 whole = make_int2(0, 1);
-        HZ_HIP(hipMemcpyAsync(b_trange.p, &whole, 8, hipMemcpyHostToDevice, st));
     }
-    // node / leaf blocks per temp node and their prefix sums over the temp ids ([n4 + 1]: the last entry is the total)
-    {
-        const size_t N4 = (size_t)n4 + 1;
-        HZ_HIP(b_nb.alloc(N4 * 4)); HZ_HIP(b_lb.alloc(N4 * 4)); HZ_HIP(b_nbs.alloc(N4 * 4)); HZ_HIP(b_lbs.alloc(N4 * 4));
-        HZ_HIP(b_scan7.alloc(scan_temp_elems(N4) * 4 + 16));
-        HZ_HIP(hipMemsetAsync((uint32_t *)b_nb.p + n4, 0, 4, st));
-        HZ_HIP(hipMemsetAsync((uint32_t *)b_lb.p + n4, 0, 4, st));
-        hipLaunchKernelGGL(k_tmp_counts, dim3((n4 + 255) / 256), dim3(256), 0, st, n4, (const NodeTmp *)b_tmp4.p,
-                           (uint32_t *)b_nb.p, (uint32_t *)b_lb.p);
-        int rc = exclusive_scan_u32((const uint32_t *)b_nb.p, (uint32_t *)b_nbs.p, N4, (uint32_t *)b_scan7.p, st);
-        if (rc) return rc;
-        rc = exclusive_scan_u32((const uint32_t *)b_lb.p, (uint32_t *)b_lbs.p, N4, (uint32_t *)b_scan7.p, st);
-        if (rc) return rc;
-    }
+    // exact sizes of the final arrays
+    HZ_HIP(b_sizes.alloc(16));
+    HZ_HIP(hipMemsetAsync(b_sizes.p, 0, 16, st));
+    hipLaunchKernelGGL(k_bfs_sizes, dim3((n4 + 255) / 256), dim3(256), 0, st, n4, (const NodeTmp *)b_tmp4.p,
+                       (unsigned int *)b_sizes.p);
     unsigned int sizes[2] = {0, 0};
-    HZ_HIP(hipMemcpyAsync(&sizes[0], (uint32_t *)b_nbs.p + n4, 4, hipMemcpyDeviceToHost, st));
-    HZ_HIP(hipMemcpyAsync(&sizes[1], (uint32_t *)b_lbs.p + n4, 4, hipMemcpyDeviceToHost, st));
+    HZ_HIP(hipMemcpyAsync(sizes, b_sizes.p, 8, hipMemcpyDeviceToHost, st));
     HZ_HIP(hipStreamSynchronize(st));
     const size_t n_node_blocks = (size_t)sizes[0] + 1;                 // + the root's own block
     const size_t n_leaf_blocks = sizes[1];
@@ -850,84 +774,59 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     // unused slots of partly filled blocks stay zero (never referenced: their boxes cannot be hit)
     HZ_HIP(hipMemsetAsync(blob + h.off_nodes, 0, h.total_bytes - h.off_nodes, st));
 
-    // ---- 8. numbering, level by level: breadth first at the top, depth-first regions below -------------------------
-    TempBuf b_fr[8], b_s0, b_s1, b_x0, b_x1, b_scan_tmp, b_parent, b_lparent;
-    // a level has at most n_nodes / 4 + 1 ... n_nodes entries; the widest is the last one
-    const size_t fcap = n_nodes + 4;
-    HZ_HIP(arena3.reserve(8 * Arena::pad(fcap * 4) + 4 * Arena::pad(fcap * 4) + Arena::pad(scan_temp_elems(fcap) * 4 + 16) +
-                          Arena::pad(n_nodes * 4) + Arena::pad((n_leaf_blocks ? n_leaf_blocks : 1) * 4) + 4096));
+    // ---- 8. breadth-first numbering, level by level ---------------------------------------------------------
+    TempBuf b_fr0, b_fr1, b_need_n, b_need_l, b_scan_n, b_scan_l, b_scan_tmp, b_parent, b_lparent;
+    HZ_HIP(arena3.reserve(7 * Arena::pad(n_nodes * 4) + Arena::pad(scan_temp_elems(n_nodes) * 4 + 16) +
+                          Arena::pad((n_leaf_blocks ? n_leaf_blocks : 1) * 4) + 4096));
     g_arena = &arena3;
-    for (int q = 0; q < 8; q++) HZ_HIP(b_fr[q].alloc(fcap * 4));
-    HZ_HIP(b_s0.alloc(fcap * 4)); HZ_HIP(b_s1.alloc(fcap * 4)); HZ_HIP(b_x0.alloc(fcap * 4)); HZ_HIP(b_x1.alloc(fcap * 4));
-    HZ_HIP(b_scan_tmp.alloc(scan_temp_elems(fcap) * 4 + 16));
+    HZ_HIP(b_fr0.alloc(n_nodes * 4)); HZ_HIP(b_fr1.alloc(n_nodes * 4));
+    HZ_HIP(b_need_n.alloc(n_nodes * 4)); HZ_HIP(b_need_l.alloc(n_nodes * 4));
+    HZ_HIP(b_scan_n.alloc(n_nodes * 4)); HZ_HIP(b_scan_l.alloc(n_nodes * 4));
+    HZ_HIP(b_scan_tmp.alloc(scan_temp_elems(n_nodes) * 4 + 16));
     HZ_HIP(b_parent.alloc(n_nodes * 4)); HZ_HIP(b_lparent.alloc((n_leaf_blocks ? n_leaf_blocks : 1) * 4));
     HZ_HIP(hipMemsetAsync(b_parent.p, 0xff, n_nodes * 4, st));       // -1: the root has no parent
-    Frontier fr[2];
-    for (int q = 0; q < 2; q++) {
-        fr[q].v = (int *)b_fr[4 * q].p; fr[q].self = (int *)b_fr[4 * q + 1].p;
-        fr[q].cha = (int *)b_fr[4 * q + 2].p; fr[q].lbb = (int *)b_fr[4 * q + 3].p;
-    }
+    int *fr[2] = {(int *)b_fr0.p, (int *)b_fr1.p};
     {
-        const int zero = 0;                                            // the root: temp node 0 in slot 0
-        HZ_HIP(hipMemcpyAsync(fr[0].v, &zero, 4, hipMemcpyHostToDevice, st));
-        HZ_HIP(hipMemcpyAsync(fr[0].self, &zero, 4, hipMemcpyHostToDevice, st));
+        const int first_frontier[4] = {0, -1, -1, -1};                 // block 0: the root and three unused slots
+        HZ_HIP(hipMemcpyAsync(fr[0], first_frontier, sizeof(first_frontier), hipMemcpyHostToDevice, st));
     }
-    int cur = 0, cnt = 1, levels = 0, n_top = 4;
-    size_t node_blocks_done = 1, leaf_blocks_done = 0;               // block 0 holds the root
-    bool regions_done = false;
-    auto last_of = [&](const uint32_t *scan, const uint32_t *val, int n, size_t *total) -> int {
-        uint32_t a2[2] = {0, 0};
-        HZ_HIP(hipMemcpyAsync(&a2[0], scan + (n - 1), 4, hipMemcpyDeviceToHost, st));
-        HZ_HIP(hipMemcpyAsync(&a2[1], val + (n - 1), 4, hipMemcpyDeviceToHost, st));
-        HZ_HIP(hipStreamSynchronize(st));
-        *total = (size_t)a2[0] + a2[1];
-        return HZ_OK;
-    };
+    int cur = 0, cnt = 4, level_start = 0, levels = 0;
+    size_t node_blocks_done = 1, leaf_blocks_done = 0;
     while (cnt > 0) {
-        if (levels >= HZ_MAX_STACK) return set_error(HZ_ERR_DEPTH, "BVH deeper than %d levels", HZ_MAX_STACK);
+        levels++;
+        if (levels > HZ_MAX_STACK) return set_error(HZ_ERR_DEPTH, "BVH deeper than %d levels", HZ_MAX_STACK);
         const int g = (cnt + 255) / 256;
-        int rc;
-        if (!regions_done) {
-            // blocks of this level's entries: one each while breadth first; at the switch level every entry gets the
-            // whole region of its subtree and the levels below address themselves
-            const bool sw = levels >= HZ_TOP_LEVELS;
-            if (sw) hipLaunchKernelGGL(k_region_sizes, dim3(g), dim3(256), 0, st, cnt, fr[cur], (const int2 *)b_trange.p,
-                                       (const uint32_t *)b_nbs.p, (const uint32_t *)b_lbs.p, (uint32_t *)b_s0.p, (uint32_t *)b_s1.p);
-            else hipLaunchKernelGGL(k_need, dim3(g), dim3(256), 0, st, cnt, fr[cur], (const NodeTmp *)b_tmp4.p,
-                                    (uint32_t *)b_s0.p, (uint32_t *)b_s1.p);
-            if ((rc = exclusive_scan_u32((const uint32_t *)b_s0.p, (uint32_t *)b_x0.p, (size_t)cnt, (uint32_t *)b_scan_tmp.p, st))) return rc;
-            if ((rc = exclusive_scan_u32((const uint32_t *)b_s1.p, (uint32_t *)b_x1.p, (size_t)cnt, (uint32_t *)b_scan_tmp.p, st))) return rc;
-            hipLaunchKernelGGL(k_assign_bfs, dim3(g), dim3(256), 0, st, cnt, fr[cur], (const uint32_t *)b_x0.p,
-                               (const uint32_t *)b_x1.p, (int)node_blocks_done, (int)leaf_blocks_done);
-            size_t nb = 0, lb = 0;
-            if ((rc = last_of((const uint32_t *)b_x0.p, (const uint32_t *)b_s0.p, cnt, &nb))) return rc;
-            if ((rc = last_of((const uint32_t *)b_x1.p, (const uint32_t *)b_s1.p, cnt, &lb))) return rc;
-            node_blocks_done += nb; leaf_blocks_done += lb;
-            if (sw) regions_done = true; else n_top = (int)(4 * node_blocks_done);
-            if (node_blocks_done > n_node_blocks || leaf_blocks_done > n_leaf_blocks)
-                return set_error(HZ_ERR_HIP, "BVH numbering ran past its arrays (internal error)");
-        }
-        hipLaunchKernelGGL(k_child_counts, dim3(g), dim3(256), 0, st, cnt, fr[cur], (const NodeTmp *)b_tmp4.p, (uint32_t *)b_s0.p);
-        if ((rc = exclusive_scan_u32((const uint32_t *)b_s0.p, (uint32_t *)b_x0.p, (size_t)cnt, (uint32_t *)b_scan_tmp.p, st))) return rc;
-        size_t next_cnt = 0;
-        if ((rc = last_of((const uint32_t *)b_x0.p, (const uint32_t *)b_s0.p, cnt, &next_cnt))) return rc;
-        if (next_cnt > fcap) return set_error(HZ_ERR_HIP, "BVH numbering: frontier overflow (internal error)");
-        EmitArgs e;
-        e.cur = fr[cur]; e.next = fr[cur ^ 1]; e.cnt = cnt; e.child_off = (const uint32_t *)b_x0.p;
-        e.tmp = (const NodeTmp *)b_tmp4.p; e.trange = (const int2 *)b_trange.p;
-        e.nb_scan = (const uint32_t *)b_nbs.p; e.lb_scan = (const uint32_t *)b_lbs.p;
-        e.depth_first = regions_done ? 1 : 0;
+        hipLaunchKernelGGL(k_bfs_need, dim3(g), dim3(256), 0, st, cnt, (const int *)fr[cur], (const NodeTmp *)b_tmp4.p,
+                           (uint32_t *)b_need_n.p, (uint32_t *)b_need_l.p);
+        int rc = exclusive_scan_u32((const uint32_t *)b_need_n.p, (uint32_t *)b_scan_n.p, (size_t)cnt, (uint32_t *)b_scan_tmp.p, st);
+        if (rc) return rc;
+        rc = exclusive_scan_u32((const uint32_t *)b_need_l.p, (uint32_t *)b_scan_l.p, (size_t)cnt, (uint32_t *)b_scan_tmp.p, st);
+        if (rc) return rc;
+        uint32_t last[4] = {0, 0, 0, 0};                               // scan and need of the last entry, both kinds
+        HZ_HIP(hipMemcpyAsync(&last[0], (uint32_t *)b_scan_n.p + (cnt - 1), 4, hipMemcpyDeviceToHost, st));
+        HZ_HIP(hipMemcpyAsync(&last[1], (uint32_t *)b_need_n.p + (cnt - 1), 4, hipMemcpyDeviceToHost, st));
+        HZ_HIP(hipMemcpyAsync(&last[2], (uint32_t *)b_scan_l.p + (cnt - 1), 4, hipMemcpyDeviceToHost, st));
+        HZ_HIP(hipMemcpyAsync(&last[3], (uint32_t *)b_need_l.p + (cnt - 1), 4, hipMemcpyDeviceToHost, st));
+        HZ_HIP(hipStreamSynchronize(st));
+        const size_t nb = (size_t)last[0] + last[1], lb = (size_t)last[2] + last[3];
+        if (node_blocks_done + nb > n_node_blocks || leaf_blocks_done + lb > n_leaf_blocks)
+            return set_error(HZ_ERR_HIP, "BVH numbering ran past its arrays (internal error)");
+        BfsEmit e;
+        e.frontier = fr[cur]; e.cnt = cnt; e.level_start = level_start;
+        e.tmp = (const NodeTmp *)b_tmp4.p;
+        e.scan_node = (const uint32_t *)b_scan_n.p; e.scan_leaf = (const uint32_t *)b_scan_l.p;
+        e.node_blocks_before = (int)node_blocks_done; e.leaf_blocks_before = (int)leaf_blocks_done;
+        e.next_frontier = fr[cur ^ 1];
         e.nodes = d_nodes; e.prims = d_prims; e.parent = (int *)b_parent.p; e.leaf_parent = (int *)b_lparent.p;
         e.vals = vals;
-        hipLaunchKernelGGL(k_emit_level, dim3(g), dim3(256), 0, st, e, bp);
-        levels++;
-        cnt = (int)next_cnt;
+        hipLaunchKernelGGL(k_bfs_emit, dim3(g), dim3(256), 0, st, e, bp);
+        level_start = (int)(4 * node_blocks_done);
+        node_blocks_done += nb; leaf_blocks_done += lb;
+        cnt = (int)(4 * nb);
         cur ^= 1;
     }
-    if (!regions_done && (node_blocks_done != n_node_blocks || leaf_blocks_done != n_leaf_blocks))
+    if (node_blocks_done != n_node_blocks || leaf_blocks_done != n_leaf_blocks)
         return set_error(HZ_ERR_HIP, "BVH numbering did not fill its arrays (internal error)");
-    if (regions_done && (node_blocks_done != n_node_blocks || leaf_blocks_done != n_leaf_blocks))
-        return set_error(HZ_ERR_HIP, "BVH numbering: region sizes do not add up (internal error)");
     // ---- hit-cache ancestors (from the final numbering) ------------------------------------------------------
     if (n_leaf_blocks)
         hipLaunchKernelGGL(k_anc_bfs, dim3((unsigned)((n_leaf_blocks + 255) / 256)), dim3(256), 0, st, (int)n_leaf_blocks,
@@ -936,7 +835,7 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     HZ_HIP(hipGetLastError());
     // height = node levels of the numbering (wrapper levels included): the traversal stack holds one entry per level
     const int height = levels;
-    n_top = (int)std::min<size_t>((size_t)n_top, std::min<size_t>(n_nodes, HZ_MAX_TOP_NODES));   // breadth-first numbered slots
+    const int n_top = (int)std::min<size_t>(n_nodes, HZ_MAX_TOP_NODES);
     h.height = height;
     h.n_top = n_top;
     HZ_HIP(hipMemcpyAsync(blob, &h, sizeof(h), hipMemcpyHostToDevice, st));
