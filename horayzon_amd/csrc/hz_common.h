@@ -50,8 +50,10 @@ struct BlobHeader {
 static_assert(sizeof(BlobHeader) == 256, "BlobHeader must be 256 bytes");
 
 // traversal links: >= 0 node index; < 0 leaf, record index = link & 0x7fffffff (sign + magnitude, so that child k of
-// a block is `first + k` for both kinds); HZ_EMPTY: nothing
-#define HZ_EMPTY ((int)0xffffffff)
+// a block is `first + k` for both kinds); HZ_EMPTY: nothing (the largest positive value: "is a node" is one unsigned
+// compare, "is a leaf" a sign test)
+#define HZ_EMPTY ((int)0x7fffffff)
+#define HZ_IS_NODE(link) ((unsigned)(link) < 0x7fffffffu)
 #define HZ_LEAF_BIT 0x80000000u
 #define HZ_LEAF_ID(link) ((int)((unsigned)(link) & 0x7fffffffu))
 struct __attribute__((aligned(64))) Node {
@@ -375,11 +377,12 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
 #define HZ_SAVE() do { t.node = node; t.sp = sp; t.pf = pf; t.pm = pm; t.lq0 = lq0; t.lq1 = lq1; } while (0)
     int res = -1;                 // single exit: lanes leave the loop through `res`, state is saved once
     while (res < 0) {
-        // set leaves aside while the leaf queue (QLEN entries, filled front to back) has room
-        if (node < 0 && node != HZ_EMPTY && lq0 == HZ_EMPTY) { lq0 = node; HZ_POP(); }
-        if (node < 0 && node != HZ_EMPTY && lq1 == HZ_EMPTY) { lq1 = node; HZ_POP(); }
-        const bool can_node = node >= 0;
-        const bool can_leaf = lq0 != HZ_EMPTY;
+        // set leaves aside while the leaf queue (QLEN entries, filled front to back; a queued leaf is negative, an empty
+        // place HZ_EMPTY) has room
+        if (node < 0 && lq0 >= 0) { lq0 = node; HZ_POP(); }
+        if (node < 0 && lq1 >= 0) { lq1 = node; HZ_POP(); }
+        const bool can_node = HZ_IS_NODE(node);
+        const bool can_leaf = lq0 < 0;
         // votes taken before any lane leaves: a lane that is finished contributes to neither mask, so the
         // masks equal those of the lanes that stay (and stay plain scalar compares)
         const unsigned long long m_node = __ballot(can_node), m_leaf = __ballot(can_leaf);
@@ -409,17 +412,11 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
                 h |= hz_qbox_hit(nr, rb, tfar, n1.y, n2.y) ? 2 : 0;
                 h |= hz_qbox_hit(nr, rb, tfar, n1.z, n2.z) ? 4 : 0;
                 h |= hz_qbox_hit(nr, rb, tfar, n1.w, n2.w) ? 8 : 0;
-                if (h != 0) {
-                    const int first = __float_as_int(n0.w);
-                    const int rest = h & (h - 1);
-                    if (rest != 0) {             // siblings to come back to: they become the pending set of this level
-                        if (pm != 0) { stack[sp * TPB + tid] = hz_entry_pack(pf, pm); sp++; }
-                        pf = first; pm = rest;
-                    }
-                    node = first + __builtin_ctz((unsigned)h);
-                } else {
-                    HZ_POP();
+                if (h != 0) {                    // the hit children become the pending set of this level ...
+                    if (pm != 0) { stack[sp * TPB + tid] = hz_entry_pack(pf, pm); sp++; }
+                    pf = __float_as_int(n0.w); pm = h;
                 }
+                HZ_POP();                        // ... and the first of them (or of a level above) is entered
             }
         } else {
             // ---------------- leaf step: the two triangles of a DEM quad (or one TIN triangle) ---
