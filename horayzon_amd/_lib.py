@@ -26,7 +26,7 @@ class hz_opts(C.Structure):
                 ("count_work", C.c_int32), ("no_hit_cache", C.c_int32),
                 ("svf", C.c_void_p), ("vec_tilt", C.c_void_p),
                 ("skip_hori", C.c_int32), ("chunk_rows", C.c_int32),
-                ("reserved0", C.c_int32), ("hori_is_slab", C.c_int32),
+                ("level_stack", C.c_int32), ("hori_is_slab", C.c_int32),
                 ("no_near_skip", C.c_int32), ("verify_near", C.c_int32)]
 
 
@@ -39,7 +39,7 @@ class hz_stats(C.Structure):
                 ("bvh_height", C.c_int32), ("elev_num", C.c_int32),
                 ("scene_bytes", C.c_uint64), ("wave_node_iters", C.c_uint64),
                 ("wave_leaf_iters", C.c_uint64), ("wave_refills", C.c_uint64),
-                ("t_svf_s", C.c_double),
+                ("t_svf_s", C.c_double), ("stack_fallbacks", C.c_uint64),
                 ("rays_shortened", C.c_uint64), ("near_violations", C.c_uint64), ("t_near_s", C.c_double)]
 
     def as_dict(self):

@@ -347,6 +347,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
 
     unsigned long long cnt[16] = {0};
     float ms = 0.0f, ms_svf = 0.0f;
+    int fallbacks = 0;
 
     // HIP events on the kernels' stream: horizon kernel and SVF kernel are timed separately
     struct Ev { hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr; };
@@ -430,8 +431,28 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
                 return fail(set_error(HZ_ERR_HIP, "counter reset failed"));
             // the buffer of chunk n is the one chunk n - 2 was copied out of
             if (stream_out && n_chunk >= 2) (void)hipStreamWaitEvent(st, evs[ev_of[(size_t)n_chunk - 2]].d, 0);
+            a.level_stack = (sc->level_stack.load(std::memory_order_relaxed) != 0 || (opts && opts->level_stack > 0)) ? 1
+                            : ((opts && opts->level_stack < 0) ? opts->level_stack : 0);
             (void)hipEventRecord(e.a, st);
-            rc = horizon_launch(sc, a, st);
+            int safe = 0;
+            rc = horizon_launch(sc, a, st, &safe);
+            if (!rc && !safe) {
+                // fast stack discipline: did a wave run out of entries?  Then its results are not trusted: the same
+                // rows again with the one-entry-per-level kernel, which the scene keeps from now on
+                unsigned long long ov = 0;
+                if (hipMemcpyAsync(&ov, (unsigned long long *)cnt_dev + 8, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess)
+                    return fail(set_error(HZ_ERR_HIP, "horizon kernel failed: %s", hipGetErrorString(hipGetLastError())));
+                if (ov != 0) {
+                    sc->level_stack.store(1, std::memory_order_relaxed);
+                    fallbacks++;
+                    a.level_stack = 1;
+                    if (hipMemcpyAsync(cnt_dev, zeros, sizeof(zeros), hipMemcpyHostToDevice, st) != hipSuccess)
+                        return fail(set_error(HZ_ERR_HIP, "counter reset failed"));
+                    (void)hipEventRecord(e.a, st);
+                    rc = horizon_launch(sc, a, st, &safe);
+                }
+            }
             (void)hipEventRecord(e.b, st);
             if (!rc && want_svf)
                 rc = svf_launch(d_azim.dev, hori_chunk, d_tilt.dev + 3 * (size_t)rb * dim_in_1, re - rb, dim_in_1,
@@ -472,6 +493,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         stats->t_d2h_s += d2h_s;
         stats->t_total_s += t_total.stop();
         stats->elev_num = tb.elev_num; stats->bvh_height = sc->hdr.height; stats->scene_bytes = sc->hdr.total_bytes;
+        stats->stack_fallbacks += (uint64_t)fallbacks;
         stats->rays_shortened += cnt[9]; stats->near_violations += cnt[10]; stats->t_near_s += (double)ms_near * 1e-3;
     }
     if (opts && opts->verbose) {   // the reference's report, horizon_comp.cpp:673-700, 805-810 (same lines, same order)

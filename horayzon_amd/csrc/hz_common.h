@@ -360,20 +360,35 @@ __device__ __forceinline__ void hz_entry_unpack(int e, int &pf, int &pm) {
 
 #define HZ_WAVE_TICK(c, lane_) do { const unsigned long long m_ = __ballot(1); if ((lane_) == __ffsll((long long)m_) - 1) (c)++; } while (0)
 
-template <int TPB, bool COUNT, int QLEN = 2, bool NODELET = false>
+// Two stack disciplines (LEVELSTACK), same results:
+//   false: every pending sibling is its own LDS entry (up to 3 per level).  Cheapest in VALU instructions -- the kernel
+//          is VALU-issue bound -- but its worst case is 3 x height entries, more LDS than five resident workgroups per
+//          CU can have; the stack gets `stack_cap` entries (rays need far fewer in practice), a node step that would
+//          not find 3 free entries drops the excess instead of writing out of bounds and raises `overflow`, and the
+//          host repeats that launch with the other discipline.
+//   true:  one entry per level as described above: `height` entries, no overflow case (+10 % VALU instructions on
+//          the 3601^2 tile).
+template <int TPB, bool COUNT, int QLEN = 2, bool NODELET = false, bool LEVELSTACK = true>
 __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Prim *__restrict__ prims,
                                         const float4 *top, int ntop, int *stack, int tid,
                                         float ox, float oy, float oz, float dx, float dy, float dz, float tfar,
                                         const RayBox &rb, TravState &t, int regroup, int leaf_bias,
-                                        TravCounters &cnt) {
+                                        TravCounters &cnt, int stack_cap, unsigned &overflow) {
     const int lane = tid & 63;
     int node = t.node, sp = t.sp, pf = t.pf, pm = t.pm, lq0 = t.lq0, lq1 = t.lq1;
     const int n_entry = __popcll(__ballot(1));   // lanes that entered with a ray
-// next link: a pending sibling of the current level, else of the closest level above that has one (LDS), else nothing
-#define HZ_POP() do { if (pm == 0) { const bool ne = sp > 0; sp = ne ? sp - 1 : 0; const int pv = stack[sp * TPB + tid]; \
-                          hz_entry_unpack(ne ? pv : 0, pf, pm); } \
-                      const int slot_ = __builtin_ctz((unsigned)pm | 16u); \
-                      node = (pm != 0) ? pf + slot_ : HZ_EMPTY; pm &= pm - 1; } while (0)
+// next link.  LEVELSTACK: a pending sibling of the current level, else of the closest level above that has one (LDS);
+// else: the top LDS entry (branch-free: read the clamped top, keep it only if the stack was not empty)
+#define HZ_POP() do { \
+        if (LEVELSTACK) { \
+            if (pm == 0) { const bool ne = sp > 0; sp = ne ? sp - 1 : 0; const int pv = stack[sp * TPB + tid]; \
+                           hz_entry_unpack(ne ? pv : 0, pf, pm); } \
+            const int slot_ = __builtin_ctz((unsigned)pm | 16u); \
+            node = (pm != 0) ? pf + slot_ : HZ_EMPTY; pm &= pm - 1; \
+        } else { \
+            const bool ne = sp > 0; sp = ne ? sp - 1 : 0; const int pv = stack[sp * TPB + tid]; \
+            node = ne ? pv : HZ_EMPTY; \
+        } } while (0)
 #define HZ_SAVE() do { t.node = node; t.sp = sp; t.pf = pf; t.pm = pm; t.lq0 = lq0; t.lq1 = lq1; } while (0)
     int res = -1;                 // single exit: lanes leave the loop through `res`, state is saved once
     while (res < 0) {
@@ -408,15 +423,27 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
                 // signs, ~45 VALU per step) was measured to be a net loss: these are any-hit rays, a blocked ray
                 // is blocked over a long stretch behind the first ridge, and near-horizon rays that only
                 // nick a crest are served by the hit cache.
-                int h = hz_qbox_hit(nr, rb, tfar, n1.x, n2.x) ? 1 : 0;
-                h |= hz_qbox_hit(nr, rb, tfar, n1.y, n2.y) ? 2 : 0;
-                h |= hz_qbox_hit(nr, rb, tfar, n1.z, n2.z) ? 4 : 0;
-                h |= hz_qbox_hit(nr, rb, tfar, n1.w, n2.w) ? 8 : 0;
-                if (h != 0) {                    // the hit children become the pending set of this level ...
-                    if (pm != 0) { stack[sp * TPB + tid] = hz_entry_pack(pf, pm); sp++; }
-                    pf = __float_as_int(n0.w); pm = h;
+                const bool h0 = hz_qbox_hit(nr, rb, tfar, n1.x, n2.x), h1 = hz_qbox_hit(nr, rb, tfar, n1.y, n2.y);
+                const bool h2 = hz_qbox_hit(nr, rb, tfar, n1.z, n2.z), h3 = hz_qbox_hit(nr, rb, tfar, n1.w, n2.w);
+                const int first = __float_as_int(n0.w);
+                if (LEVELSTACK) {
+                    const int h = (h0 ? 1 : 0) | (h1 ? 2 : 0) | (h2 ? 4 : 0) | (h3 ? 8 : 0);
+                    if (h != 0) {                    // the hit children become the pending set of this level ...
+                        if (pm != 0) { stack[sp * TPB + tid] = hz_entry_pack(pf, pm); sp++; }
+                        pf = first; pm = h;
+                    }
+                    HZ_POP();                        // ... and the first of them (or of a level above) is entered
+                } else {
+                    if (sp > stack_cap - 3) { overflow = 1u; sp = stack_cap - 3; }
+                    int next = HZ_EMPTY;
+                    // branch-free pushes: the candidate is always stored at the stack top and only kept (sp advanced)
+                    // when it was a real link
+                    if (h3) next = first + 3;
+                    if (h2) { stack[sp * TPB + tid] = next; sp += (next != HZ_EMPTY) ? 1 : 0; next = first + 2; }
+                    if (h1) { stack[sp * TPB + tid] = next; sp += (next != HZ_EMPTY) ? 1 : 0; next = first + 1; }
+                    if (h0) { stack[sp * TPB + tid] = next; sp += (next != HZ_EMPTY) ? 1 : 0; next = first; }
+                    if (next != HZ_EMPTY) node = next; else HZ_POP();
                 }
-                HZ_POP();                        // ... and the first of them (or of a level above) is entered
             }
         } else {
             // ---------------- leaf step: the two triangles of a DEM quad (or one TIN triangle) ---

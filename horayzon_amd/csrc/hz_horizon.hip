@@ -43,7 +43,7 @@ struct HorizonParams {
     int row_begin, row_end;
     TileMap tm;                    // tile grid of the slab -> workgroups (XCD aware)
     float dist, hori_fill, ray_org_elev;
-    int top_nodes, regroup, stack_bytes, leaf_bias, stage_bytes, hit_cache;
+    int top_nodes, regroup, stack_bytes, leaf_bias, stage_bytes, hit_cache, stack_cap;
     const unsigned short *near_idx;   // near-field certificates of this launch's rows (hz_near.hip) or null
     const float *near_r;
     int verify_near;
@@ -51,7 +51,9 @@ struct HorizonParams {
 };
 
 // LDS: [ per-lane stacks int[depth][256] | output staging float[4][256] | top-of-tree nodelet Node[top_nodes] ]
-template <int ALG, bool COUNT, bool STAGE, bool NODELET>
+// LEVELSTACK: the traversal's stack discipline (hz_common.h).  false = one LDS entry per pending sibling: fewest VALU
+// instructions, `stack_cap` entries, overflow flagged in counters[8]; true = one entry per tree level, cannot overflow.
+template <int ALG, bool COUNT, bool STAGE, bool NODELET, bool LEVELSTACK>
 __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *stack = reinterpret_cast<int *>(smem);
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
     TravState ts; hz_trav_reset(ts);
     int cache = 0;           // hit cache: subtree above the leaf that blocked this cell's last blocked ray
     bool second = false;     // the cache walk found nothing: the root traversal is still due
+    unsigned overflow = 0;   // !LEVELSTACK: a ray needed more stack entries than this launch has (see hz_trace)
     // near-field certificate of this cell (hz_near.hip): rays of azimuth k with a table index >= near_idx[k] clear
     // everything within near_r of the origin and start their box tests at parameter near_r
     unsigned shortened = 0, violations = 0;        // COUNT only
@@ -165,8 +168,8 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
         }
         // ---- traversal (hz_common.h: speculative while-while, one postponed leaf per lane) ------
         if (ray_active) {
-            const int r = hz_trace<HZ_TPB, COUNT, HZ_QLEN, NODELET>(p.sv.nodes, p.sv.prims, top, ntop, stack, tid, ox, oy, oz,
-                                                 dx, dy, dz, tfar, rb, ts, p.regroup, p.leaf_bias, tc);
+            const int r = hz_trace<HZ_TPB, COUNT, HZ_QLEN, NODELET, LEVELSTACK>(p.sv.nodes, p.sv.prims, top, ntop, stack, tid, ox, oy, oz,
+                                                 dx, dy, dz, tfar, rb, ts, p.regroup, p.leaf_bias, tc, p.stack_cap, overflow);
             if (r == 0 && second) {                      // nothing in the cached subtree: full traversal
                 second = false; hz_trav_reset(ts);
             } else if (COUNT && p.verify_near && r != 2 && tn > 0.0f && !verifying) {
@@ -192,7 +195,9 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
             wn += __shfl_xor(wn, off); wl += __shfl_xor(wl, off); wa += __shfl_xor(wa, off);
         }
     }
+    const bool any_overflow = !LEVELSTACK && __ballot(overflow != 0u) != 0ull;
     if (lane == 0) {
+        if (any_overflow) atomicAdd(&p.counters[8], 1ull);
         if (r) atomicAdd(&p.counters[0], r);
         if (g) atomicAdd(&p.counters[1], g);
         if (cc) atomicAdd(&p.counters[4], cc);
@@ -208,26 +213,30 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
     }
 }
 
-template <int ALG, bool COUNT, bool STAGE, bool NODELET = false>
+template <int ALG, bool COUNT, bool STAGE, bool NODELET, bool LEVELSTACK>
 static int launch_one(const HorizonParams &p, int grid, size_t lds, hipStream_t st) {
-    HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_horizon<ALG, COUNT, STAGE, NODELET>),
+    HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_horizon<ALG, COUNT, STAGE, NODELET, LEVELSTACK>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_horizon<ALG, COUNT, STAGE, NODELET>), dim3(grid), dim3(HZ_TPB), lds, st, p);
+    hipLaunchKernelGGL((k_horizon<ALG, COUNT, STAGE, NODELET, LEVELSTACK>), dim3(grid), dim3(HZ_TPB), lds, st, p);
     HZ_HIP(hipGetLastError());
     return HZ_OK;
 }
 
 template <int ALG>
-static int launch_alg(const HorizonParams &p, int grid, size_t lds, bool count, hipStream_t st) {
+static int launch_alg(const HorizonParams &p, int grid, size_t lds, bool count, bool level_stack, hipStream_t st) {
     const bool stage = p.stage_bytes != 0;
     if (ALG == ALG_GUESS && !count && p.top_nodes > 0)      // opt-in LDS nodelet variant (opts.top_nodes > 0)
-        return stage ? launch_one<ALG_GUESS, false, true, true>(p, grid, lds, st)
-                     : launch_one<ALG_GUESS, false, false, true>(p, grid, lds, st);
-    if (count) return stage ? launch_one<ALG, true, true>(p, grid, lds, st) : launch_one<ALG, true, false>(p, grid, lds, st);
-    return stage ? launch_one<ALG, false, true>(p, grid, lds, st) : launch_one<ALG, false, false>(p, grid, lds, st);
+        return stage ? launch_one<ALG_GUESS, false, true, true, true>(p, grid, lds, st)
+                     : launch_one<ALG_GUESS, false, false, true, true>(p, grid, lds, st);
+    if (level_stack) {
+        if (count) return stage ? launch_one<ALG, true, true, false, true>(p, grid, lds, st) : launch_one<ALG, true, false, false, true>(p, grid, lds, st);
+        return stage ? launch_one<ALG, false, true, false, true>(p, grid, lds, st) : launch_one<ALG, false, false, false, true>(p, grid, lds, st);
+    }
+    if (count) return stage ? launch_one<ALG, true, true, false, false>(p, grid, lds, st) : launch_one<ALG, true, false, false, false>(p, grid, lds, st);
+    return stage ? launch_one<ALG, false, true, false, false>(p, grid, lds, st) : launch_one<ALG, false, false, false, false>(p, grid, lds, st);
 }
 
-int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
+int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *used_level_stack) {
     HorizonParams p;
     p.sv = scene_view(sc);
     p.tb.azim_sin = a.azim_sin; p.tb.azim_cos = a.azim_cos;
@@ -244,11 +253,20 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
     const int tiles_i = (rows + 15) / 16;
     p.tm = make_tile_map(tiles_i, (a.dim_in_1 + 15) / 16);
     p.dist = a.dist; p.hori_fill = a.hori_fill; p.ray_org_elev = a.ray_org_elev;
-    // stack: one entry per tree level (siblings are contiguous: an entry is a block + the mask of children still to
-    // visit, hz_common.h), so `height` entries can never overflow: 12 KB per workgroup for the 3601^2 tile, 14 KB for
-    // the 14401^2 mosaic -- the kernel's 96 VGPRs (5 workgroups per CU), not LDS, bound the residency
+    // stack.  The fast discipline keeps every pending sibling as its own LDS entry (fewest VALU instructions in a
+    // VALU-issue-bound kernel) and gets the entries that still allow 5 workgroups per CU next to the 4 KB output
+    // staging: 27 (measured: <= 31 KiB of LDS per workgroup -> 5 resident, 32 KiB -> 4); rays of the 3601^2 tile use
+    // <= 20.  Its worst case (3 per level) does not fit, so an overflowing wave raises counters[8] and horizon_run
+    // repeats that launch with the one-entry-per-level discipline (`height` entries, cannot overflow, +10 % VALU) and
+    // keeps it for the scene.  Shallow trees whose worst case fits never need the second kernel.
     const int stage = ((a.azim_num & 3) == 0 && (reinterpret_cast<size_t>(a.hori) & 15) == 0) ? 4 * HZ_TPB * 4 : 0;
-    const int depth = std::max(sc->hdr.height, 1);
+    const int height = std::max(sc->hdr.height, 1);
+    // (a.level_stack < 0: test hook, the fast discipline with that many entries)
+    const int fast_cap = a.level_stack < 0 ? std::max(-a.level_stack, 3) : std::max((31 * 1024 - stage) / (HZ_TPB * 4), 3);
+    const bool level_stack = a.level_stack > 0 || (a.top_nodes > 0 && a.alg == ALG_GUESS && !a.count_work);
+    const int depth = level_stack ? height : std::min(fast_cap, 3 * height);
+    if (used_level_stack) *used_level_stack = (level_stack || depth >= 3 * height) ? 1 : 0;   // 1: cannot overflow
+    p.stack_cap = depth;
     p.stack_bytes = depth * HZ_TPB * 4;
     // output staging (4 azimuths per lane) when the 16 B stores are aligned: azim_num % 4 == 0
     p.stage_bytes = stage;
@@ -269,9 +287,9 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st) {
     const int grid = p.tm.per_xcd * 8;
     const bool count = a.count_work != 0;
     switch (a.alg) {
-        case ALG_DISCRETE: return launch_alg<ALG_DISCRETE>(p, grid, lds, count, st);
-        case ALG_BINARY: return launch_alg<ALG_BINARY>(p, grid, lds, count, st);
-        default: return launch_alg<ALG_GUESS>(p, grid, lds, count, st);
+        case ALG_DISCRETE: return launch_alg<ALG_DISCRETE>(p, grid, lds, count, level_stack, st);
+        case ALG_BINARY: return launch_alg<ALG_BINARY>(p, grid, lds, count, level_stack, st);
+        default: return launch_alg<ALG_GUESS>(p, grid, lds, count, level_stack, st);
     }
 }
 

@@ -42,6 +42,8 @@ struct Scene {
     void *blob = nullptr;
     size_t blob_bytes = 0;
     bool owns_blob = false;
+    // 1 once a launch with the fast stack discipline overflowed: later launches use the one-entry-per-level kernel
+    mutable std::atomic<int> level_stack{0};
     // scratch of the near-field certificates, grown on demand and kept with the scene (hz_api.hip); a scene is
     // used by one call at a time per stream, like its stream
     mutable void *near_buf = nullptr;
@@ -111,14 +113,15 @@ struct HorizonArgs {
     const float *azim_sin, *azim_cos, *elev_ang, *elev_sin, *elev_cos;  // device tables
     const int *mid_idx;
     int top_nodes, regroup, count_work, hit_cache;
+    int level_stack;                     // 1: one-entry-per-level traversal stack (cannot overflow); 0: fast discipline
     const unsigned short *near_idx;      // near-field certificates of rows [row_begin, row_end) (hz_near.hip) or null
     const float *near_r;
     int verify_near;                     // counting instantiation: re-trace every shortened ray from parameter 0
     unsigned long long *counters;        // device u64[16]: [0] rays, [1] guards, [2] nodes, [3] tris, [4] cells,
-                                         // [5..7] wave iterations,
+                                         // [5..7] wave iterations, [8] waves whose fast-discipline stack overflowed,
                                          // [9] rays shortened by a certificate, [10] certificate violations (verify)
 };
-int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st);
+int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *used_level_stack = nullptr);
 int topo_launch(int kind, const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
                 int len_2, float *out, hipStream_t st);
 int svf_launch(const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,

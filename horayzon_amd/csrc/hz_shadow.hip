@@ -64,8 +64,9 @@ __device__ __forceinline__ bool occluded(const SceneView &sv, int *stack, int ti
     const RayBox rb = hz_raybox(ox - sv.cx, oy - sv.cy, oz - sv.cz, dx, dy, dz);
     TravState ts; hz_trav_reset(ts);
     TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.w_nodes = 0; tc.w_leaves = 0;
+    unsigned overflow = 0;      // unused: the one-entry-per-level stack cannot overflow
     return hz_trace<HZ_TPB, false>(sv.nodes, sv.prims, nullptr, 0, stack, tid, ox, oy, oz, dx, dy, dz, tfar, rb,
-                                   ts, 0, HZ_SHADOW_LEAF_BIAS, tc) == 1;
+                                   ts, 0, HZ_SHADOW_LEAF_BIAS, tc, 0, overflow) == 1;
 }
 
 __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {

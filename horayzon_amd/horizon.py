@@ -35,7 +35,7 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
                     num_tri_simp=1, elev_ang_low_lim=-15.0, mask=None,
                     hori_fill=0.0, ray_org_elev=0.01, *, device=0, verbose=False,
                     scene=None, svf_vec_tilt=None, svf_only=False, rows=None, count_work=False, devices=None,
-                    _top_nodes=-1, _regroup=-1, _hit_cache=True, _chunk_rows=0, _near_skip=True,
+                    _top_nodes=-1, _regroup=-1, _hit_cache=True, _chunk_rows=0, _near_skip=True, _level_stack=False,
                     _verify_near=False):
     """Horizon computation for gridded domain.
 
@@ -139,6 +139,7 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
     opts.no_hit_cache = 0 if _hit_cache else 1
     opts.chunk_rows = _chunk_rows
     opts.no_near_skip = 0 if _near_skip else 1
+    opts.level_stack = int(_level_stack)      # True / 1: level stack from the start; -n: fast stack of n entries (tests)
     opts.verify_near = int(bool(_verify_near))
     opts.skip_hori = 1 if svf_only else 0
     opts.count_work = int(bool(count_work))

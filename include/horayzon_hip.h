@@ -55,7 +55,9 @@ typedef struct hz_opts {
     int32_t chunk_rows;    /* rows per launch when hori is host memory or skipped (chunks are      */
                            /*   double buffered and copied out while the next one is traced);      */
                            /*   <= 0: as many rows as fit 4 GiB                                     */
-    int32_t reserved0;     /* (was stack_entries: the traversal stack now holds one entry per tree level and cannot overflow) */
+    int32_t level_stack;   /* 1: use the one-entry-per-tree-level traversal stack from the start (cannot overflow, +10 % */
+                           /*   VALU); 0: the fast discipline first, the other one only for launches whose stack overflowed; */
+                           /*   < 0 (tests): the fast discipline with -level_stack entries                                 */
     int32_t hori_is_slab;  /* 0: hori_buffer (and svf) address inner-domain row 0 (reference layout, [dim_in_0][..]); */
                            /*   1: they address row_begin, i.e. hold only the slab [row_end - row_begin][dim_in_1].. */
                            /*   -- the form for resident HBM slab buffers (the caller never forms an address        */
@@ -87,6 +89,7 @@ typedef struct hz_stats {
     uint64_t wave_leaf_iters; /*   step / leaf step / ray refill section (SIMT  */
     uint64_t wave_refills;    /*   efficiency = lane count / (64 x wave count)) */
     double t_svf_s;        /* sky-view-factor kernel (when opts.svf is set)    */
+    uint64_t stack_fallbacks; /* launches repeated with the one-entry-per-level stack (fast stack overflowed)            */
     uint64_t rays_shortened;  /* count_work: rays that started beyond the cell's neighbourhood (near-field certificate) */
     uint64_t near_violations; /* count_work + verify_near: shortened rays whose full-length re-trace disagreed (0)      */
     double t_near_s;       /* certificate pre-pass (hz_near.hip)                */

@@ -31,13 +31,13 @@ json.dump(out, open("profiles/%s/pmc_fetch_write_summary.json" % rnd, "w"), inde
 k = [x for x in out["FETCH_SIZE"] if KERNEL in x][0]
 f, w = out["FETCH_SIZE"][k]["mean_KiB"], out["WRITE_SIZE"][k]["mean_KiB"]
 cal_r = out["FETCH_SIZE"]["hz::k_bounds"]["mean_KiB"] * 1024 / (12 * 3601 * 3601)
-cal_w = out["WRITE_SIZE"]["hz::k_emit_prims"]["mean_KiB"] * 1024 / (48 * 3600 * 3600)
+cal_w = out["WRITE_SIZE"]["hz::k_morton"]["mean_KiB"] * 1024 / (8 * 3600 * 3600)     # key + primitive id per quad
 b = json.loads(open("gpurun_out/%s_kt_bench.json" % pre).read().strip().splitlines()[-1])
 t = {"tile": 3601, "azim": 360, "rows_per_step": 512, "kernel_source_sha": sha,
      "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024, "fetch_bytes": 2 * f * 1024, "write_bytes": w * 1024,
      "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (profiles/%s/pmc_fetch_write_summary.json), mean "
              "over the launches of 2 steps; KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2); calibration "
-             "on this run: k_bounds read ratio %.3f, k_emit_prims write ratio %.3f; kernel %s" % (rnd, cal_r, cal_w, k)}
+             "on this run: k_bounds read ratio %.3f, k_morton write ratio %.3f; kernel %s" % (rnd, cal_r, cal_w, k)}
 json.dump(t, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps(t))
 # ---- VALU model: scale the per-iteration constants so that they reproduce SQ_INSTS_VALU ------------------------

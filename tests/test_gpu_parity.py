@@ -266,6 +266,21 @@ def test_traversal_stack_is_one_entry_per_level(hip, orc):
     assert 7 <= sc.stats["bvh_height"] <= 10                  # ~ log4(140 x 150 quads) + 1
     h, _ = hip.horizon.horizon_gridded(**kw, **par, scene=sc)
     assert np.array_equal(h, ref) and hip.horizon.last_stats["num_rays"] == so["rays"]
+    # The default launch uses the fast discipline (one LDS entry per pending sibling, fewest instructions) with the
+    # entries that fit; a wave that runs out is detected and that launch repeated with the level stack.  Forced here
+    # with tiny fast stacks; `_level_stack=True` uses the level stack from the start.
+    seen = set()
+    for cap in (0, -3, -4, -7, -30, 1):
+        h2, _ = hip.horizon.horizon_gridded(**kw, **par, _level_stack=cap)
+        st = dict(hip.horizon.last_stats)
+        assert np.array_equal(h2, ref) and st["num_rays"] == so["rays"], cap
+        seen.add((cap, st["stack_fallbacks"]))
+    assert (0, 0) in seen and (-3, 1) in seen and (-30, 0) in seen and (1, 0) in seen
+    # ... and a scene remembers: after one overflow its launches go straight to the level stack
+    hip.horizon.horizon_gridded(**kw, **par, scene=sc, _level_stack=-3)
+    assert hip.horizon.last_stats["stack_fallbacks"] == 1
+    hip.horizon.horizon_gridded(**kw, **par, scene=sc, _level_stack=-3)
+    assert hip.horizon.last_stats["stack_fallbacks"] == 0
     # a 3 x 1500 strip: a very unbalanced quadtree over (x, y)
     rng = np.random.default_rng(9)
     strip = cases.rough_terrain(3, 1500, seed=4, offset=0, relief=300.0)
