@@ -273,7 +273,7 @@ def roofline(args, stats, steps, cw, peaks, A, n, rps):
     rays_launch = stats.num_rays / max(steps, 1)
     cells_launch = stats.num_cells / max(steps, 1)
     b_io = (12 + 12 + 12 + 1 + 12 + 4) * cells_launch + 4.0 * A * cells_launch
-    r = {"kernel": "hz::k_horizon<2,false,true,false>", "kernel_ms_per_launch": 1e3 * k_launch_s,
+    r = {"kernel": "hz::k_horizon<2,false,true,false,false> (guess_constant, staged output, fast stack discipline)", "kernel_ms_per_launch": 1e3 * k_launch_s,
          "mray_per_s_kernel": rays_launch / k_launch_s / 1e6 if k_launch_s else None,
          "svf_kernel_ms_per_launch": 1e3 * stats.t_svf_s / max(steps, 1)}
     model = dict(VALU_MODEL_DEFAULT)
