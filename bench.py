@@ -5,16 +5,18 @@
 SRTM-like tile (1 arc-second spacing at 46 deg N, seeded fractal, integer metres), 16-cell ring,
 360 azimuth sectors, guess_constant, dist_search 50 km, hori_acc 0.25 deg, with the horizon array AND
 the fused sky view factor written to HBM.  A "step" is one pass of the hot path over one batch of
-grid cells: a slab of `--rows-per-step` inner-domain rows (512 x 3569 cells x 360 azimuths = 1.83 M
-cells, 6.6e8 output values, ~1.4e9 rays) against the full-tile LBVH.  The 3569 rows make 7 slabs (six
-of 512 rows and a ragged last one of 497); consecutive steps take consecutive slabs (wrapping), so the
-default K = 7 steps cover the whole tile exactly once.  Inputs (scene blob, per-cell frames, mask,
-tilt) are resident in HBM before the timed region and outputs stay in HBM; the library is called through
-its C ABI with device pointers (slab-local output buffers, opts.hori_is_slab).
+grid cells: by default the whole inner domain of the tile in ONE launch (3569 x 3569 cells x 360 azimuths =
+12.7 M cells, 4.6e9 output values = 18.3 GB, ~9.9e9 rays) against the full-tile LBVH; `--rows-per-step R` makes
+a step a slab of R inner-domain rows instead (consecutive steps take consecutive slabs, wrapping; the last slab
+is ragged).  One launch per tile is the default because every launch ends with a tail in which the last
+workgroups run on a draining GPU (a lane owns one cell for all 360 azimuths, ~50 ms): 7 slabs of 512 rows pay it
+7 times (5.63 M cells/s against 6.06 M for the whole tile, same kernel, same box).  Inputs (scene blob, per-cell
+frames, mask, tilt) are resident in HBM before the timed region and outputs stay in HBM; the library is called
+through its C ABI with device pointers (slab-local output buffers, opts.hori_is_slab).
 N > 1 (torch.distributed.run, one rank per GPU, RCCL): weak scaling -- rank 0 builds the scene and
 broadcasts the blob over xGMI once (set-up, untimed, like the BVH build); rank r then takes steps
-r K ... r K + K - 1 of the same slab sequence (no data-path collective); the SVF rows of every rank's
-last step are gathered on rank 0 inside the timed region.
+r K ... r K + K - 1 of the same step sequence (with whole-tile steps: the same tile on every rank; no data-path
+collective); the SVF rows of every rank's last step are gathered on rank 0 inside the timed region.
 
 --workload c5 (BASELINE.json config 5, strong scaling): the 4 x 4 mosaic (14401 x 14401, 206 M cells),
 SVF-fused (the 298 GB horizon is never materialised), inner rows split by dist.row_slabs over WORLD_SIZE
@@ -51,7 +53,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", choices=("c3", "c5"), default="c3")
-    ap.add_argument("--rows-per-step", type=int, default=512)
+    ap.add_argument("--rows-per-step", type=int, default=0, help="inner-domain rows per step (0: the whole tile in one launch)")
     ap.add_argument("--tile", type=int, default=None, help="DEM size (3601 for c3, 14401 for c5)")
     ap.add_argument("--azim", type=int, default=360)
     ap.add_argument("--dist-search", type=float, default=50.0)
@@ -159,13 +161,13 @@ def run_c3(ctx):
     args, rank, world, dev = ctx["args"], ctx["rank"], ctx["world"], ctx["dev"]
     L = _lib.lib()
     n, off, A = args.tile or 3601, 16, args.azim
-    rps = args.rows_per_step
     g = synth.fractal_tile(n=n, offset=off)
     in0 = in1 = n - 2 * off
+    rps = args.rows_per_step if 0 < args.rows_per_step < in0 else in0
     scene, scene_stats, t_build, t_bcast = make_scene(ctx, g, n)
     blob_ptr, blob_bytes = scene.blob()
-    n_slabs = (in0 + rps - 1) // rps                 # 7 for the 3601^2 tile: six of 512 rows + one of 497
-    steps = args.steps if args.steps is not None else n_slabs
+    n_slabs = (in0 + rps - 1) // rps                 # 1 by default; 7 with --rows-per-step 512 (six of 512 rows + 497)
+    steps = args.steps if args.steps is not None else max(n_slabs, 3)
     warmup = args.warmup if args.warmup is not None else 1
 
     # per-cell inputs resident in HBM
@@ -250,10 +252,12 @@ def run_c3(ctx):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "c3: horizon_gridded guess_constant + fused SVF, %dx%d synthetic SRTM-like tile, "
-                               "%d azimuths, dist_search %g km, slabs of <= %d rows per step (%d slabs cover the tile)"
-                               % (n, n, A, args.dist_search, rps, n_slabs),
-                   "cells_per_step": cells_launch, "rays_per_cell_azimuth": rays_launch / max(cells_launch * A, 1),
-                   "parallelism": "weak scaling x%d: same slab sequence, rank r starts at step r K; scene broadcast once" % world,
+                               "%d azimuths, dist_search %g km, %s"
+                               % (n, n, A, args.dist_search,
+                                  "the whole inner domain (%d rows) per step, one launch" % in0 if n_slabs == 1 else
+                                  "slabs of <= %d rows per step (%d slabs cover the tile)" % (rps, n_slabs)),
+                   "rows_per_step": rps, "cells_per_step": cells_launch, "rays_per_cell_azimuth": rays_launch / max(cells_launch * A, 1),
+                   "parallelism": "weak scaling x%d: same step sequence, rank r starts at step r K; scene broadcast once" % world,
                    "bvh_build_s": scene_stats["t_bvh_s"] if scene_stats else None,
                    "scene_bytes": int(blob_bytes), "scene_bcast_s": t_bcast, "scene_create_wall_s": t_build,
                    "load_imbalance_max_over_mean": imbalance, "near_prepass_ms_per_step": 1e3 * stats.t_near_s / max(steps, 1)},
@@ -300,7 +304,7 @@ def roofline(args, stats, steps, cw, peaks, A, n, rps):
         b_trav = rays_launch * (nodes_per_ray * 64.0 + tris_per_ray * 24.0)
         lanes = (cw.nodes_visited + cw.tris_tested / 2.0) / max(64.0 * (cw.wave_node_iters + cw.wave_leaf_iters), 1.0)
         r.update({"nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray,
-                  "valu_winst_per_launch": winst, "lane_utilisation_node_leaf_steps": lanes})
+                  "valu_winst_per_launch": winst, "valu_model_constants": model, "lane_utilisation_node_leaf_steps": lanes})
         if peaks and peaks["valu_winst_per_s"]:
             r.update({"bound": "valu_issue", "achieved": winst / k_launch_s / 1e9, "peak": peaks["valu_winst_per_s"] / 1e9,
                       "unit": "G wave-instructions/s", "frac": winst / k_launch_s / peaks["valu_winst_per_s"],

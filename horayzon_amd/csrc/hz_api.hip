@@ -301,10 +301,22 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     const bool stream_out = !skip_hori && !is_device_ptr(hori_slab_host);
     if (skip_hori || stream_out) {
         if (skip_hori && !want_svf) return set_error(HZ_ERR_ARG, "skip_hori without svf: nothing to compute");
-        if (opts && opts->chunk_rows > 0) chunk_rows = std::min(chunk_rows, opts->chunk_rows);
-        else chunk_rows = (int)std::max<size_t>(16, std::min<size_t>((size_t)chunk_rows, ((size_t)4 << 30) / row_bytes));
-        chunk_rows = std::min(chunk_rows, row_end - row_begin);
-        HZ_HIP(hipMalloc(&tmp_hori, (size_t)chunk_rows * row_bytes));
+        // Every launch ends with a tail (the last workgroups run on a draining GPU; a lane owns its cell for all
+        // azimuths), so launches should be few: 16 GiB of horizon per launch when it is only the SVF's input (nothing is
+        // copied out; less if HBM is short), 4 GiB when chunks are copied to the host behind the next chunk's kernel.
+        size_t target = skip_hori ? ((size_t)16 << 30) : ((size_t)4 << 30);
+        const bool fixed = opts && opts->chunk_rows > 0;
+        for (;;) {
+            chunk_rows = row_end - row_begin;
+            if (fixed) chunk_rows = std::min(chunk_rows, opts->chunk_rows);
+            else chunk_rows = (int)std::max<size_t>(16, std::min<size_t>((size_t)chunk_rows, target / row_bytes));
+            chunk_rows = std::min(chunk_rows, row_end - row_begin);
+            if (hipMalloc(&tmp_hori, (size_t)chunk_rows * row_bytes) == hipSuccess) break;
+            (void)hipGetLastError();
+            tmp_hori = nullptr;
+            if (fixed || target <= ((size_t)1 << 30)) return set_error(HZ_ERR_HIP, "hipMalloc of the horizon chunk (%zu bytes) failed", (size_t)chunk_rows * row_bytes);
+            target >>= 1;
+        }
         if (stream_out && chunk_rows < row_end - row_begin) HZ_HIP(hipMalloc(&tmp_hori2, (size_t)chunk_rows * row_bytes));
     } else {
         if ((rc = d_hori.bind(hori_slab_host, slab_cells * (size_t)azim_num))) return rc;

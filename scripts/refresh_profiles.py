@@ -33,7 +33,7 @@ f, w = out["FETCH_SIZE"][k]["mean_KiB"], out["WRITE_SIZE"][k]["mean_KiB"]
 cal_r = out["FETCH_SIZE"]["hz::k_bounds"]["mean_KiB"] * 1024 / (12 * 3601 * 3601)
 cal_w = out["WRITE_SIZE"]["hz::k_morton"]["mean_KiB"] * 1024 / (8 * 3600 * 3600)     # key + primitive id per quad
 b = json.loads(open("gpurun_out/%s_kt_bench.json" % pre).read().strip().splitlines()[-1])
-t = {"tile": 3601, "azim": 360, "rows_per_step": 512, "kernel_source_sha": sha,
+t = {"tile": 3601, "azim": 360, "rows_per_step": b["config"]["rows_per_step"], "kernel_source_sha": sha,
      "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024, "fetch_bytes": 2 * f * 1024, "write_bytes": w * 1024,
      "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (profiles/%s/pmc_fetch_write_summary.json), mean "
              "over the launches of 2 steps; KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2); calibration "
@@ -48,11 +48,11 @@ if kk:
     m = {c: sum(v) / len(v) for (kn, c), v in sq.items() if KERNEL in kn}
     bs = json.loads(open("gpurun_out/%s_sq_bench.json" % pre).read().strip().splitlines()[-1])
     model_winst = bs["roofline"].get("valu_winst_per_launch")
-    d = dict(bench.VALU_MODEL_DEFAULT)
+    d = bs["roofline"].get("valu_model_constants") or dict(bench.VALU_MODEL_DEFAULT)   # the constants that run used
     fac = m["SQ_INSTS_VALU"] / model_winst if model_winst else None
-    vm = {"kernel_source_sha": sha, "sq_counters_per_launch": m, "model_winst_default_constants": model_winst,
+    vm = {"kernel_source_sha": sha, "sq_counters_per_launch": m, "model_winst_before": model_winst,
           "scale": fac, "lane_utilisation_valu": m["SQ_THREAD_CYCLES_VALU"] / (64.0 * m["SQ_INSTS_VALU"]) if m.get("SQ_INSTS_VALU") else None,
-          "note": "per-iteration constants of bench.py scaled by SQ_INSTS_VALU / (default model) on the launches of 2 bench steps "
+          "note": "per-iteration constants of that bench run scaled by SQ_INSTS_VALU / (its model) on the launches of 2 bench steps "
                   "(the counter pass of the same run supplies the wave-iteration counts)"}
     if fac:
         for key in ("node_iter", "leaf_iter", "refill_iter"):
