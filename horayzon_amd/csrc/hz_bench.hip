@@ -63,8 +63,11 @@ int bench_valu_peak(int packed, int waves_per_simd, double *winst_per_s_per_simd
     HZ_HIP(hipGetDeviceProperties(&prop, dev));
     const int cus = prop.multiProcessorCount;
     const int w = std::min(std::max(waves_per_simd, 1), 8);
-    // one workgroup = 4 waves = one wave per SIMD of a CU; w workgroups per CU are resident at a time;
-    // 8 rounds of them so that the dispatch order cannot leave SIMDs idle for long
+    // one workgroup = 4 waves = one wave per SIMD of a CU.  cus * w * 8 workgroups of 22 VGPRs are all resident at
+    // once for w = 1 (8 waves per SIMD) and run in w rounds otherwise, so `w` only lengthens the run: 3.5 ms per
+    // round.  Keep the run short: a burst of a few ms is issued at the full engine clock (4.06 cycles per instruction
+    // at the nominal 2.4 GHz), a 28 ms run of nothing but FMAs is power-limited (4.2 cycles) -- the traversal
+    // kernels, with their mixed instructions, are not (they reach 4.07 for seconds).
     const int grid = cus * w * 8;
     const int trips = 4096;
     float *out = nullptr;

@@ -197,8 +197,9 @@ int hz_topographic_openness(const float *azim, const float *hori, int len_0, int
 int hz_debug_sort_pairs(uint32_t *keys, uint32_t *vals, size_t n, int device);
 int hz_debug_exclusive_scan(const uint32_t *in, uint32_t *out, size_t n, int device);
 /* Machine calibration for the roofline (bench.py, untimed section).  hz_debug_valu_peak: chains of      */
-/* independent v_fma_f32 (packed = 1: v_pk_fma_f32) with `waves_per_simd` resident waves -> wave-level    */
-/* VALU instructions per second and SIMD, the shader clock [GHz] and the number of SIMDs.                */
+/* independent v_fma_f32 (packed = 1: v_pk_fma_f32) at 8 waves per SIMD, `waves_per_simd` rounds of      */
+/* 3.5 ms (the name is historical: it only sets the length of the run; long pure-FMA runs are power-     */
+/* limited) -> wave-level VALU instructions per second and SIMD, the engine clock [GHz], the SIMD count. */
 /* hz_debug_copy_peak: float4 device-to-device copy of `bytes` -> read + write GB/s.                     */
 int hz_debug_valu_peak(int device, int packed, int waves_per_simd, double *winst_per_s_per_simd,
                        double *clock_ghz, int *simds);

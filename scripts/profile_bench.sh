@@ -16,5 +16,7 @@ timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${P}
     python $R/bench.py --steps 2 --no-cpu-baseline --no-count --no-peaks > /dev/null 2> $R/gpurun_out/${P}_write.err
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS --output-format csv -d $R/gpurun_out/${P}_sq -- \
     python $R/bench.py --steps 2 --no-cpu-baseline --no-peaks > $R/gpurun_out/${P}_sq_bench.json 2> $R/gpurun_out/${P}_sq.err
+timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/${P}_grbm -- \
+    python $R/bench.py --steps 2 --no-cpu-baseline --no-count --no-peaks > /dev/null 2> $R/gpurun_out/${P}_grbm.err
 cd $R
 tail -1 gpurun_out/${P}_kt_bench.json | cut -c1-400

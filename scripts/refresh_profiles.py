@@ -9,14 +9,15 @@ import bench
 pre, rnd = sys.argv[1], sys.argv[2]
 os.makedirs("profiles/%s" % rnd, exist_ok=True)
 sha = bench.kernel_source_sha()
-shutil.copy(glob.glob("gpurun_out/%s_kt/*/*kernel_stats.csv" % pre)[0], "profiles/%s/bench_kernel_stats.csv" % rnd)
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)       # gpurun_out/ keeps the files of earlier calls
+shutil.copy(newest("gpurun_out/%s_kt/*/*kernel_stats.csv" % pre), "profiles/%s/bench_kernel_stats.csv" % rnd)
 shutil.copy("gpurun_out/%s_kt_bench.json" % pre, "profiles/%s/bench_under_rocprof.json" % rnd)
 KERNEL = "k_horizon<2, false, true, false"
 
 
 def per_kernel(d, names):
     agg = {}
-    for f in glob.glob("gpurun_out/%s_%s/*/*counter_collection.csv" % (pre, d)):
+    for f in [newest("gpurun_out/%s_%s/*/*counter_collection.csv" % (pre, d))]:
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] in names:
                 agg.setdefault((r["Kernel_Name"].split("(")[0], r["Counter_Name"]), []).append(float(r["Counter_Value"]))
@@ -54,6 +55,16 @@ if kk:
           "scale": fac, "lane_utilisation_valu": m["SQ_THREAD_CYCLES_VALU"] / (64.0 * m["SQ_INSTS_VALU"]) if m.get("SQ_INSTS_VALU") else None,
           "note": "per-iteration constants of that bench run scaled by SQ_INSTS_VALU / (its model) on the launches of 2 bench steps "
                   "(the counter pass of the same run supplies the wave-iteration counts)"}
+    # engine cycles of the launch (own PMC pass) -> the clock the kernel ran at and the share of issue slots it used
+    gr = per_kernel("grbm", ("GRBM_GUI_ACTIVE",))
+    gk = [v for (kn, c), v in gr.items() if KERNEL in kn]
+    if gk:
+        cyc = sum(gk[0]) / len(gk[0]) / 8.0          # rocprofv3 sums the counter over the 8 XCDs
+        kt = [r for r in csv.DictReader(open("profiles/%s/bench_kernel_stats.csv" % rnd)) if KERNEL in r["Name"]][0]
+        dur = float(kt["AverageNs"]) * 1e-9
+        simds = bs["roofline"].get("simds") or 1024
+        vm.update({"grbm_gui_active_cycles_per_launch": cyc, "engine_clock_ghz_during_kernel": cyc / dur / 1e9,
+                   "valu_issue_slots_used": 4.0 * m["SQ_INSTS_VALU"] / (simds * cyc)})
     if fac:
         for key in ("node_iter", "leaf_iter", "refill_iter"):
             vm[key] = d[key] * fac
