@@ -328,9 +328,9 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         if ((rc = d_azim.bind(azim_h.data(), (size_t)azim_num, st))) return rc;
     }
     DevIn<unsigned long long> d_cnt;
-    unsigned long long zeros[16] = {0};
+    unsigned long long zeros[24] = {0};      // counters; behind them the list of tiles to redo (hz_horizon.hip)
     void *cnt_dev = nullptr;
-    HZ_HIP(hipMalloc(&cnt_dev, sizeof(zeros)));
+    HZ_HIP(hipMalloc(&cnt_dev, sizeof(zeros) + HZ_REDO_CAP * sizeof(int)));
     d_cnt.owned = cnt_dev;
     HZ_HIP(hipStreamSynchronize(st));
     const double h2d_s = t_h2d.stop();
@@ -354,12 +354,14 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     const bool use_near = !(opts && opts->no_near_skip) && sc->hdr.n_tin == 0 && azim_num <= near_max_azim() &&
                           tb.elev_num <= 65534;
     a.near_idx = nullptr; a.near_r = nullptr;
+    a.tile_list = nullptr; a.n_list = 0;
     a.verify_near = (opts && opts->verify_near) ? 1 : 0;
     float ms_near = 0.0f;
 
     unsigned long long cnt[16] = {0};
     float ms = 0.0f, ms_svf = 0.0f;
     int fallbacks = 0;
+    unsigned long long redo_tiles = 0;
 
     // HIP events on the kernels' stream: horizon kernel and SVF kernel are timed separately
     struct Ev { hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr; };
@@ -449,20 +451,30 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             int safe = 0;
             rc = horizon_launch(sc, a, st, &safe);
             if (!rc && !safe) {
-                // fast stack discipline: did a wave run out of entries?  Then its results are not trusted: the same
-                // rows again with the one-entry-per-level kernel, which the scene keeps from now on
+                // fast stack discipline: did a workgroup run out of entries?  Its tile does not count and is computed
+                // again with the one-entry-per-level kernel: tile by tile when they are few (deep trees overflow in a
+                // few places only), the whole launch -- and every later launch on this scene -- when they are many
                 unsigned long long ov = 0;
                 if (hipMemcpyAsync(&ov, (unsigned long long *)cnt_dev + 8, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
                     hipStreamSynchronize(st) != hipSuccess)
                     return fail(set_error(HZ_ERR_HIP, "horizon kernel failed: %s", hipGetErrorString(hipGetLastError())));
                 if (ov != 0) {
-                    sc->level_stack.store(1, std::memory_order_relaxed);
+                    const unsigned long long tiles = (unsigned long long)((re - rb + 15) / 16) * (unsigned long long)((dim_in_1 + 15) / 16);
                     fallbacks++;
                     a.level_stack = 1;
-                    if (hipMemcpyAsync(cnt_dev, zeros, sizeof(zeros), hipMemcpyHostToDevice, st) != hipSuccess)
-                        return fail(set_error(HZ_ERR_HIP, "counter reset failed"));
-                    (void)hipEventRecord(e.a, st);
-                    rc = horizon_launch(sc, a, st, &safe);
+                    if (ov <= HZ_REDO_CAP && ov * 4 <= tiles) {
+                        a.tile_list = reinterpret_cast<const int *>((unsigned long long *)cnt_dev + 24);
+                        a.n_list = (int)ov;
+                        redo_tiles += ov;
+                        rc = horizon_launch(sc, a, st, &safe);
+                        a.tile_list = nullptr; a.n_list = 0;
+                    } else {
+                        sc->level_stack.store(1, std::memory_order_relaxed);
+                        if (hipMemcpyAsync(cnt_dev, zeros, sizeof(zeros), hipMemcpyHostToDevice, st) != hipSuccess)
+                            return fail(set_error(HZ_ERR_HIP, "counter reset failed"));
+                        (void)hipEventRecord(e.a, st);
+                        rc = horizon_launch(sc, a, st, &safe);
+                    }
                 }
             }
             (void)hipEventRecord(e.b, st);
@@ -505,7 +517,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         stats->t_d2h_s += d2h_s;
         stats->t_total_s += t_total.stop();
         stats->elev_num = tb.elev_num; stats->bvh_height = sc->hdr.height; stats->scene_bytes = sc->hdr.total_bytes;
-        stats->stack_fallbacks += (uint64_t)fallbacks;
+        stats->stack_fallbacks += (uint64_t)fallbacks; stats->stack_redo_tiles += redo_tiles;
         stats->rays_shortened += cnt[9]; stats->near_violations += cnt[10]; stats->t_near_s += (double)ms_near * 1e-3;
     }
     if (opts && opts->verbose) {   // the reference's report, horizon_comp.cpp:673-700, 805-810 (same lines, same order)

@@ -48,6 +48,8 @@ struct HorizonParams {
     const float *near_r;
     int verify_near;
     unsigned long long *counters;
+    const int *tile_list;          // null, or the workgroup numbers (of the full launch) this launch repeats
+    int *redo_list;                // !LEVELSTACK: workgroups whose stack overflowed append their number here (count: counters[8])
 };
 
 // LDS: [ per-lane stacks int[depth][256] | output staging float[4][256] | top-of-tree nodelet Node[top_nodes] ]
@@ -68,7 +70,8 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
     }
 
     int ti = 0, tj = 0;
-    const bool has_tile = hz_tile_of_block(p.tm, blockIdx.x, &ti, &tj);
+    const int wg = p.tile_list ? p.tile_list[blockIdx.x] : (int)blockIdx.x;
+    const bool has_tile = hz_tile_of_block(p.tm, wg, &ti, &tj);
     const int wave = tid >> 6, lane = tid & 63;
     const int i = p.row_begin + ti * 16 + (wave >> 1) * 8 + (lane >> 3);
     const int j = tj * 16 + (wave & 1) * 8 + (lane & 7);
@@ -195,9 +198,16 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
             wn += __shfl_xor(wn, off); wl += __shfl_xor(wl, off); wa += __shfl_xor(wa, off);
         }
     }
-    const bool any_overflow = !LEVELSTACK && __ballot(overflow != 0u) != 0ull;
+    // !LEVELSTACK: a workgroup in which a ray ran out of stack entries does not count; its tile is computed again by
+    // the one-entry-per-level kernel (horizon_run), which overwrites everything this workgroup wrote
+    if (!LEVELSTACK && __syncthreads_or(overflow != 0u)) {
+        if (tid == 0) {
+            const unsigned long long slot = atomicAdd(&p.counters[8], 1ull);
+            if (slot < (unsigned long long)HZ_REDO_CAP) p.redo_list[slot] = wg;
+        }
+        return;
+    }
     if (lane == 0) {
-        if (any_overflow) atomicAdd(&p.counters[8], 1ull);
         if (r) atomicAdd(&p.counters[0], r);
         if (g) atomicAdd(&p.counters[1], g);
         if (cc) atomicAdd(&p.counters[4], cc);
@@ -283,8 +293,11 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
     p.hit_cache = (a.hit_cache != 0) ? 1 : 0;
     p.near_idx = a.near_idx; p.near_r = a.near_r; p.verify_near = a.verify_near;
     p.counters = a.counters;
+    p.tile_list = a.tile_list;
+    p.redo_list = reinterpret_cast<int *>(a.counters + 24);
     const size_t lds = (size_t)p.stack_bytes + (size_t)p.stage_bytes + (size_t)top * sizeof(Node);
-    const int grid = p.tm.per_xcd * 8;
+    const int grid = a.tile_list ? a.n_list : p.tm.per_xcd * 8;
+    if (grid <= 0) return HZ_OK;
     const bool count = a.count_work != 0;
     switch (a.alg) {
         case ALG_DISCRETE: return launch_alg<ALG_DISCRETE>(p, grid, lds, count, level_stack, st);
