@@ -419,7 +419,7 @@ def run_c5(ctx):
                    "bvh_build_s": scene_stats["t_bvh_s"] if scene_stats else None, "scene_bytes": int(blob_bytes),
                    "scene_bcast_s": t_bcast, "scene_create_wall_s": t_build, "kernel_s_rank0": stats.t_kernel_s,
                    "svf_kernel_s_rank0": stats.t_svf_s, "near_prepass_s_rank0": stats.t_near_s,
-                   "stack_fallbacks_rank0": int(stats.stack_fallbacks), "stack_redo_tiles_rank0": int(stats.stack_redo_tiles),
+                   "stack_fallbacks_rank0": int(stats.stack_fallbacks), "stack_redo_blocks_rank0": int(stats.stack_redo_blocks),
                    "gathered_svf_finite": svf_ok},
         "roofline": {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None,
                      "traffic": None, "note": "see the c3 line: same kernel; c5 reports scaling, not the kernel roofline"},

@@ -41,7 +41,7 @@ class hz_stats(C.Structure):
                 ("wave_leaf_iters", C.c_uint64), ("wave_refills", C.c_uint64),
                 ("t_svf_s", C.c_double), ("stack_fallbacks", C.c_uint64),
                 ("rays_shortened", C.c_uint64), ("near_violations", C.c_uint64), ("t_near_s", C.c_double),
-                ("stack_redo_tiles", C.c_uint64)]
+                ("stack_redo_blocks", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

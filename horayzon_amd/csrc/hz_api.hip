@@ -361,7 +361,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     unsigned long long cnt[16] = {0};
     float ms = 0.0f, ms_svf = 0.0f;
     int fallbacks = 0;
-    unsigned long long redo_tiles = 0;
+    unsigned long long redo_blocks = 0;
 
     // HIP events on the kernels' stream: horizon kernel and SVF kernel are timed separately
     struct Ev { hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr; };
@@ -451,21 +451,21 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             int safe = 0;
             rc = horizon_launch(sc, a, st, &safe);
             if (!rc && !safe) {
-                // fast stack discipline: did a workgroup run out of entries?  Its tile does not count and is computed
-                // again with the one-entry-per-level kernel: tile by tile when they are few (deep trees overflow in a
+                // fast stack discipline: did a wave run out of entries?  Its 8 x 8 block does not count and is computed
+                // again with the one-entry-per-level kernel: block by block when they are few (deep trees overflow in a
                 // few places only), the whole launch -- and every later launch on this scene -- when they are many
                 unsigned long long ov = 0;
                 if (hipMemcpyAsync(&ov, (unsigned long long *)cnt_dev + 8, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
                     hipStreamSynchronize(st) != hipSuccess)
                     return fail(set_error(HZ_ERR_HIP, "horizon kernel failed: %s", hipGetErrorString(hipGetLastError())));
                 if (ov != 0) {
-                    const unsigned long long tiles = (unsigned long long)((re - rb + 15) / 16) * (unsigned long long)((dim_in_1 + 15) / 16);
+                    const unsigned long long tiles = (unsigned long long)((re - rb + 7) / 8) * (unsigned long long)((dim_in_1 + 7) / 8);   // 8 x 8 blocks
                     fallbacks++;
                     a.level_stack = 1;
                     if (ov <= HZ_REDO_CAP && ov * 4 <= tiles) {
                         a.tile_list = reinterpret_cast<const int *>((unsigned long long *)cnt_dev + 24);
                         a.n_list = (int)ov;
-                        redo_tiles += ov;
+                        redo_blocks += ov;
                         rc = horizon_launch(sc, a, st, &safe);
                         a.tile_list = nullptr; a.n_list = 0;
                     } else {
@@ -517,7 +517,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         stats->t_d2h_s += d2h_s;
         stats->t_total_s += t_total.stop();
         stats->elev_num = tb.elev_num; stats->bvh_height = sc->hdr.height; stats->scene_bytes = sc->hdr.total_bytes;
-        stats->stack_fallbacks += (uint64_t)fallbacks; stats->stack_redo_tiles += redo_tiles;
+        stats->stack_fallbacks += (uint64_t)fallbacks; stats->stack_redo_blocks += redo_blocks;
         stats->rays_shortened += cnt[9]; stats->near_violations += cnt[10]; stats->t_near_s += (double)ms_near * 1e-3;
     }
     if (opts && opts->verbose) {   // the reference's report, horizon_comp.cpp:673-700, 805-810 (same lines, same order)

@@ -48,8 +48,9 @@ struct HorizonParams {
     const float *near_r;
     int verify_near;
     unsigned long long *counters;
-    const int *tile_list;          // null, or the workgroup numbers (of the full launch) this launch repeats
-    int *redo_list;                // !LEVELSTACK: workgroups whose stack overflowed append their number here (count: counters[8])
+    const int *tile_list;          // null, or the n_list blocks (workgroup number * 4 + wave, of the full launch) to repeat
+    int n_list;
+    int *redo_list;                // !LEVELSTACK: waves whose stack overflowed append their block here (count: counters[8])
 };
 
 // LDS: [ per-lane stacks int[depth][256] | output staging float[4][256] | top-of-tree nodelet Node[top_nodes] ]
@@ -69,12 +70,15 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
         __syncthreads();
     }
 
+    // wave -> 8 x 8 block of cells: quadrant `wave` of the tile of workgroup blockIdx.x, or -- in a launch that repeats
+    // blocks whose fast stack overflowed -- the block the list names (entry = workgroup number * 4 + quadrant)
     int ti = 0, tj = 0;
-    const int wg = p.tile_list ? p.tile_list[blockIdx.x] : (int)blockIdx.x;
-    const bool has_tile = hz_tile_of_block(p.tm, wg, &ti, &tj);
     const int wave = tid >> 6, lane = tid & 63;
-    const int i = p.row_begin + ti * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const int j = tj * 16 + (wave & 1) * 8 + (lane & 7);
+    int blk = (int)blockIdx.x * 4 + wave;
+    if (p.tile_list) blk = (blk < p.n_list) ? p.tile_list[blk] : -1;
+    const bool has_tile = blk >= 0 && hz_tile_of_block(p.tm, blk >> 2, &ti, &tj);
+    const int i = p.row_begin + ti * 16 + ((blk >> 1) & 1) * 8 + (lane >> 3);
+    const int j = tj * 16 + (blk & 1) * 8 + (lane & 7);
     const bool in_dom = has_tile && (i < p.row_end) && (j < p.dim_in_1);
 
     const Tables &t = p.tb;
@@ -198,12 +202,12 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
             wn += __shfl_xor(wn, off); wl += __shfl_xor(wl, off); wa += __shfl_xor(wa, off);
         }
     }
-    // !LEVELSTACK: a workgroup in which a ray ran out of stack entries does not count; its tile is computed again by
-    // the one-entry-per-level kernel (horizon_run), which overwrites everything this workgroup wrote
-    if (!LEVELSTACK && __syncthreads_or(overflow != 0u)) {
-        if (tid == 0) {
+    // !LEVELSTACK: a wave in which a ray ran out of stack entries does not count; its block is computed again by the
+    // one-entry-per-level kernel (horizon_run), which overwrites everything this wave wrote
+    if (!LEVELSTACK && __ballot(overflow != 0u) != 0ull) {
+        if (lane == 0) {
             const unsigned long long slot = atomicAdd(&p.counters[8], 1ull);
-            if (slot < (unsigned long long)HZ_REDO_CAP) p.redo_list[slot] = wg;
+            if (slot < (unsigned long long)HZ_REDO_CAP) p.redo_list[slot] = (int)blockIdx.x * 4 + wave;
         }
         return;
     }
@@ -293,10 +297,10 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
     p.hit_cache = (a.hit_cache != 0) ? 1 : 0;
     p.near_idx = a.near_idx; p.near_r = a.near_r; p.verify_near = a.verify_near;
     p.counters = a.counters;
-    p.tile_list = a.tile_list;
+    p.tile_list = a.tile_list; p.n_list = a.n_list;
     p.redo_list = reinterpret_cast<int *>(a.counters + 24);
     const size_t lds = (size_t)p.stack_bytes + (size_t)p.stage_bytes + (size_t)top * sizeof(Node);
-    const int grid = a.tile_list ? a.n_list : p.tm.per_xcd * 8;
+    const int grid = a.tile_list ? (a.n_list + 3) / 4 : p.tm.per_xcd * 8;
     if (grid <= 0) return HZ_OK;
     const bool count = a.count_work != 0;
     switch (a.alg) {

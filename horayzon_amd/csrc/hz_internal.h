@@ -114,8 +114,8 @@ struct HorizonArgs {
     const int *mid_idx;
     int top_nodes, regroup, count_work, hit_cache;
     int level_stack;                     // 1: one-entry-per-level traversal stack (cannot overflow); 0: fast discipline
-    const int *tile_list;                // null: every tile of the rows; else the n_list tiles (workgroup numbers of the
-    int n_list;                          //   full launch) to compute -- the redo of tiles whose fast stack overflowed
+    const int *tile_list;                // null: every tile of the rows; else the n_list 8 x 8 blocks (workgroup number of
+    int n_list;                          //   the full launch * 4 + wave) to compute: the blocks whose fast stack overflowed
     const unsigned short *near_idx;      // near-field certificates of rows [row_begin, row_end) (hz_near.hip) or null
     const float *near_r;
     int verify_near;                     // counting instantiation: re-trace every shortened ray from parameter 0
@@ -123,7 +123,7 @@ struct HorizonArgs {
                                          // [5..7] wave iterations, [8] waves whose fast-discipline stack overflowed,
                                          // [9] rays shortened by a certificate, [10] certificate violations (verify)
 };
-#define HZ_REDO_CAP 4096                 // tiles of one launch that can be repeated one by one after a stack overflow
+#define HZ_REDO_CAP 16384                // 8 x 8 blocks of one launch that can be repeated one by one after a stack overflow
 int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *used_level_stack = nullptr);
 int topo_launch(int kind, const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
                 int len_2, float *out, hipStream_t st);

@@ -89,12 +89,12 @@ typedef struct hz_stats {
     uint64_t wave_leaf_iters; /*   step / leaf step / ray refill section (SIMT  */
     uint64_t wave_refills;    /*   efficiency = lane count / (64 x wave count)) */
     double t_svf_s;        /* sky-view-factor kernel (when opts.svf is set)    */
-    uint64_t stack_fallbacks; /* launches after which tiles (or the whole launch) were repeated with the one-entry-per-  */
+    uint64_t stack_fallbacks; /* launches after which blocks (or the whole launch) were repeated with the one-entry-per- */
                               /*   level stack because a ray ran out of entries of the fast one                          */
     uint64_t rays_shortened;  /* count_work: rays that started beyond the cell's neighbourhood (near-field certificate) */
     uint64_t near_violations; /* count_work + verify_near: shortened rays whose full-length re-trace disagreed (0)      */
     double t_near_s;       /* certificate pre-pass (hz_near.hip)                */
-    uint64_t stack_redo_tiles; /* 16 x 16 tiles repeated one by one after such an overflow (few: deep trees overflow in  */
+    uint64_t stack_redo_blocks; /* 8 x 8 blocks repeated one by one after such an overflow (few: deep trees overflow in    */
                                /*   a few places; many overflows repeat the launch and switch the scene for good)        */
 } hz_stats;
 
