@@ -13,13 +13,18 @@ pytestmark = pytest.mark.gpu
 def test_random_configurations(hip, orc):
     n = int(os.environ.get("HZ_FUZZ_N", "24"))
     rng = np.random.default_rng(int(os.environ.get("HZ_FUZZ_SEED", "20260928")))
+    redo_seen = 0
     for it in range(n):
         kw, par, extra, tilt = cases.fuzz_case(rng)
         in0, in1 = kw["vec_norm"].shape[:2]
         verify = (it % 3 == 0)          # every third configuration re-traces its shortened rays (near-field certificates)
-        out = hip.horizon.horizon_gridded(**kw, **par, **extra, count_work=verify, _verify_near=verify)
+        # every fourth one runs with a short fast stack: blocks whose rays run out of entries are repeated with the
+        # one-entry-per-level kernel (a few blocks one by one, many as a whole launch)
+        stack = {"_level_stack": -int(rng.integers(4, 15))} if it % 4 == 1 else {}
+        out = hip.horizon.horizon_gridded(**kw, **par, **extra, **stack, count_work=verify, _verify_near=verify)
         h_gpu, a_gpu = out[0], out[1]
         st = hip.horizon.last_stats
+        redo_seen += int(st["stack_redo_blocks"] > 0)
         assert st["near_violations"] == 0, "config %d: a near-field certificate shortened a ray that hits nearby" % it
         ro = {"rows": extra["rows"]} if "rows" in extra else {}
         h_cpu, a_cpu, so = orc.horizon_gridded(**kw, **par, **ro, return_stats=True)
@@ -33,6 +38,7 @@ def test_random_configurations(hip, orc):
             r0, r1 = extra.get("rows", (0, in0))
             svf_cpu = orc.sky_view_factor(a_cpu, h_cpu[r0:r1], tilt[r0:r1])
             assert np.abs(out[2][r0:r1] - svf_cpu).max() <= 1.0e-5, desc
+    print("configurations with blocks repeated one by one:", redo_seen)
 
 
 def test_random_locations(hip, orc):
