@@ -85,6 +85,49 @@ def test_c3_shadow_matches_horizon(hip, orc, tile):
     assert 0.02 < (sh == 2).mean() < 0.98
 
 
+def test_c3_whole_tile_in_one_launch(hip, orc, tile):
+    """What bench.py times: the whole inner domain of the tile (12.7 M cells, 18.3 GB of horizon) in ONE launch with
+    everything resident in HBM.  Row bands of it (both tile edges, the middle) equal the same rows computed as small
+    slabs, and the middle band equals the oracle, bit for bit."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    from horayzon_amd import _lib
+    kw = cases.grid_kwargs(tile)
+    in0 = in1 = 3569
+    A, dev = 360, "cuda:0"
+    sc = hip.Scene.create(kw["vert_grid"], 3601, 3601)
+    d_norm = torch.from_numpy(kw["vec_norm"]).to(dev); d_north = torch.from_numpy(kw["vec_north"]).to(dev)
+    d_mask = torch.ones((in0, in1), dtype=torch.uint8, device=dev)
+    d_hori = torch.full((in0, in1, A), float("nan"), dtype=torch.float32, device=dev)
+
+    def run(rows, out):
+        opts = _lib.hz_opts(); opts.device = 0; opts.top_nodes = -1; opts.regroup = -1
+        opts.row_begin, opts.row_end = rows
+        opts.hori_is_slab = 1
+        st = _lib.hz_stats()
+        _lib.check(_lib.lib().hz_horizon_gridded_scene(
+            sc._h, d_norm.data_ptr(), d_north.data_ptr(), 16, 16, out.data_ptr(), in0, in1, A, 50.0, 0.25,
+            b"guess_constant", -15.0, d_mask.data_ptr(), 0.0, 0.01, C.byref(opts), C.byref(st)))
+        return st
+
+    st = run((0, in0), d_hori)
+    # (guard events: cells at the rim of the tile whose lowest ray leaves the DEM unobstructed -- the case in which the
+    # reference never leaves its loop, horizon_comp.cpp:474-488)
+    assert st.num_cells == in0 * in1 and st.stack_fallbacks == 0 and st.guard_events < 0.001 * in0 * in1 * A
+    assert 2.0 <= st.num_rays / (in0 * in1 * A) <= 3.0            # horizon_comp.cpp:809-810
+    assert not bool(torch.isnan(d_hori).any().item())
+    rays_bands = 0
+    for rows in ((0, 3), (1777, 1781), (3566, 3569)):
+        d_band = torch.full((rows[1] - rows[0], in1, A), float("nan"), dtype=torch.float32, device=dev)
+        sb = run(rows, d_band)
+        assert bool((d_band == d_hori[rows[0]:rows[1]]).all().item()), rows
+        rays_bands += sb.num_rays
+    ref, _, so = orc.horizon_gridded(**kw, dist_search=50.0, azim_num=A, rows=(1777, 1781), slab_only=True,
+                                     return_stats=True)
+    assert np.array_equal(d_hori[1777:1781].cpu().numpy(), ref)
+    assert rays_bands > so["rays"]
+
+
 @pytest.mark.skipif("HZ_FULLSIZE_BANDS" not in __import__("os").environ,
                     reason="wide full-size sweep: set HZ_FULLSIZE_BANDS=0:32,1760:1792,... (needs many host cores)")
 def test_c3_row_bands_bit_identical(hip, orc, tile):
