@@ -54,7 +54,7 @@ SYMBOLS = (
     "hz_horizon_gridded", "hz_horizon_gridded_scene", "hz_horizon_locations",
     "hz_horizon_locations_scene", "hz_horizon_tables",
     "hz_sky_view_factor", "hz_visible_sky_fraction", "hz_topographic_openness",
-    "hz_slope_plane_meth", "hz_slope_vector_meth", "hz_lonlat2ecef", "hz_ecef2enu",
+    "hz_slope_plane_meth", "hz_slope_vector_meth", "hz_lonlat2ecef", "hz_ecef2enu", "hz_wgs2swiss", "hz_swiss2wgs",
     "hz_ecef2enu_vector", "hz_surf_norm", "hz_north_dir", "hz_vert_grid_len", "hz_pack_vertices",
     "hz_debug_sort_pairs", "hz_debug_exclusive_scan",
     "hz_debug_valu_peak", "hz_debug_copy_peak",
@@ -129,6 +129,8 @@ def lib():
     L.hz_slope_vector_meth.argtypes = [vp, vp, vp, ip, ip, vp, ip, vp, ip]
     L.hz_lonlat2ecef.argtypes = [vp, vp, vp, C.c_size_t, ip, vp, vp, vp, ip]
     L.hz_ecef2enu.argtypes = [vp, vp, vp, C.c_size_t, C.c_double, C.c_double, ip, vp, vp, vp, ip]
+    L.hz_wgs2swiss.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp, ip]
+    L.hz_swiss2wgs.argtypes = [vp, vp, vp, C.c_size_t, vp, vp, vp, ip]
     L.hz_ecef2enu_vector.argtypes = [vp, C.c_size_t, C.c_double, C.c_double, ip, vp, ip]
     L.hz_surf_norm.argtypes = [vp, vp, C.c_size_t, vp, ip]
     L.hz_north_dir.argtypes = [vp, vp, vp, vp, C.c_size_t, ip, vp, ip]

@@ -1,5 +1,6 @@
-"""horayzon.auxiliary -- the one routine of the reference's auxiliary module that sits on the hot path's
-input side: ``rearrange_pad_buffer`` (reference horayzon/auxiliary.py:49-95), on MI355X.
+"""horayzon.auxiliary -- the routines of the reference's auxiliary module that sit on the hot path's
+input side: ``rearrange_pad_buffer`` (reference horayzon/auxiliary.py:49-95) on MI355X, and ``pad_buffer``
+(:100-135; host-side: it prepares the few-element TIN buffers ``vert_simp`` / ``tri_ind_simp``).
 
 NumPy in -> NumPy out as the reference; torch tensors in HBM in -> a torch tensor in HBM out (the chain
 lon/lat/elevation -> ENU -> vert_grid -> scene -> horizon / SVF / shadow then never touches host memory)."""
@@ -36,3 +37,17 @@ def rearrange_pad_buffer(x, y, z, *, device=0):
         raise TypeError("One or more input arguments are of invalid type")
     _lib.check(_lib.lib().hz_pack_vertices(ptr(x), ptr(y), ptr(z), n, ptr(out), len(out), device))
     return out
+
+
+def pad_buffer(buffer):
+    """Padding of a one-dimensional geometry buffer as the reference does it (auxiliary.py:100-135): at least 16 zero
+    elements are appended and the byte size becomes a multiple of 16.  This library copies its inputs to HBM and
+    never reads the padding -- the function exists so that code written for the reference runs unchanged."""
+    if not isinstance(buffer, np.ndarray):
+        raise ValueError("argument 'buffer' has invalid type")
+    if buffer.ndim != 1:
+        raise ValueError("argument 'buffer' must be one-dimensional")
+    add_elem = 16
+    if not (buffer.nbytes % 16) == 0:
+        add_elem += ((16 - (buffer.nbytes % 16)) // buffer[0].nbytes)
+    return np.append(buffer, np.zeros(add_elem, dtype=buffer.dtype))

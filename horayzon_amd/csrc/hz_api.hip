@@ -956,6 +956,36 @@ int hz_lonlat2ecef(const double *lon, const double *lat, const float *h, size_t 
     return HZ_OK;
 }
 
+int hz_wgs2swiss(const double *lon, const double *lat, const float *h_wgs, size_t n, double *e, double *no, float *h_ch,
+                 int device) {
+    if (!lon || !lat || !h_wgs || !e || !no || !h_ch) return set_error(HZ_ERR_ARG, "NULL argument");
+    int rc = select_device(device);
+    if (rc) return rc;
+    hipStream_t st = nullptr;
+    DevIn<double> da, db; DevIn<float> dh; DevOut<double> oa, ob; DevOut<float> oh;
+    if ((rc = da.bind(lon, n, st)) || (rc = db.bind(lat, n, st)) || (rc = dh.bind(h_wgs, n, st))) return rc;
+    if ((rc = oa.bind(e, n)) || (rc = ob.bind(no, n)) || (rc = oh.bind(h_ch, n))) return rc;
+    if ((rc = prep_wgs2swiss(da.dev, db.dev, dh.dev, n, oa.dev, ob.dev, oh.dev, st))) return rc;
+    if ((rc = oa.finish(st)) || (rc = ob.finish(st)) || (rc = oh.finish(st))) return rc;
+    HZ_HIP(hipStreamSynchronize(st));
+    return HZ_OK;
+}
+
+int hz_swiss2wgs(const double *e, const double *no, const float *h_ch, size_t n, double *lon, double *lat, float *h_wgs,
+                 int device) {
+    if (!e || !no || !h_ch || !lon || !lat || !h_wgs) return set_error(HZ_ERR_ARG, "NULL argument");
+    int rc = select_device(device);
+    if (rc) return rc;
+    hipStream_t st = nullptr;
+    DevIn<double> da, db; DevIn<float> dh; DevOut<double> oa, ob; DevOut<float> oh;
+    if ((rc = da.bind(e, n, st)) || (rc = db.bind(no, n, st)) || (rc = dh.bind(h_ch, n, st))) return rc;
+    if ((rc = oa.bind(lon, n)) || (rc = ob.bind(lat, n)) || (rc = oh.bind(h_wgs, n))) return rc;
+    if ((rc = prep_swiss2wgs(da.dev, db.dev, dh.dev, n, oa.dev, ob.dev, oh.dev, st))) return rc;
+    if ((rc = oa.finish(st)) || (rc = ob.finish(st)) || (rc = oh.finish(st))) return rc;
+    HZ_HIP(hipStreamSynchronize(st));
+    return HZ_OK;
+}
+
 int hz_ecef2enu(const double *x_ecef, const double *y_ecef, const double *z_ecef, size_t n, double lon_or,
                 double lat_or, int ellps, float *x_enu, float *y_enu, float *z_enu, int device) {
     if (!x_ecef || !y_ecef || !z_ecef || !x_enu || !y_enu || !z_enu) return set_error(HZ_ERR_ARG, "NULL argument");

@@ -190,6 +190,10 @@ int prep_ecef2enu(int ellps, double lon_or, double lat_or, const double *X, cons
                   size_t n, float *xe, float *ye, float *ze, hipStream_t st);
 int prep_ecef2enu_vector(int ellps, double lon_or, double lat_or, const float *v, size_t n, float *o, hipStream_t st);
 int prep_surf_norm(const double *lon, const double *lat, size_t n, float *o, hipStream_t st);
+int prep_wgs2swiss(const double *lon, const double *lat, const float *h_wgs, size_t n, double *e, double *no, float *h_ch,
+                   hipStream_t st);
+int prep_swiss2wgs(const double *e, const double *no, const float *h_ch, size_t n, double *lon, double *lat, float *h_wgs,
+                   hipStream_t st);
 int prep_pack_vertices(const float *x, const float *y, const float *z, size_t n, size_t n_total, float *out,
                        hipStream_t st);
 int prep_north_dir(int ellps, const double *X, const double *Y, const double *Z, const float *vn, size_t n,

@@ -251,6 +251,51 @@ int prep_ecef2enu_vector(int ellps, double lon_or, double lat_or, const float *v
     return HZ_OK;
 }
 
+// Swiss projection coordinates (LV95) <-> WGS84, swisstopo's approximate formulas as the reference evaluates them
+// (transform.pyx:306-345, :390-432): float64 arithmetic, the height in float32
+__global__ __launch_bounds__(256) void k_wgs2swiss(const double *__restrict__ lon, const double *__restrict__ lat,
+                                                  const float *__restrict__ h_wgs, size_t n, double *__restrict__ e,
+                                                  double *__restrict__ no, float *__restrict__ h_ch) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double lo = ((lon[i] * 3600.0) - 26782.5) / 10000.0;       // arc seconds relative to Bern, in 10000"
+    const double la = ((lat[i] * 3600.0) - 169028.66) / 10000.0;
+    e[i] = 2600072.37 + 211455.93 * lo - 10938.51 * lo * la - 0.36 * lo * (la * la) - 44.54 * (lo * lo * lo);
+    no[i] = 1200147.07 + 308807.95 * la + 3745.25 * (lo * lo) + 76.63 * (la * la) - 194.56 * (lo * lo) * la
+            + 119.79 * (la * la * la);
+    h_ch[i] = (float)((double)h_wgs[i] - 49.55 + 2.73 * lo + 6.94 * la);
+}
+
+__global__ __launch_bounds__(256) void k_swiss2wgs(const double *__restrict__ e, const double *__restrict__ no,
+                                                  const float *__restrict__ h_ch, size_t n, double *__restrict__ lon,
+                                                  double *__restrict__ lat, float *__restrict__ h_wgs) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double ep = (e[i] - 2600000.0) / 1000000.0, np_ = (no[i] - 1200000.0) / 1000000.0;   // civilian system, 1000 km
+    const double lo = 2.6779094 + 4.728982 * ep + 0.791484 * ep * np_ + 0.1306 * ep * (np_ * np_) - 0.0436 * (ep * ep * ep);
+    const double la = 16.9023892 + 3.238272 * np_ - 0.270978 * (ep * ep) - 0.002528 * (np_ * np_) - 0.0447 * (ep * ep) * np_
+                      - 0.0140 * (np_ * np_ * np_);
+    h_wgs[i] = (float)((double)h_ch[i] + 49.55 - 12.60 * ep - 22.64 * np_);
+    lon[i] = lo * (100.0 / 36.0);                                      // 10000" -> degree
+    lat[i] = la * (100.0 / 36.0);
+}
+
+int prep_wgs2swiss(const double *lon, const double *lat, const float *h_wgs, size_t n, double *e, double *no, float *h_ch,
+                   hipStream_t st) {
+    if (n == 0) return HZ_OK;
+    hipLaunchKernelGGL(k_wgs2swiss, dim3(grid_of(n)), dim3(256), 0, st, lon, lat, h_wgs, n, e, no, h_ch);
+    HZ_HIP(hipGetLastError());
+    return HZ_OK;
+}
+
+int prep_swiss2wgs(const double *e, const double *no, const float *h_ch, size_t n, double *lon, double *lat, float *h_wgs,
+                   hipStream_t st) {
+    if (n == 0) return HZ_OK;
+    hipLaunchKernelGGL(k_swiss2wgs, dim3(grid_of(n)), dim3(256), 0, st, e, no, h_ch, n, lon, lat, h_wgs);
+    HZ_HIP(hipGetLastError());
+    return HZ_OK;
+}
+
 int prep_surf_norm(const double *lon, const double *lat, size_t n, float *o, hipStream_t st) {
     if (n == 0) return HZ_OK;
     hipLaunchKernelGGL(k_surf_norm, dim3(grid_of(n)), dim3(256), 0, st, lon, lat, n, o);

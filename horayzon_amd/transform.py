@@ -1,7 +1,7 @@
 """horayzon.transform -- the coordinate transforms that prepare curved-DEM input for the
 horizon / shadow path, on MI355X (reference: horayzon/transform.pyx).
-Only the routines on that preparation chain are provided: lonlat2ecef, ecef2enu,
-ecef2enu_vector, TransformerEcef2enu, rotation_matrix_glob2loc."""
+lonlat2ecef, ecef2enu, ecef2enu_vector, TransformerEcef2enu, rotation_matrix_glob2loc and the Swiss projection
+pair wgs2swiss / swiss2wgs (the swissALTI3D input path of the reference's examples)."""
 import numpy as np
 
 from . import _lib
@@ -99,6 +99,34 @@ def ecef2enu_vector(vec_ecef, trans_ecef2enu, *, device=0):
     _lib.check(_lib.lib().hz_ecef2enu_vector(ptr(v), v.shape[0], float(t.lon_or), float(t.lat_or),
                                              _ELLPS[getattr(t, "ellps", "WGS84")], ptr(out), device))
     return out.reshape(shp)
+
+
+def _triple(a, b, c, sym, *, device):
+    """shared body of wgs2swiss / swiss2wgs: (f64, f64, f32) arrays of one shape -> (f64, f64, f32)"""
+    if (a.shape != b.shape) or (b.shape != c.shape):
+        raise ValueError("Inconsistent shapes / number of dimensions of "
+                         + "input arrays")
+    if ((a.dtype != "float64") or (b.dtype != "float64")
+            or (c.dtype != "float32")):
+        raise ValueError("Input array(s) has/have incorrect data type(s)")
+    shp = a.shape
+    a, b, c = (np.ascontiguousarray(v).ravel() for v in (a, b, c))
+    o0, o1, o2 = np.empty(a.size, np.float64), np.empty(a.size, np.float64), np.empty(a.size, np.float32)
+    _lib.check(getattr(_lib.lib(), sym)(ptr(a), ptr(b), ptr(c), a.size, ptr(o0), ptr(o1), ptr(o2), device))
+    return o0.reshape(shp), o1.reshape(shp), o2.reshape(shp)
+
+
+def wgs2swiss(lon, lat, h_wgs, *, device=0):
+    """Ellipsoidal WGS84 longitude / latitude [degree] (float64) and height above the ellipsoid (float32) to Swiss
+    projection coordinates LV95: ``e``, ``n`` [metre] (float64) and ``h_ch`` (float32).  Arguments, checks and
+    formulas as the reference (transform.pyx:266-345)."""
+    return _triple(lon, lat, h_wgs, "hz_wgs2swiss", device=device)
+
+
+def swiss2wgs(e, n, h_ch, *, device=0):
+    """Swiss projection coordinates LV95 [metre] (float64, height float32) to WGS84 longitude / latitude [degree]
+    (float64) and height above the ellipsoid (float32); reference transform.pyx:349-432."""
+    return _triple(e, n, h_ch, "hz_swiss2wgs", device=device)
 
 
 def rotation_matrix_glob2loc(vec_north_enu, vec_norm_enu):

@@ -223,6 +223,12 @@ int hz_slope_vector_meth(const float *x, const float *y, const float *z, int len
 /* _lonlat2ecef_1d, transform.pyx:60-103: lon, lat f64[n] [degree], h f32[n] -> f64[n] x 3      */
 int hz_lonlat2ecef(const double *lon, const double *lat, const float *h, size_t n, int ellps,
                    double *x_ecef, double *y_ecef, double *z_ecef, int device);
+/* _wgs2swiss_1d, transform.pyx:306-345: lon, lat f64[n] [degree], h_wgs f32[n] -> LV95 e, n f64[n] [m], */
+/* h_ch f32[n]; _swiss2wgs_1d, transform.pyx:390-432: the inverse (swisstopo's approximate formulas)  */
+int hz_wgs2swiss(const double *lon, const double *lat, const float *h_wgs, size_t n,
+                 double *e, double *n_out, float *h_ch, int device);
+int hz_swiss2wgs(const double *e, const double *n_in, const float *h_ch, size_t n,
+                 double *lon, double *lat, float *h_wgs, int device);
 /* _ecef2enu_1d with TransformerEcef2enu(lon_or, lat_or, ellps), transform.pyx:152-189, 438-487 */
 int hz_ecef2enu(const double *x_ecef, const double *y_ecef, const double *z_ecef, size_t n,
                 double lon_or, double lat_or, int ellps, float *x_enu, float *y_enu, float *z_enu,

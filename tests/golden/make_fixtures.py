@@ -122,3 +122,17 @@ for ellps in ("sphere", "GRS80", "WGS84"):
                 k + "tilt_plane_rot": t_plane_rot, k + "tilt_vector": t_vec, k + "tilt_vector_rot": t_vec_rot})
 np.savez_compressed(os.path.join(here, "prep_reference.npz"), **{k: np.asarray(v) for k, v in out.items()})
 print("prep fixtures:", len(out), "arrays")
+
+# ---- Swiss projection (LV95) <-> WGS84 (transform.pyx:266-432) and auxiliary.pad_buffer ---------------------
+rng = np.random.default_rng(20220622)
+sw = {}
+lon = rng.uniform(5.8, 10.6, (9, 13)); lat = rng.uniform(45.7, 47.9, (9, 13))
+h = rng.uniform(190.0, 4600.0, (9, 13)).astype(np.float32)
+e, n, h_ch = transform.wgs2swiss(lon, lat, h)
+sw.update(lon=lon, lat=lat, h_wgs=h, e=np.asarray(e), n=np.asarray(n), h_ch=np.asarray(h_ch))
+e2 = rng.uniform(2.48e6, 2.84e6, 57); n2 = rng.uniform(1.07e6, 1.30e6, 57)
+h2 = rng.uniform(190.0, 4600.0, 57).astype(np.float32)
+lo2, la2, hw2 = transform.swiss2wgs(e2, n2, h2)
+sw.update(e2=e2, n2=n2, h_ch2=h2, lon2=np.asarray(lo2), lat2=np.asarray(la2), h_wgs2=np.asarray(hw2))
+np.savez_compressed(os.path.join(here, "swiss_reference.npz"), **sw)
+print("swiss_reference.npz:", {k: (v.dtype.name, v.shape) for k, v in sw.items()})

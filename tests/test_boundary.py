@@ -280,3 +280,20 @@ def test_library_never_destroys_a_stream():
     out = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
     assert "hipStreamCreateWithFlags" in out
     assert "hipStreamDestroy" not in out
+
+
+def test_pad_buffer_mirrors_the_reference():
+    """auxiliary.pad_buffer (reference auxiliary.py:100-135): >= 16 zero elements appended, byte size a multiple of 16."""
+    from horayzon_amd import auxiliary
+    for dtype, n, want in ((np.float32, 4, 20), (np.float32, 5, 24), (np.int32, 7, 24), (np.float64, 3, 20),
+                           (np.float32, 16, 32)):
+        b = np.arange(1, n + 1).astype(dtype)
+        p = auxiliary.pad_buffer(b)
+        assert p.dtype == dtype and len(p) == want and p.nbytes % 16 == 0
+        assert np.array_equal(p[:n], b) and not p[n:].any()
+    with pytest.raises(ValueError):
+        auxiliary.pad_buffer([1.0, 2.0])
+    with pytest.raises(ValueError):
+        auxiliary.pad_buffer(np.zeros((2, 2), np.float32))
+    import horayzon
+    assert horayzon.auxiliary.pad_buffer is auxiliary.pad_buffer

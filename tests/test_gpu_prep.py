@@ -38,6 +38,27 @@ def test_slope_planar(hip):
     assert np.abs(np.linalg.norm(tp[1:-1, 1:-1], axis=2) - 1.0).max() < 1e-6
 
 
+def test_swiss_projection_against_reference_fixture(hip):
+    """wgs2swiss / swiss2wgs (transform.pyx:266-432) against values the reference itself produced
+    (tests/golden/make_fixtures.py), and the round trip within the accuracy of swisstopo's approximate formulas."""
+    d = np.load(os.path.join(os.path.dirname(GOLD), "swiss_reference.npz"))
+    T = hip.transform
+    e, n, h = T.wgs2swiss(d["lon"], d["lat"], d["h_wgs"])
+    assert e.dtype == n.dtype == np.float64 and h.dtype == np.float32 and e.shape == d["lon"].shape
+    assert np.abs(e - d["e"]).max() <= 1e-8 and np.abs(n - d["n"]).max() <= 1e-8      # metres, float64
+    assert np.abs(h - d["h_ch"]).max() <= 5e-4                                           # float32 at ~4 km
+    lon, lat, hw = T.swiss2wgs(d["e2"], d["n2"], d["h_ch2"])
+    assert np.abs(lon - d["lon2"]).max() <= 1e-13 and np.abs(lat - d["lat2"]).max() <= 1e-13
+    assert np.abs(hw - d["h_wgs2"]).max() <= 5e-4
+    lon_b, lat_b, h_b = T.swiss2wgs(e, n, h)                          # approximate formulas: a few metres at the rim
+    assert np.abs(lon_b - d["lon"]).max() <= 1e-4 and np.abs(lat_b - d["lat"]).max() <= 1e-4
+    assert np.abs(h_b - d["h_wgs"]).max() <= 0.5
+    with pytest.raises(ValueError):
+        T.wgs2swiss(d["lon"], d["lat"], d["h_wgs"].astype(np.float64))
+    with pytest.raises(ValueError):
+        T.swiss2wgs(d["e2"][:5], d["n2"], d["h_ch2"])
+
+
 @pytest.mark.parametrize("ellps", ("sphere", "GRS80", "WGS84"))
 def test_input_preparation_chain(hip, ellps):
     d = np.load(GOLD)
