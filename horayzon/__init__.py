@@ -1,8 +1,8 @@
 """Drop-in alias: ``import horayzon`` resolves the hot-path modules
 (``horizon``, ``shadow``, ``topo_param`` sky view factor / slope, and the ``transform`` /
-``direction`` routines and ``auxiliary.rearrange_pad_buffer`` that prepare curved-DEM input) to the MI355X
-implementation in ``horayzon_amd``.  Everything else of the reference package
-(DEM loaders, transforms, ...) is out of scope."""
+``direction`` / ``auxiliary`` routines that prepare the input) to the MI355X implementation in ``horayzon_amd``.
+Everything else of the reference package (DEM and geoid loaders, ocean masking, domain helpers: file and network
+I/O) is out of scope."""
 import sys as _sys
 
 from horayzon_amd import auxiliary, direction, horizon, shadow, topo_param, transform   # noqa: F401
