@@ -297,3 +297,33 @@ def test_pad_buffer_mirrors_the_reference():
         auxiliary.pad_buffer(np.zeros((2, 2), np.float32))
     import horayzon
     assert horayzon.auxiliary.pad_buffer is auxiliary.pad_buffer
+
+
+def test_bench_roofline_arithmetic():
+    """bench.py's roofline object from known counters: achieved = wave-level VALU instructions / kernel time, peak as
+    handed in, frac = achieved / peak; HBM pair from the stamped traffic file only when it matches the run."""
+    import types
+    import bench
+    from horayzon_amd import _lib
+    args = types.SimpleNamespace()
+    st = _lib.hz_stats(); st.t_kernel_s = 4.0; st.num_rays = 2 * 10 ** 10; st.num_cells = 2 * 12737761; st.t_svf_s = 0.06
+    cw = _lib.hz_stats(); cw.num_rays = 10 ** 10; cw.nodes_visited = 22 * 10 ** 10; cw.tris_tested = 6 * 10 ** 10
+    cw.wave_node_iters = 5 * 10 ** 9; cw.wave_leaf_iters = 10 ** 9; cw.wave_refills = 5 * 10 ** 8
+    peaks = {"valu_winst_per_s": 6.144e11, "valu_winst_per_s_measured": 6.0e11, "simds": 1024, "clock_ghz": 2.4,
+             "cycles_per_wave_inst_measured": 4.096, "copy_gbs": 4600.0}
+    r = bench.roofline(args, st, 2, cw, peaks, 360, 3601, 3569)
+    m = r["valu_model_constants"]
+    winst = 5e9 * m["node_iter"] + 1e9 * m["leaf_iter"] + 5e8 * m["refill_iter"]      # per launch: rays per launch = cw rays
+    assert r["bound"] == "valu_issue" and r["unit"] == "G wave-instructions/s"
+    assert abs(r["valu_winst_per_launch"] - winst) <= 1e-6 * winst
+    assert abs(r["achieved"] - winst / 2.0 / 1e9) <= 1e-6 * r["achieved"] and r["peak"] == 614.4
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel_ms_per_launch"] == 2000.0
+    assert r["nodes_per_ray"] == 22.0 and r["tris_per_ray"] == 6.0
+    if r["traffic"] is not None:          # stamped for these kernel sources and this launch shape
+        assert abs(r["hbm"]["hbm_frac"] - r["traffic"] / 2.0 / 1e9 / 8000.0) < 1e-12
+    # another launch shape: the measured traffic does not apply
+    r2 = bench.roofline(args, st, 2, cw, peaks, 360, 3601, 512)
+    assert r2["traffic"] is None and r2["hbm"]["hbm_frac"] is None
+    # no counter pass: only the HBM view
+    r3 = bench.roofline(args, st, 2, None, None, 360, 3601, 3569)
+    assert r3["bound"] == "hbm" and r3["peak"] == bench.HBM_PEAK_GBS
