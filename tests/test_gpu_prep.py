@@ -241,9 +241,10 @@ def test_device_resident_chain_equals_host_chain(hip, orc):
     assert np.array_equal(r["shadow"].cpu().numpy(), sh)
 
 
-def test_device_resident_chain_on_the_c3_tile(hip):
-    """The same chain at config-3 size (3601 x 3601 one-arc-second tile on the WGS84 ellipsoid), timed: raw tile in
-    HBM -> everything up to the scene, then a 64-row slab of horizon + SVF and one shadow mask."""
+def test_device_resident_chain_on_the_c3_tile(hip, orc):
+    """The same chain at config-3 size (3601 x 3601 one-arc-second tile on the WGS84 ellipsoid: the CURVED variant of
+    config 3), timed: raw tile in HBM -> everything up to the scene, then a 64-row slab of horizon + SVF and one shadow
+    mask.  Two rows of the slab are checked against the oracle, bit for bit."""
     torch = pytest.importorskip("torch")
     import json
     import time
@@ -264,5 +265,11 @@ def test_device_resident_chain_on_the_c3_tile(hip):
     # curved-earth frames: normals tilt away from the ENU z axis towards the tile edges
     vn = r["vec_norm"]
     assert float(vn[..., 2].min().item()) < 0.99999 and abs(float((vn ** 2).sum(-1).mean().item()) - 1.0) < 1e-6
+    # the oracle on the device-prepared curved geometry (non axis-aligned frames at full size)
+    xe, ye, ze = (r[k].cpu().numpy() for k in ("xe", "ye", "ze"))
+    ref, _, so = orc.horizon_gridded(synth.pack_vertices(xe, ye, ze), n, n, r["vec_norm"].cpu().numpy(),
+                                     r["vec_north"].cpu().numpy(), off, off, dist_search=50.0, azim_num=360,
+                                     rows=(1760, 1762), slab_only=True, return_stats=True)
+    assert np.array_equal(r["hori"][:2].cpu().numpy(), ref) and so["guards"] == 0
     print(json.dumps({"chain_wall_s": wall, "bvh_build_s": r["scene"].stats["t_bvh_s"], "slab_kernel_s": st.t_kernel_s,
                       "slab_cells_per_s": st.num_cells / st.t_kernel_s, "rays_per_cell_azimuth": st.num_rays / (st.num_cells * 360.0)}))
