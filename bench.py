@@ -97,6 +97,9 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
+    # (several ranks may share a GPU when the multi-rank code path is exercised on a box with fewer GPUs than ranks:
+    #  HZ_DIST_BACKEND=gloo, since RCCL refuses two ranks on one device)
+    local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     # HZ_FORCE_DIST=1 runs the multi-rank code path (RCCL broadcast of the scene, gather, all-reduce)
     # even with a single rank -- used to exercise it on a 1-GPU box
@@ -106,7 +109,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda:%d" % local_rank))
+        backend = os.environ.get("HZ_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda:%d" % local_rank))
+        else:
+            dist.init_process_group(backend)
     ctx = dict(args=args, world=world, rank=rank, local_rank=local_rank, use_dist=use_dist,
                dev="cuda:%d" % local_rank)
     out = run_c5(ctx) if args.workload == "c5" else run_c3(ctx)

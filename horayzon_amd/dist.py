@@ -95,6 +95,13 @@ def broadcast_scene(scene, device, src=0, group=None, *, to_tensor=None, adopt=N
     return _lib.Scene.adopt(buf.data_ptr(), int(buf.numel()), device, keepalive=buf)
 
 
+def _host_staged(t, group):
+    """gloo moves only CPU tensors for gather / all_gather: a CUDA tensor on a gloo group (several ranks sharing one
+    GPU in a test) goes through host memory; on RCCL the tensor is used as it is."""
+    import torch.distributed as dist
+    return t.cpu() if (t.is_cuda and dist.get_backend(group) == "gloo") else t
+
+
 def gather_rows(local, slabs, dst=0, group=None):
     """Gather per-rank row slabs (torch tensors, leading axis = rows of the slab; ``None`` for an
     empty slab) into the full array on ``dst``.  CUDA tensors (RCCL) and CPU tensors (gloo).
@@ -107,6 +114,8 @@ def gather_rows(local, slabs, dst=0, group=None):
     if local is None:
         raise ValueError("gather_rows needs a (possibly 0-row) tensor on every rank")
     tail = tuple(local.shape[1:])
+    dev = local.device
+    local = _host_staged(local, group)
     padded = torch.zeros((max_rows,) + tail, dtype=local.dtype, device=local.device)
     padded[:local.shape[0]] = local
     out = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
@@ -118,7 +127,7 @@ def gather_rows(local, slabs, dst=0, group=None):
         out = allv if rank == dst else None
     if rank != dst:
         return None
-    return torch.cat([out[r][:slabs[r][1] - slabs[r][0]] for r in range(world)], dim=0)
+    return torch.cat([out[r][:slabs[r][1] - slabs[r][0]] for r in range(world)], dim=0).to(dev)
 
 
 def sharded_rows(mask, compute, *, sync=None, dst=0, group=None, gather=True):
@@ -140,8 +149,7 @@ def sharded_rows(mask, compute, *, sync=None, dst=0, group=None, gather=True):
     if sync is not None:
         sync()
     t_compute = time.perf_counter() - t0
-    dev = local.device
-    t = torch.tensor([t_compute], dtype=torch.float64, device=dev)
+    t = _host_staged(torch.tensor([t_compute], dtype=torch.float64, device=local.device), group)
     ts = [torch.empty_like(t) for _ in range(world)]
     dist.all_gather(ts, t, group=group)
     t_ranks = [float(x.item()) for x in ts]
