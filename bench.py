@@ -24,6 +24,16 @@ ranks after ONE broadcast of the scene blob; each rank computes its slab (chunke
 the SVF is gathered on rank 0.  The timed region is the whole sharded job; `--steps` repeats it.
 Reports cells/s, scene_bcast_s and the measured load imbalance (slowest rank / mean rank).
 
+c5 is built for the first real 8-GPU run: only rank 0 synthesises the mosaic; the blob is broadcast straight out of
+its allocation (no second copy); every rank derives the per-cell inputs of ITS slab on the device from the vertex
+array inside the blob and passes them slab-local (opts.inputs_are_slab); the slabs are balanced by COST -- a sampled
+pre-pass of one-row counting launches, split over the ranks (dist.estimate_row_cost) -- and both the predicted and the
+measured load imbalance are reported.  `--emulate-ranks R` (one GPU) computes the R slabs of such a partition one
+after the other and reports their times: the load balance an R-GPU run would see, measured without R GPUs.
+
+--workload c4 (BASELINE.json config 4): Terrain.shadow over 144 diurnal sun positions of the c3 tile, outputs resident
+in HBM; a step = one pass over all sun positions; its own roofline (shadow kernel).
+
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -52,7 +62,16 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--workload", choices=("c3", "c5"), default="c3")
+    ap.add_argument("--workload", choices=("c3", "c4", "c5"), default="c3")
+    ap.add_argument("--no-e2e", action="store_true", help="c3: skip the untimed NumPy-in / NumPy-out call of horizon_gridded")
+    ap.add_argument("--suns", type=int, default=144, help="c4: sun positions per step")
+    ap.add_argument("--refrac", type=int, default=0, help="c4: atmospheric refraction on (1) / off (0)")
+    ap.add_argument("--which", choices=("shadow", "sw_dir_cor"), default="shadow", help="c4: output kind")
+    ap.add_argument("--balance", choices=("cost", "cells"), default="cost", help="c5: how the row slabs are balanced")
+    ap.add_argument("--cost-samples", type=int, default=0, help="c5: probe rows of the cost pre-pass (0: max(16, 4 x ranks))")
+    ap.add_argument("--emulate-ranks", type=int, default=0, help="c5, one GPU: time the slabs of an R-rank partition one by one")
+    ap.add_argument("--dump-svf-rows", default="", help="c5: comma separated inner-domain rows of the gathered SVF to save")
+    ap.add_argument("--dump-path", default="", help="c5: .npy file for --dump-svf-rows")
     ap.add_argument("--rows-per-step", type=int, default=0, help="inner-domain rows per step (0: the whole tile in one launch)")
     ap.add_argument("--tile", type=int, default=None, help="DEM size (3601 for c3, 14401 for c5)")
     ap.add_argument("--azim", type=int, default=360)
@@ -116,7 +135,7 @@ def main():
             dist.init_process_group(backend)
     ctx = dict(args=args, world=world, rank=rank, local_rank=local_rank, use_dist=use_dist,
                dev="cuda:%d" % local_rank)
-    out = run_c5(ctx) if args.workload == "c5" else run_c3(ctx)
+    out = {"c3": run_c3, "c4": run_c4, "c5": run_c5}[args.workload](ctx)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -137,7 +156,7 @@ def make_scene(ctx, g, n):
     import horayzon_amd as hz
     from horayzon_amd.dist import broadcast_scene
     t0 = time.time()
-    scene = hz.Scene.create(g["vert_grid"], n, n, device=ctx["local_rank"]) if ctx["rank"] == 0 else None
+    scene = hz.Scene.create(g["vert_grid"], n, n, device=ctx["local_rank"]) if ctx["rank"] == 0 else None   # g: rank 0 only
     t_build = time.time() - t0
     scene_stats = scene.stats if scene is not None else None
     t_bcast = 0.0
@@ -269,12 +288,42 @@ def run_c3(ctx):
                    "parallelism": "weak scaling x%d: same step sequence, rank r starts at step r K; scene broadcast once" % world,
                    "bvh_build_s": scene_stats["t_bvh_s"] if scene_stats else None,
                    "scene_bytes": int(blob_bytes), "scene_bcast_s": t_bcast, "scene_create_wall_s": t_build,
-                   "load_imbalance_max_over_mean": imbalance, "near_prepass_ms_per_step": 1e3 * stats.t_near_s / max(steps, 1)},
+                   "load_imbalance_max_over_mean": imbalance, "near_prepass_ms_per_step": 1e3 * stats.t_near_s / max(steps, 1),
+                   # the reference's searches do not terminate where these fire (horizon_comp.cpp:474-488, README.md:209-213):
+                   # rim cells whose rays leave the DEM below the lowest table angle; this library stops them and counts
+                   "guard_events_per_step": stats.guard_events / max(steps, 1),
+                   "guard_cells_per_step": stats.guard_cells / max(steps, 1),
+                   "stack_fallbacks": int(stats.stack_fallbacks), "stack_redo_blocks": int(stats.stack_redo_blocks),
+                   "height_field": int(stats.height_field), "near_certificates_used": int(stats.near_used)},
         "roofline": roofline(args, stats, steps, cw, peaks, A, n, rps),
     }
+    if world == 1 and not args.no_e2e:
+        # free the resident buffers of the timed region first: the drop-in call allocates its own
+        del d_hori, d_svf, d_tilt, d_norm, d_north, d_mask
+        torch.cuda.empty_cache()
+        out["config"]["e2e_numpy_call"] = e2e_numpy_call(g, vec_tilt_h, args, A)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(g, args, A)
     return out
+
+
+def e2e_numpy_call(g, vec_tilt, args, A):
+    """UNTIMED (not part of `value`): the drop-in call as a user of the reference makes it -- NumPy in, NumPy out
+    (horizon.pyx:170-197): vertices and per-cell inputs uploaded, BVH built, horizon traced in chunks that are
+    copied into the caller's 18 GB array behind the next chunk's kernel, SVF fused."""
+    import horayzon_amd as hz
+    kw = {k: g[k] for k in ("vert_grid", "dem_dim_0", "dem_dim_1", "vec_norm", "vec_north", "offset_0", "offset_1")}
+    t0 = time.perf_counter()
+    hori, azim, svf = hz.horizon.horizon_gridded(**kw, dist_search=args.dist_search, azim_num=A, svf_vec_tilt=vec_tilt)
+    wall = time.perf_counter() - t0
+    st = hz.horizon.last_stats
+    ok = bool(np.isfinite(hori[::97, ::89]).all() and np.isfinite(svf).all())
+    return {"wall_s": wall, "lib_total_s": st["t_total_s"], "h2d_s": st["t_h2d_s"], "bvh_build_s": st["t_bvh_s"],
+            "kernel_s": st["t_kernel_s"], "near_prepass_s": st["t_near_s"], "svf_s": st["t_svf_s"],
+            "d2h_tail_s": st["t_d2h_s"], "out_gb": hori.nbytes / 1e9, "cells_per_s_e2e": st["num_cells"] / wall,
+            "finite": ok,
+            "note": "untimed, outside `value`: NumPy in / NumPy out through horayzon.horizon.horizon_gridded; "
+                    "d2h_tail_s is the part of the device-to-host copy that did not hide behind the kernels"}
 
 
 def roofline(args, stats, steps, cw, peaks, A, n, rps):
@@ -349,56 +398,101 @@ def roofline(args, stats, steps, cw, peaks, A, n, rps):
 # ------------------------------------------------------------------------------------------------
 # config 5: the 14401^2 mosaic, SVF-fused, row-sharded over the ranks
 # ------------------------------------------------------------------------------------------------
+def _tilt_rows_device(verts, off, in1, b, e):
+    """vec_tilt of inner-domain rows [b, e) from the vertex array inside the blob, on the device: the same centred
+    differences (float64) as synth.tilt_from_planar_dem -- a stand-in for topo_param.slope_plane_meth."""
+    import torch
+    z = verts[b + off - 1:e + off + 1, off - 1:off + in1 + 1, 2].double()
+    x = verts[0, off - 1:off + in1 + 1, 0].double()
+    y = verts[b + off - 1:e + off + 1, 0, 1].double()
+    dzdx = (z[1:-1, 2:] - z[1:-1, :-2]) / (x[2:] - x[:-2])[None, :]
+    dzdy = (z[2:, 1:-1] - z[:-2, 1:-1]) / (y[2:] - y[:-2])[:, None]
+    nrm = torch.sqrt(dzdx * dzdx + dzdy * dzdy + 1.0)
+    t = torch.stack([-dzdx / nrm, -dzdy / nrm, 1.0 / nrm], dim=2).float()
+    t = t / torch.sqrt((t.double() ** 2).sum(dim=2, keepdim=True)).float()
+    return t.contiguous()
+
+
 def run_c5(ctx):
     import torch
     import torch.distributed as dist
     from horayzon_amd import _lib, synth
-    from horayzon_amd.dist import sharded_rows, row_slabs
+    from horayzon_amd.dist import (sharded_rows, row_slabs, estimate_row_cost, predicted_imbalance,
+                                   device_bytes_tensor)
     args, rank, world, dev = ctx["args"], ctx["rank"], ctx["world"], ctx["dev"]
     L = _lib.lib()
     n, off, A = args.tile or 14401, 16, args.azim
     steps = args.steps if args.steps is not None else 1
     warmup = args.warmup if args.warmup is not None else 1
-    g = synth.fractal_tile(n=n, offset=off)       # every rank generates the same seeded mosaic
     in0 = in1 = n - 2 * off
+    # only the building rank synthesises the mosaic; everybody else receives vertices + LBVH in the one broadcast
+    g = synth.fractal_tile(n=n, offset=off) if rank == 0 else None
     scene, scene_stats, t_build, t_bcast = make_scene(ctx, g, n)
+    del g
     blob_ptr, blob_bytes = scene.blob()
-    vec_tilt_h, _ = synth.tilt_from_planar_dem(g["x"], g["y"], g["z"], off)
-    d_tilt = torch.from_numpy(vec_tilt_h).to(dev)
-    del vec_tilt_h, g
-    d_norm = torch.zeros((in0, in1, 3), dtype=torch.float32, device=dev); d_norm[..., 2] = 1.0
-    d_north = torch.zeros((in0, in1, 3), dtype=torch.float32, device=dev); d_north[..., 1] = 1.0
-    mask_h = np.ones((in0, in1), np.uint8)
-    d_mask = torch.from_numpy(mask_h).to(dev)
+    vptr, d0, d1, height_field = scene.vertices()
+    verts = device_bytes_tensor(vptr, d0 * d1 * 12, ctx["local_rank"], owner=scene).view(torch.float32).view(d0, d1, 3)
     stats = _lib.hz_stats()
 
-    def compute(b, e, st=None):
+    def slab_inputs(b, e):
+        """Per-cell inputs of rows [b, e) only, made on this rank's GPU (planar frames; tilt from the blob's vertices)."""
+        norm = torch.zeros((e - b, in1, 3), dtype=torch.float32, device=dev); norm[..., 2] = 1.0
+        north = torch.zeros((e - b, in1, 3), dtype=torch.float32, device=dev); north[..., 1] = 1.0
+        mask = torch.ones((e - b, in1), dtype=torch.uint8, device=dev)
+        return norm, north, mask, _tilt_rows_device(verts, off, in1, b, e)
+
+    def run_slab(b, e, st, azim=A, count=False):
         svf = torch.full((max(e - b, 0), in1), float("nan"), dtype=torch.float32, device=dev)
         if e <= b:
             return svf
+        norm, north, mask, tilt = slab_inputs(b, e)
         opts = _lib.hz_opts()
         opts.device = ctx["local_rank"]
         opts.top_nodes = -1; opts.regroup = -1
-        opts.vec_tilt = d_tilt.data_ptr()
+        opts.vec_tilt = tilt.data_ptr()
         opts.svf = svf.data_ptr()
-        opts.hori_is_slab = 1
+        opts.hori_is_slab = 1; opts.inputs_are_slab = 1
         opts.skip_hori = 1                       # the horizon lives in a bounded device buffer, chunk by chunk
+        opts.count_work = int(count)
         opts.row_begin, opts.row_end = b, e
-        rc = L.hz_horizon_gridded_scene(scene._h, d_norm.data_ptr(), d_north.data_ptr(), off, off, None, in0, in1, A,
-                                        args.dist_search, 0.25, b"guess_constant", -15.0, d_mask.data_ptr(), 0.0,
-                                        0.01, C.byref(opts), C.byref(st if st is not None else stats))
+        rc = L.hz_horizon_gridded_scene(scene._h, norm.data_ptr(), north.data_ptr(), off, off, None, in0, in1, azim,
+                                        args.dist_search, 0.25, b"guess_constant", -15.0, mask.data_ptr(), 0.0,
+                                        0.01, C.byref(opts), C.byref(st))
         _lib.check(rc)
         return svf
 
-    slabs = row_slabs(mask_h, world)
+    def compute(b, e):
+        return run_slab(b, e, stats)
+
+    # cost of one row: wave-level VALU work of a counting launch with an eighth of the azimuths
+    a_probe = max(8, (A // 8) // 4 * 4)
+    probe_s = [0.0]
+
+    def probe(row):
+        t0 = time.perf_counter()
+        st = _lib.hz_stats()
+        run_slab(row, row + 1, st, azim=a_probe, count=True)
+        probe_s[0] += time.perf_counter() - t0
+        m = VALU_MODEL_DEFAULT
+        return m["node_iter"] * st.nodes_visited + 0.5 * m["leaf_iter"] * st.tris_tested + m["refill_iter"] * st.num_rays
+
+    n_samples = args.cost_samples or max(16, 4 * max(world, args.emulate_ranks))
+
+    slab0 = row_slabs(in0, world)[rank]
     for w in range(warmup):      # a short slab of this rank's rows: clocks, allocator
-        b, e = slabs[rank]
-        compute(b, min(b + 64, e), _lib.hz_stats())
+        run_slab(slab0[0], min(slab0[0] + 64, slab0[1]), _lib.hz_stats())
+    if args.emulate_ranks > 1:
+        return emulate_ranks(ctx, in0, in1, run_slab, probe, n_samples, blob_bytes)
     barrier(ctx)
     t0 = time.perf_counter()
-    res = None
+    res, cost, t_cost = None, None, 0.0
     for s in range(steps):
-        res = sharded_rows(mask_h, compute, sync=torch.cuda.synchronize, dst=0)
+        probe_s[0] = 0.0
+        if args.balance == "cost" and (world > 1 or os.environ.get("HZ_FORCE_COST")):
+            tc0 = time.perf_counter()
+            cost = estimate_row_cost(in0, probe, samples=n_samples)
+            t_cost = time.perf_counter() - tc0
+        res = sharded_rows(in0, compute, sync=torch.cuda.synchronize, dst=0, cost=cost)
     barrier(ctx)
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -412,6 +506,9 @@ def run_c5(ctx):
     svf_ok = None
     if res is not None and res["full"] is not None:
         svf_ok = bool(torch.isfinite(res["full"]).all().item()) and tuple(res["full"].shape) == (in0, in1)
+        if args.dump_svf_rows and args.dump_path:
+            rows = [int(r) for r in args.dump_svf_rows.split(",")]
+            np.save(args.dump_path, res["full"][rows].cpu().numpy())
     return {
         "metric": "grid_cells_per_s (horizon_gridded + SVF, 360 azimuths, 4x4 mosaic of 3601^2 SRTM-like tiles)",
         "value": cells_total / elapsed, "unit": "cells/s", "mray_per_s": rays_total / elapsed / 1e6,
@@ -420,17 +517,146 @@ def run_c5(ctx):
         "config": {"workload": "c5: horizon_gridded guess_constant, SVF-fused (horizon never materialised), %dx%d synthetic "
                                "mosaic, %d azimuths, dist_search %g km; one step = the whole inner domain (%d x %d cells)"
                                % (n, n, A, args.dist_search, in0, in1),
-                   "parallelism": "row slabs over %d ranks (dist.row_slabs), scene broadcast once, SVF gathered on rank 0" % world,
+                   "parallelism": "row slabs over %d ranks (dist.row_slabs, balanced by %s), scene broadcast once out of "
+                                  "the blob allocation, slab-local inputs made on each rank's GPU, SVF gathered on rank 0"
+                                  % (world, "sampled cost" if cost is not None else "cell count"),
                    "slabs": res["slabs"] if res else None, "t_ranks_s": res["t_ranks"] if res else None,
                    "load_imbalance_max_over_mean": res["imbalance"] if res else None,
+                   "load_imbalance_predicted": res["imbalance_predicted"] if res else None,
+                   "load_imbalance_predicted_if_balanced_by_cells":
+                       predicted_imbalance(row_slabs(in0, world), cost) if cost is not None else None,
+                   "cost_prepass_s": t_cost, "cost_prepass_probe_rows": n_samples if cost is not None else 0,
+                   "cost_prepass_probe_azimuths": a_probe,
                    "bvh_build_s": scene_stats["t_bvh_s"] if scene_stats else None, "scene_bytes": int(blob_bytes),
-                   "scene_bcast_s": t_bcast, "scene_create_wall_s": t_build, "kernel_s_rank0": stats.t_kernel_s,
+                   "scene_bcast_s": t_bcast, "scene_bcast_zero_copy": True, "scene_create_wall_s": t_build,
+                   "kernel_s_rank0": stats.t_kernel_s,
                    "svf_kernel_s_rank0": stats.t_svf_s, "near_prepass_s_rank0": stats.t_near_s,
                    "stack_fallbacks_rank0": int(stats.stack_fallbacks), "stack_redo_blocks_rank0": int(stats.stack_redo_blocks),
-                   "gathered_svf_finite": svf_ok},
+                   "guard_events_rank0": int(stats.guard_events), "guard_cells_rank0": int(stats.guard_cells),
+                   "height_field": int(height_field), "gathered_svf_finite": svf_ok},
         "roofline": {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None,
                      "traffic": None, "note": "see the c3 line: same kernel; c5 reports scaling, not the kernel roofline"},
     }
+
+
+def emulate_ranks(ctx, in0, in1, run_slab, probe, n_samples, blob_bytes):
+    """One GPU: the R slabs of a cost-balanced and of a cell-count-balanced R-rank partition, computed one after the
+    other and timed -- max / mean of those times is the load imbalance an R-GPU run of this job would see (each slab
+    runs alone on the GPU, exactly as on its own rank)."""
+    import torch
+    from horayzon_amd import _lib
+    from horayzon_amd.dist import row_slabs, estimate_row_cost, predicted_imbalance
+    R = ctx["args"].emulate_ranks
+    t0 = time.perf_counter()
+    cost = estimate_row_cost(in0, probe, samples=n_samples)
+    t_cost = time.perf_counter() - t0
+    out = {"emulated_ranks": R, "cost_prepass_s_one_rank_doing_all_probes": t_cost, "probe_rows": n_samples}
+    total_cells, total_s = 0, 0.0
+    for name, slabs in (("cost", row_slabs(in0, R, cost)), ("cells", row_slabs(in0, R))):
+        ts = []
+        for b, e in slabs:
+            st = _lib.hz_stats()
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            run_slab(b, e, st)
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - t1)
+            total_cells += st.num_cells; total_s += ts[-1]
+        out[name] = {"slabs": slabs, "t_slab_s": ts, "imbalance_measured": max(ts) / (sum(ts) / len(ts)),
+                     "imbalance_predicted": predicted_imbalance(slabs, cost), "job_s_if_parallel": max(ts)}
+    return {"metric": "load balance of an emulated %d-rank c5 partition (one GPU, slabs timed one by one)" % R,
+            "value": total_cells / total_s, "unit": "cells/s", "n_gpus": 1, "steps": 1, "warmup": 0,
+            "ms_per_step": 1e3 * total_s, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic", "config": {"workload": "c5 --emulate-ranks %d" % R, **out,
+                                                            "scene_bytes": int(blob_bytes)},
+            "roofline": {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave-instructions/s",
+                         "frac": None, "traffic": None, "note": "load-balance probe, see the c3 line for the kernel"}}
+
+
+# ------------------------------------------------------------------------------------------------
+# config 4: shadow mask over one day of sun positions on the c3 tile
+# ------------------------------------------------------------------------------------------------
+def run_c4(ctx):
+    import torch
+    import horayzon_amd as hz
+    from horayzon_amd import _lib, synth
+    args, rank, world, dev = ctx["args"], ctx["rank"], ctx["world"], ctx["dev"]
+    n, off = args.tile or 3601, 16
+    S = args.suns
+    g = synth.fractal_tile(n=n, offset=off)
+    in0 = in1 = n - 2 * off
+    scene, scene_stats, t_build, t_bcast = make_scene(ctx, g, n)
+    vec_tilt, enl = synth.tilt_from_planar_dem(g["x"], g["y"], g["z"], off)
+    vec_norm, _ = synth.planar_frames(in0, in1)
+    elev = np.ascontiguousarray(g["z"][off:off + in0, off:off + in1])
+    mask = np.ones((in0, in1), np.uint8)
+    suns, alt, _ = synth.sun_positions(num=S)
+    terrain = hz.shadow.Terrain(device=ctx["local_rank"])
+    terrain.initialise(g["vert_grid"], n, n, off, off, vec_tilt, vec_norm, enl, elev, mask,
+                       refrac_cor=bool(args.refrac), scene=scene)
+    shadow = args.which == "shadow"
+    out = torch.empty((S, in0, in1), dtype=torch.uint8 if shadow else torch.float32, device=dev)   # resident output
+    fn = terrain.shadow_batch if shadow else terrain.sw_dir_cor_batch
+    steps = args.steps if args.steps is not None else 3
+    warmup = args.warmup if args.warmup is not None else 1
+    cw = None
+    if rank == 0 and not args.no_count:          # counter pass (untimed): node visits / triangle tests of all positions
+        terrain.count_work(True)
+        fn(suns, out)
+        cw = dict(terrain.last_stats)
+        terrain.count_work(False)
+    for w in range(warmup):
+        fn(suns, out)
+    barrier(ctx)
+    t_kernel, rays = 0.0, 0
+    t0 = time.perf_counter()
+    for s in range(steps):
+        fn(suns, out)
+        t_kernel += terrain.last_stats["t_kernel_s"]; rays += terrain.last_stats["num_rays"]
+    barrier(ctx)
+    elapsed = time.perf_counter() - t0
+    if ctx["use_dist"]:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        return None
+    cells = in0 * in1
+    k_step = t_kernel / max(steps, 1)
+    V = n * n
+    out_b = 1 if shadow else 4
+    # SURVEY 8(d) "shadow bytes": 12 V + 33 C once at initialise, 1 C (shadow) / 4 C (sw_dir_cor) per sun position;
+    # B_trav = rays x (node visits x 64 B + triangle tests x 24 B) from the counting pass
+    b_io = S * out_b * cells + (12.0 * V + 33.0 * cells)
+    b_trav = (cw["nodes_visited"] * 64.0 + cw["tris_tested"] * 24.0) if cw else 0.0
+    alg = (b_io + b_trav) / k_step / 1e9 if k_step else None
+    codes = None
+    if shadow:
+        o = out[S // 2].cpu().numpy()
+        codes = [float((o == c).mean()) for c in range(4)]
+    res = {
+        "metric": "grid_cells_per_s (Terrain.%s, %d sun positions, 3601^2 SRTM-like tile)" % (args.which, S),
+        "value": world * steps * S * cells / elapsed, "unit": "cells/s",
+        "mray_per_s": world * rays / elapsed / 1e6,
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / max(steps, 1),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "c4: Terrain.%s over %d diurnal sun positions (lat 46 N, day 172), %dx%d synthetic tile, "
+                               "refrac_cor=%s, outputs resident in HBM; a step = all %d positions"
+                               % (args.which, S, n, n, bool(args.refrac), S),
+                   "ms_per_sun_position": 1e3 * k_step / S, "rays_per_step": rays / max(steps, 1),
+                   "sun_alt_deg_minmax": [float(np.rad2deg(alt.min())), float(np.rad2deg(alt.max()))],
+                   "code_fractions_0123_at_noon": codes,
+                   "bvh_build_s": scene_stats["t_bvh_s"] if scene_stats else None},
+        "roofline": {"bound": "hbm", "kernel": "hz::k_shadow<false>", "kernel_ms_per_step": 1e3 * k_step,
+                     "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / HBM_PEAK_GBS if alg else None,
+                     "alg_bytes_per_step": b_io + b_trav, "io_bytes_per_step": b_io, "traffic": None,
+                     "nodes_per_ray": cw["nodes_visited"] / max(cw["num_rays"], 1) if cw else None,
+                     "tris_per_ray": cw["tris_tested"] / max(cw["num_rays"], 1) if cw else None,
+                     "lane_utilisation_node_leaf_steps":
+                         (cw["nodes_visited"] + cw["tris_tested"] / 2.0) / max(64.0 * (cw["wave_node_iters"] + cw["wave_leaf_iters"]), 1.0) if cw else None,
+                     "note": "algorithmic bytes are mostly cache-served node re-reads (SURVEY 8d); the kernel is VALU-issue "
+                             "bound like k_horizon (profiles/r02/pmc_shadow_summary.json: 81 % of the issue slots)"},
+    }
+    return res
 
 
 def cpu_baseline(g, args, A):

@@ -27,7 +27,8 @@ class hz_opts(C.Structure):
                 ("svf", C.c_void_p), ("vec_tilt", C.c_void_p),
                 ("skip_hori", C.c_int32), ("chunk_rows", C.c_int32),
                 ("level_stack", C.c_int32), ("hori_is_slab", C.c_int32),
-                ("no_near_skip", C.c_int32), ("verify_near", C.c_int32)]
+                ("no_near_skip", C.c_int32), ("verify_near", C.c_int32),
+                ("inputs_are_slab", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class hz_stats(C.Structure):
@@ -41,7 +42,8 @@ class hz_stats(C.Structure):
                 ("wave_leaf_iters", C.c_uint64), ("wave_refills", C.c_uint64),
                 ("t_svf_s", C.c_double), ("stack_fallbacks", C.c_uint64),
                 ("rays_shortened", C.c_uint64), ("near_violations", C.c_uint64), ("t_near_s", C.c_double),
-                ("stack_redo_blocks", C.c_uint64)]
+                ("stack_redo_blocks", C.c_uint64), ("guard_cells", C.c_uint64),
+                ("height_field", C.c_int32), ("near_used", C.c_int32)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -50,7 +52,7 @@ class hz_stats(C.Structure):
 # every symbol include/horayzon_hip.h declares (tests check that all are exported)
 SYMBOLS = (
     "hz_last_error", "hz_abi_struct_sizes", "hz_device_count", "hz_device_info",
-    "hz_scene_create", "hz_scene_blob", "hz_scene_adopt", "hz_scene_destroy",
+    "hz_scene_create", "hz_scene_blob", "hz_scene_vertices", "hz_scene_adopt", "hz_scene_destroy",
     "hz_horizon_gridded", "hz_horizon_gridded_scene", "hz_horizon_locations",
     "hz_horizon_locations_scene", "hz_horizon_tables",
     "hz_sky_view_factor", "hz_visible_sky_fraction", "hz_topographic_openness",
@@ -60,7 +62,7 @@ SYMBOLS = (
     "hz_debug_valu_peak", "hz_debug_copy_peak",
     "hz_terrain_create", "hz_terrain_initialise", "hz_terrain_initialise_scene",
     "hz_terrain_shadow", "hz_terrain_sw_dir_cor", "hz_terrain_shadow_batch",
-    "hz_terrain_sw_dir_cor_batch", "hz_terrain_destroy",
+    "hz_terrain_sw_dir_cor_batch", "hz_terrain_count_work", "hz_terrain_destroy",
 )
 
 
@@ -105,6 +107,7 @@ def lib():
     L.hz_scene_create.argtypes = [vp, ip, ip, C.c_char_p, vp, ip, vp, ip, ip,
                                   C.POINTER(vp), C.POINTER(hz_stats)]
     L.hz_scene_blob.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    L.hz_scene_vertices.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.hz_scene_adopt.argtypes = [vp, C.c_size_t, ip, C.POINTER(vp)]
     L.hz_scene_destroy.argtypes = [vp]
     L.hz_horizon_gridded.argtypes = [
@@ -149,6 +152,7 @@ def lib():
     L.hz_terrain_sw_dir_cor.argtypes = [vp, vp, vp, C.POINTER(hz_stats)]
     L.hz_terrain_shadow_batch.argtypes = [vp, vp, ip, vp, C.POINTER(hz_stats)]
     L.hz_terrain_sw_dir_cor_batch.argtypes = [vp, vp, ip, vp, C.POINTER(hz_stats)]
+    L.hz_terrain_count_work.argtypes = [vp, ip]
     L.hz_terrain_destroy.argtypes = [vp]
     for name in SYMBOLS:
         if name not in ("hz_last_error", "hz_vert_grid_len"):
@@ -231,6 +235,12 @@ class Scene:
         n = C.c_size_t()
         check(lib().hz_scene_blob(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
+
+    def vertices(self):
+        """(device pointer of the f32[d0 * d1][3] vertex array inside the blob, d0, d1, height_field)."""
+        p, d0, d1, hf = C.c_void_p(), C.c_int(0), C.c_int(0), C.c_int(0)
+        check(lib().hz_scene_vertices(self._h, C.byref(p), C.byref(d0), C.byref(d1), C.byref(hf)))
+        return p.value, d0.value, d1.value, bool(hf.value)
 
     def close(self):
         if getattr(self, "_h", None):

@@ -202,12 +202,14 @@ struct Terrain {
     bool own_tilt = false, own_norm = false, own_enl = false, own_elev = false, own_mask = false;
     float fill = 0, ang_max = 89.0f;
     int refrac = 0;
+    int count_work = 0;                       // hz_terrain_count_work
     unsigned long long *counters = nullptr;   // device u64[16]
     hipStream_t stream = nullptr;
     bool initialised = false;
 };
 
 static void terrain_release_arrays(Terrain *t) {
+    (void)hipSetDevice(t->device);
     if (t->own_tilt && t->tilt) (void)hipFree(t->tilt);
     if (t->own_norm && t->norm) (void)hipFree(t->norm);
     if (t->own_enl && t->enl) (void)hipFree(t->enl);
@@ -215,6 +217,8 @@ static void terrain_release_arrays(Terrain *t) {
     if (t->own_mask && t->mask) (void)hipFree(t->mask);
     t->tilt = t->norm = t->enl = t->elev = t->mask = nullptr;
     t->own_tilt = t->own_norm = t->own_enl = t->own_elev = t->own_mask = false;
+    // the counters live on the terrain's current GPU; a re-initialisation may move the terrain to another one
+    if (t->counters) { (void)hipFree(t->counters); t->counters = nullptr; }
     if (t->owns_scene && t->scene) scene_free(t->scene);
     t->scene = nullptr; t->owns_scene = false; t->initialised = false;
 }
@@ -247,13 +251,18 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     if (opts && opts->svf && !opts->vec_tilt) return set_error(HZ_ERR_ARG, "opts.svf needs opts.vec_tilt");
     // the SVF weights sectors by azim[1] - azim[0] (topo_param.pyx:433): undefined for a single azimuth
     if (opts && opts->svf && azim_num < 2) return set_error(HZ_ERR_ARG, "opts.svf needs azim_num >= 2");
+    // row slab (include/horayzon_hip.h): {0, 0} = the whole inner domain (a zeroed struct), row_end == -1 = dim_in_0,
+    // anything else must satisfy 0 <= row_begin <= row_end <= dim_in_0; begin == end is an empty slab: nothing to do
     int row_begin = 0, row_end = dim_in_0;
-    if (opts) {
-        if (opts->row_begin > 0) row_begin = opts->row_begin;
-        if (opts->row_end > 0) row_end = std::min(opts->row_end, dim_in_0);
+    if (opts && !(opts->row_begin == 0 && opts->row_end == 0)) {
+        row_begin = opts->row_begin;
+        row_end = (opts->row_end == -1) ? dim_in_0 : opts->row_end;
+        if (row_begin < 0 || row_end < 0 || row_end > dim_in_0 || row_begin > row_end)
+            return set_error(HZ_ERR_ARG, "invalid row slab [%d, %d) for dim_in_0 = %d", opts->row_begin, opts->row_end, dim_in_0);
+        if (row_begin == row_end) return HZ_OK;
     }
-    if (row_begin >= row_end) return set_error(HZ_ERR_ARG, "empty row slab [%d, %d)", row_begin, row_end);
     HZ_HIP(hipSetDevice(sc->device));
+    std::lock_guard<std::mutex> run_lock(sc->run_mu);     // one call at a time on a scene's stream and scratch
     hipStream_t st = sc->stream;
     Timer t_total; t_total.start();
 
@@ -269,10 +278,22 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     DevIn<float> d_norm, d_north, d_tilt, d_as, d_ac, d_ea, d_es, d_ec;
     DevIn<int> d_mid;
     DevIn<uint8_t> d_mask;
-    if ((rc = d_norm.bind(vec_norm, ncell * 3, st))) return rc;
-    if ((rc = d_north.bind(vec_north, ncell * 3, st))) return rc;
-    if ((rc = d_mask.bind(mask, ncell, st))) return rc;
-    if (opts && opts->svf) if ((rc = d_tilt.bind(opts->vec_tilt, ncell * 3, st))) return rc;
+    // Per-cell inputs: only the slab's rows are ever read, so only those are uploaded when the arrays are host memory.
+    // opts.inputs_are_slab: the four pointers address row_begin (a rank of a sharded job holds -- and uploads -- its own
+    // rows only); otherwise they address inner-domain row 0 (the reference's layout).  The kernels index by global
+    // cell: `in_off` shifts the slab-local device addresses back (address arithmetic only, never dereferenced outside
+    // the slab).
+    const bool inputs_are_slab = opts && opts->inputs_are_slab;
+    const size_t in_off = (size_t)row_begin * dim_in_1;
+    const size_t src_off = inputs_are_slab ? 0 : in_off;
+    (void)ncell;
+    if ((rc = d_norm.bind(vec_norm + 3 * src_off, slab_cells * 3, st))) return rc;
+    if ((rc = d_north.bind(vec_north + 3 * src_off, slab_cells * 3, st))) return rc;
+    if ((rc = d_mask.bind(mask + src_off, slab_cells, st))) return rc;
+    if (opts && opts->svf) if ((rc = d_tilt.bind(opts->vec_tilt + 3 * src_off, slab_cells * 3, st))) return rc;
+    const float *norm0 = d_norm.dev - 3 * in_off, *north0 = d_north.dev - 3 * in_off;
+    const uint8_t *mask0 = d_mask.dev - in_off;
+    const float *tilt0 = d_tilt.dev ? d_tilt.dev - 3 * in_off : nullptr;
     if ((rc = d_as.bind(tb.azim_sin.data(), (size_t)azim_num, st))) return rc;
     if ((rc = d_ac.bind(tb.azim_cos.data(), (size_t)azim_num, st))) return rc;
     if ((rc = d_ea.bind(tb.elev_ang.data(), (size_t)tb.elev_num, st))) return rc;
@@ -336,7 +357,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     const double h2d_s = t_h2d.stop();
 
     HorizonArgs a;
-    a.vec_norm = d_norm.dev; a.vec_north = d_north.dev; a.mask = d_mask.dev;
+    a.vec_norm = norm0; a.vec_north = north0; a.mask = mask0;
     a.offset_0 = offset_0; a.offset_1 = offset_1; a.dim_in_0 = dim_in_0; a.dim_in_1 = dim_in_1;
     a.azim_num = azim_num; a.elev_num = tb.elev_num; a.alg = alg;
     a.hori_acc = tb.hori_acc; a.low = tb.low; a.up = tb.up; a.dist = dist_m;
@@ -351,8 +372,12 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     // near-field certificates (hz_near.hip): one pre-pass per chunk into a scratch buffer kept with the scene.
     // Off with an outer-domain TIN (its triangles are not part of the height field the distance bound relies on),
     // beyond the azimuth count the pre-pass holds in LDS, and on request.
-    const bool use_near = !(opts && opts->no_near_skip) && sc->hdr.n_tin == 0 && azim_num <= near_max_azim() &&
-                          tb.elev_num <= 65534;
+    // Off, too, for a mesh that is not a height field over the world (x, y) plane (HZ_BLOB_HEIGHT_FIELD, checked by the
+    // scene build: the distance bound near_r assumes it); opts.no_near_skip < 0 overrides that check (tests only).
+    const int near_opt = opts ? opts->no_near_skip : 0;
+    const bool height_field = (sc->hdr.flags & HZ_BLOB_HEIGHT_FIELD) != 0;
+    const bool use_near = near_opt <= 0 && (height_field || near_opt < 0) && sc->hdr.n_tin == 0 &&
+                          azim_num <= near_max_azim() && tb.elev_num <= 65534;
     a.near_idx = nullptr; a.near_r = nullptr;
     a.tile_list = nullptr; a.n_list = 0;
     a.verify_near = (opts && opts->verify_near) ? 1 : 0;
@@ -412,7 +437,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
                 sc->near_bytes = need;
             }
             NearArgs na;
-            na.vec_norm = d_norm.dev; na.vec_north = d_north.dev; na.mask = d_mask.dev;
+            na.vec_norm = norm0; na.vec_north = north0; na.mask = mask0;
             na.azim_sin = d_as.dev; na.azim_cos = d_ac.dev;
             na.offset_0 = offset_0; na.offset_1 = offset_1; na.dim_in_1 = dim_in_1; na.row_begin = rb; na.row_end = re;
             na.azim_num = azim_num; na.elev_num = tb.elev_num;
@@ -479,7 +504,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             }
             (void)hipEventRecord(e.b, st);
             if (!rc && want_svf)
-                rc = svf_launch(d_azim.dev, hori_chunk, d_tilt.dev + 3 * (size_t)rb * dim_in_1, re - rb, dim_in_1,
+                rc = svf_launch(d_azim.dev, hori_chunk, tilt0 + 3 * (size_t)rb * dim_in_1, re - rb, dim_in_1,
                                 azim_num, d_svf.dev + (size_t)(rb - row_begin) * dim_in_1, st);
             (void)hipEventRecord(e.c, st);
             if (!rc && stream_out && n_chunk >= 1) rc = copy_out(n_chunk - 1);
@@ -519,6 +544,8 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         stats->elev_num = tb.elev_num; stats->bvh_height = sc->hdr.height; stats->scene_bytes = sc->hdr.total_bytes;
         stats->stack_fallbacks += (uint64_t)fallbacks; stats->stack_redo_blocks += redo_blocks;
         stats->rays_shortened += cnt[9]; stats->near_violations += cnt[10]; stats->t_near_s += (double)ms_near * 1e-3;
+        stats->guard_cells += cnt[11];
+        stats->height_field = height_field ? 1 : 0; stats->near_used = use_near ? 1 : 0;
     }
     if (opts && opts->verbose) {   // the reference's report, horizon_comp.cpp:673-700, 805-810 (same lines, same order)
         static const char *alg_name[3] = {"discrete_sampling", "binary search", "guess horizon from previous azimuth direction"};
@@ -551,6 +578,7 @@ static int locations_run(const Scene *sc, const float *coords, const float *vec_
     if (num_loc <= 0 || azim_num <= 0) return set_error(HZ_ERR_ARG, "num_loc and azim_num must be positive");
     if (!(hori_acc > 0.0f) || hori_acc > 10.0f) return set_error(HZ_ERR_ARG, "limit of hori_acc (10 degree) is exceeded");
     HZ_HIP(hipSetDevice(sc->device));
+    std::lock_guard<std::mutex> run_lock(sc->run_mu);
     hipStream_t st = sc->stream;
     Timer t_total; t_total.start();
     HostTables tb;
@@ -678,6 +706,16 @@ int hz_scene_blob(const hz_scene *scene, void **device_ptr, size_t *nbytes) {
     const Scene *sc = reinterpret_cast<const Scene *>(scene);
     if (device_ptr) *device_ptr = sc->blob;
     if (nbytes) *nbytes = sc->blob_bytes;
+    return HZ_OK;
+}
+
+int hz_scene_vertices(const hz_scene *scene, const float **device_ptr, int *dem_dim_0, int *dem_dim_1, int *height_field) {
+    if (!scene) return set_error(HZ_ERR_ARG, "scene is NULL");
+    const Scene *sc = reinterpret_cast<const Scene *>(scene);
+    if (device_ptr) *device_ptr = sc->verts();
+    if (dem_dim_0) *dem_dim_0 = sc->hdr.d0;
+    if (dem_dim_1) *dem_dim_1 = sc->hdr.d1;
+    if (height_field) *height_field = (sc->hdr.flags & HZ_BLOB_HEIGHT_FIELD) ? 1 : 0;
     return HZ_OK;
 }
 
@@ -1097,6 +1135,7 @@ static int terrain_init_common(Terrain *t, int offset_0, int offset_1, const flo
         offset_0 + dim_in_0 > sc->hdr.d0 || offset_1 + dim_in_1 > sc->hdr.d1)
         return set_error(HZ_ERR_ARG, "inconsistency between input arguments 'dem_dim_0', 'dem_dim_1', 'offset_0', 'offset_1' and 'vec_norm'");
     if (ang_max < 85.0f || ang_max > 89.99f) return set_error(HZ_ERR_ARG, "'ang_max' must be in the range [85.0, 89.99]");
+    std::lock_guard<std::mutex> run_lock(sc->run_mu);
     hipStream_t st = sc->stream;
     const size_t nc = (size_t)dim_in_0 * dim_in_1;
     int rc;
@@ -1161,6 +1200,7 @@ static int terrain_run(Terrain *t, const float *sun_positions, int num_sun, int 
     if (!sun_positions || num_sun <= 0) return set_error(HZ_ERR_ARG, "array 'sun_position' has incorrect shape");
     if ((which == 0 && !out_u8) || (which == 1 && !out_f32)) return set_error(HZ_ERR_ARG, "output buffer is NULL");
     HZ_HIP(hipSetDevice(t->device));
+    std::lock_guard<std::mutex> run_lock(t->scene->run_mu);
     hipStream_t st = t->stream;
     Timer t_total; t_total.start();
     const size_t nc = (size_t)t->dim_in_0 * t->dim_in_1;
@@ -1178,6 +1218,7 @@ static int terrain_run(Terrain *t, const float *sun_positions, int num_sun, int 
     a.sw_dir_cor_fill = t->fill;
     a.dot_prod_min = cosf(deg2rad_f(t->ang_max));            // shadow_comp.cpp:498
     a.refrac_cor = t->refrac; a.which = which; a.top_nodes = -1; a.counters = t->counters;
+    a.count_work = t->count_work;
     float ms = 0.0f;
     unsigned long long cnt[16];
     {
@@ -1204,11 +1245,19 @@ static int terrain_run(Terrain *t, const float *sun_positions, int num_sun, int 
     HZ_HIP(hipStreamSynchronize(st));
     if (stats) {
         stats->num_rays += cnt[0];
+        stats->nodes_visited += cnt[1]; stats->tris_tested += cnt[2];
+        stats->wave_node_iters += cnt[3]; stats->wave_leaf_iters += cnt[4];
         stats->t_kernel_s += (double)ms * 1e-3;
         stats->t_d2h_s += t_d2h.stop();
         stats->t_total_s += t_total.stop();
         stats->bvh_height = t->scene->hdr.height; stats->scene_bytes = t->scene->hdr.total_bytes;
     }
+    return HZ_OK;
+}
+
+int hz_terrain_count_work(hz_terrain *terrain, int on) {
+    if (!terrain) return set_error(HZ_ERR_ARG, "terrain is NULL");
+    reinterpret_cast<Terrain *>(terrain)->count_work = on ? 1 : 0;
     return HZ_OK;
 }
 

@@ -29,7 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #define HZ_BLOB_MAGIC 0x485a4c42u /* "HZLB" */
-#define HZ_BLOB_VERSION 5u
+#define HZ_BLOB_VERSION 6u
 #define HZ_WAVE 64
 
 struct BlobHeader {
@@ -45,9 +45,17 @@ struct BlobHeader {
     uint64_t off_anc;        // int32[P]: for every leaf the node `anc_levels` levels above it (hit cache)
     int32_t anc_levels;
     int32_t n_prim_slots;    // leaf records incl. the unused slots of partly filled blocks (prims, anc are this long)
-    uint8_t reserved[256 - 136];
+    uint32_t flags;          // HZ_BLOB_HEIGHT_FIELD: see below
+    uint32_t n_flipped;      // DEM triangles whose (x, y) projection is degenerate or oriented against the majority
+    uint8_t reserved[256 - 144];
 };
 static_assert(sizeof(BlobHeader) == 256, "BlobHeader must be 256 bytes");
+// flags bit 0: the DEM mesh is a height field over the world (x, y) plane -- every DEM triangle projects onto that plane
+// with the same orientation and a non-degenerate area (|n_z| > 1e-3 |n|), so the projection of the grid is injective
+// and "outside a window of quads" implies "horizontally outside its boundary polygon".  The near-field certificates
+// (hz_near.hip) rely on exactly that; the reference accepts any vertex buffer (horizon_comp.cpp:126-127), e.g. a frame
+// whose z axis is not "up", and for such a mesh the certificates stay off.
+#define HZ_BLOB_HEIGHT_FIELD 1u
 
 // traversal links: >= 0 node index; < 0 leaf, record index = link & 0x7fffffff (sign + magnitude, so that child k of
 // a block is `first + k` for both kinds); HZ_EMPTY: nothing (the largest positive value: "is a node" is one unsigned

@@ -211,9 +211,10 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
         }
         return;
     }
+    const int guard_cells = __popcll(__ballot(guards != 0u));   // cells where the reference's search would not terminate
     if (lane == 0) {
         if (r) atomicAdd(&p.counters[0], r);
-        if (g) atomicAdd(&p.counters[1], g);
+        if (g) { atomicAdd(&p.counters[1], g); atomicAdd(&p.counters[11], (unsigned long long)guard_cells); }
         if (cc) atomicAdd(&p.counters[4], cc);
         if (COUNT) {
             atomicAdd(&p.counters[2], nc); atomicAdd(&p.counters[3], tcn);

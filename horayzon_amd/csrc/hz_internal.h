@@ -8,6 +8,7 @@
 #include "../../include/horayzon_hip.h"
 #include "hz_common.h"
 #include <atomic>
+#include <mutex>
 
 #define HZ_MAX_TOP_NODES 2047   // upper bound of BFS-ordered top nodes (LDS staging)
 #define HZ_MAX_STACK 40         // tree levels (= LDS stack entries per lane) the traversal kernels accept
@@ -44,8 +45,12 @@ struct Scene {
     bool owns_blob = false;
     // 1 once a launch with the fast stack discipline overflowed: later launches use the one-entry-per-level kernel
     mutable std::atomic<int> level_stack{0};
-    // scratch of the near-field certificates, grown on demand and kept with the scene (hz_api.hip); a scene is
-    // used by one call at a time per stream, like its stream
+    // Calls that launch on the scene's stream (horizon, locations, terrain set-up and shadow) hold `run_mu` from their
+    // first enqueue to their last synchronisation: concurrent calls on one scene are allowed through the C ABI
+    // (`const hz_scene *`, ctypes releases the GIL) and simply run one after the other -- they share the stream, so
+    // the GPU would serialise them anyway.  This is what makes the scene-owned scratch below safe.
+    mutable std::mutex run_mu;
+    // scratch of the near-field certificates, grown on demand and kept with the scene (hz_api.hip; guarded by run_mu)
     mutable void *near_buf = nullptr;
     mutable size_t near_bytes = 0;
     BlobHeader hdr;
@@ -121,7 +126,7 @@ struct HorizonArgs {
     int verify_near;                     // counting instantiation: re-trace every shortened ray from parameter 0
     unsigned long long *counters;        // device u64[24] + int[HZ_REDO_CAP] (tiles to redo, count in [8]): [0] rays, [1] guards, [2] nodes, [3] tris, [4] cells,
                                          // [5..7] wave iterations, [8] waves whose fast-discipline stack overflowed,
-                                         // [9] rays shortened by a certificate, [10] certificate violations (verify)
+                                         // [9] rays shortened by a certificate, [10] certificate violations (verify), [11] cells with a guard event
 };
 #define HZ_REDO_CAP 16384                // 8 x 8 blocks of one launch that can be repeated one by one after a stack overflow
 int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *used_level_stack = nullptr);
@@ -166,7 +171,9 @@ struct ShadowArgs {
     int which;                           // 0 shadow (u8), 1 sw_dir_cor (f32)
     uint8_t *out_u8; float *out_f32;
     int top_nodes;
-    unsigned long long *counters;        // device u64[16]: [0] rays
+    int count_work;                      // 1: the counting instantiation
+    unsigned long long *counters;        // device u64[16]: [0] rays; count_work: [1] node visits, [2] triangle tests,
+                                         // [3] / [4] wave-level node / leaf steps
 };
 int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st);
 

@@ -127,8 +127,12 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
                     else {
                         const float lo = dl >= 0.0f ? pa : pb, span = __builtin_fabsf(dl);
                         const float m_az = 2.0e-3f + 0.02f / rmin;   // end points within the tolerance count as in the plane
+                        // (grids with centimetre spacing: the tolerance would span a large part of the circle and the
+                        //  bins would leave the (-A, 2 A) range phase 2 wraps once -- no certificate for such a cell)
+                        if (m_az > 0.25f) flags[0] = 1;
                         k_lo = (int)__builtin_floorf((lo - m_az) / dphi);
                         bins = (int)__builtin_ceilf((lo + span + m_az) / dphi) - k_lo + 1;
+                        if (m_az > 0.25f) bins = 0;
                         tasks = (bins + CH - 1) / CH;
                     }
                 }

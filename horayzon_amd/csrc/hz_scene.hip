@@ -191,11 +191,36 @@ __global__ __launch_bounds__(256) void k_leaf_boxes(BuildParams b, const uint32_
                                                    const int *__restrict__ parent_leaf,
                                                    float4 *__restrict__ leaf_lo, float4 *__restrict__ leaf_hi,
                                                    int *__restrict__ arrivals, int *__restrict__ next_list,
-                                                   unsigned int *__restrict__ next_count) {
+                                                   unsigned int *__restrict__ next_count,
+                                                   unsigned int *__restrict__ orient) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= b.n_prims) return;
-    float a[3], bb[3], c[3], d[3];
-    prim_vertices(b, (int)vals[s], a, bb, c, d);
+    const bool have = s < b.n_prims;
+    float a[3] = {0, 0, 0}, bb[3] = {0, 0, 0}, c[3] = {0, 0, 0}, d[3] = {0, 0, 0};
+    const bool quad = have && prim_vertices(b, (int)vals[s], a, bb, c, d);
+    {   // height-field check (HZ_BLOB_HEIGHT_FIELD): orientation of the two DEM triangles (a, b, c) / (b, d, c) in the
+        // world (x, y) plane; orient[0] counter-clockwise, [1] clockwise, [2] (nearly) vertical: |n_z| <= 1e-3 |n|
+        unsigned pos = 0, neg = 0, deg = 0;
+        if (quad) {
+            auto classify = [&](const float (&p0)[3], const float (&p1)[3], const float (&p2)[3]) {
+                const float ux = p1[0] - p0[0], uy = p1[1] - p0[1], uz = p1[2] - p0[2];
+                const float vx = p2[0] - p0[0], vy = p2[1] - p0[1], vz = p2[2] - p0[2];
+                const float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
+                const float n2 = (nx * nx + ny * ny) + nz * nz;
+                if (!(nz * nz > 1.0e-6f * n2)) deg++;
+                else if (nz > 0.0f) pos++;
+                else neg++;
+            };
+            classify(a, bb, c);
+            classify(bb, d, c);
+        }
+        for (int off = 32; off > 0; off >>= 1) { pos += __shfl_xor(pos, off); neg += __shfl_xor(neg, off); deg += __shfl_xor(deg, off); }
+        if ((threadIdx.x & 63) == 0) {
+            if (pos) atomicAdd(&orient[0], pos);
+            if (neg) atomicAdd(&orient[1], neg);
+            if (deg) atomicAdd(&orient[2], deg);
+        }
+    }
+    if (!have) return;
     float lo[3], hi[3];
     const float ctr[3] = {b.cx, b.cy, b.cz};
 #pragma unroll
@@ -568,7 +593,7 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
         const size_t sizes[] = {is_device_ptr(vert_grid) ? 0 : nvert * 12, has_tin ? (size_t)nvs * 12 : 0,
                                 has_tin ? (size_t)nts * 12 : 0, 24, P * 4, P * 4, P * 4, P * 4,
                                 sort_temp_elems(P) * 4, B * 8, B * 4, P * 4, B, B * 4, P * 16, P * 16, B * 16, B * 16,
-                                (B + 2 * list_cap0 + 4) * 4, B * 4, B * 4, scan_temp_elems(B) * 4};
+                                (B + 2 * list_cap0 + 8) * 4, B * 4, B * 4, scan_temp_elems(B) * 4};
         size_t total = 0;
         for (size_t x : sizes) total += Arena::pad(x ? x : 16);
         HZ_HIP(arena1.reserve(total + 4096));
@@ -666,19 +691,20 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     HZ_HIP(b_nlo.alloc((size_t)n_bin * 16)); HZ_HIP(b_nhi.alloc((size_t)n_bin * 16));
     // arrivals[n_bin] | two work lists [n_bin/2 + 1 each, a node enters a list once] | 2 list counters
     const size_t list_cap = (size_t)n_bin / 2 + 2;
-    HZ_HIP(b_cnt.alloc(((size_t)n_bin + 2 * list_cap + 4) * 4));
+    HZ_HIP(b_cnt.alloc(((size_t)n_bin + 2 * list_cap + 8) * 4));
     int *arrivals = (int *)b_cnt.p;
     int *lists[2] = {arrivals + n_bin, arrivals + n_bin + list_cap};
     unsigned int *counts = (unsigned int *)(arrivals + n_bin + 2 * list_cap);
+    unsigned int *orient = counts + 4;                   // height-field check of k_leaf_boxes
     HZ_HIP(hipMemsetAsync(arrivals, 0, (size_t)n_bin * 4, st));
-    HZ_HIP(hipMemsetAsync(counts, 0, 16, st));
+    HZ_HIP(hipMemsetAsync(counts, 0, 32, st));
     HZ_HIP(hipMemsetAsync(b_nlo.p, 0, (size_t)n_bin * 16, st));
     if (n_prims > 1)
         hipLaunchKernelGGL(k_karras, dim3((n_prims - 1 + 255) / 256), dim3(256), 0, st, keys, n_prims,
                            (int2 *)b_child.p, (int *)b_pint.p, (int *)b_pleaf.p, (uint8_t *)b_plen.p,
                            (int *)b_first.p);
     hipLaunchKernelGGL(k_leaf_boxes, dim3(gp), dim3(256), 0, st, bp, vals, (const int *)b_pleaf.p,
-                       (float4 *)b_llo.p, (float4 *)b_lhi.p, arrivals, lists[0], &counts[0]);
+                       (float4 *)b_llo.p, (float4 *)b_lhi.p, arrivals, lists[0], &counts[0], orient);
     if (n_prims > 1) {
         size_t finished = 0;
         int cur = 0;
@@ -698,6 +724,15 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
         }
         if (finished != (size_t)n_bin)
             return set_error(HZ_ERR_DEPTH, "BVH refit did not converge (%zu of %d nodes)", finished, n_bin);
+    }
+
+    {   // height field over the world (x, y) plane?  (hz_common.h: HZ_BLOB_HEIGHT_FIELD)
+        unsigned int oc[3] = {0, 0, 0};
+        HZ_HIP(hipMemcpyAsync(oc, orient, sizeof(oc), hipMemcpyDeviceToHost, st));
+        HZ_HIP(hipStreamSynchronize(st));
+        const unsigned int minority = std::min(oc[0], oc[1]);
+        h.n_flipped = minority + oc[2];
+        h.flags = (h.n_flipped == 0 && n_quads > 0) ? HZ_BLOB_HEIGHT_FIELD : 0u;
     }
 
     // ---- 6. which binary nodes open a 4-wide node; compact indices ------------------------
@@ -786,8 +821,8 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     HZ_HIP(b_parent.alloc(n_nodes * 4)); HZ_HIP(b_lparent.alloc((n_leaf_blocks ? n_leaf_blocks : 1) * 4));
     HZ_HIP(hipMemsetAsync(b_parent.p, 0xff, n_nodes * 4, st));       // -1: the root has no parent
     int *fr[2] = {(int *)b_fr0.p, (int *)b_fr1.p};
-    {
-        const int first_frontier[4] = {0, -1, -1, -1};                 // block 0: the root and three unused slots
+    {   // (static: the source of an asynchronous copy must outlive the enqueue)
+        static const int first_frontier[4] = {0, -1, -1, -1};          // block 0: the root and three unused slots
         HZ_HIP(hipMemcpyAsync(fr[0], first_frontier, sizeof(first_frontier), hipMemcpyHostToDevice, st));
     }
     int cur = 0, cnt = 4, level_start = 0, levels = 0;

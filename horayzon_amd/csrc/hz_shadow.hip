@@ -58,17 +58,19 @@ __device__ __forceinline__ float atmos_refrac(float elev_ang_true, float temp, f
 }
 
 // any-hit traversal to completion (regroup = 0: never suspends; no LDS nodelet: top = null)
+template <bool COUNT>
 __device__ __forceinline__ bool occluded(const SceneView &sv, int *stack, int tid,
                                          float ox, float oy, float oz, float dx, float dy, float dz,
-                                         float tfar) {
+                                         float tfar, TravCounters &tc) {
     const RayBox rb = hz_raybox(ox - sv.cx, oy - sv.cy, oz - sv.cz, dx, dy, dz);
     TravState ts; hz_trav_reset(ts);
-    TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.w_nodes = 0; tc.w_leaves = 0;
     unsigned overflow = 0;      // unused: the one-entry-per-level stack cannot overflow
-    return hz_trace<HZ_TPB, false>(sv.nodes, sv.prims, nullptr, 0, stack, tid, ox, oy, oz, dx, dy, dz, tfar, rb,
+    return hz_trace<HZ_TPB, COUNT>(sv.nodes, sv.prims, nullptr, 0, stack, tid, ox, oy, oz, dx, dy, dz, tfar, rb,
                                    ts, 0, HZ_SHADOW_LEAF_BIAS, tc, 0, overflow) == 1;
 }
 
+// COUNT: also count node visits / triangle tests / wave-level steps (Terrain count_work; the roofline's B_trav)
+template <bool COUNT>
 __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *stack = reinterpret_cast<int *>(smem);
@@ -81,6 +83,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
     const bool in_dom = has_tile && (i < p.dim_in_0) && (j < p.dim_in_1);
     const size_t cell = in_dom ? ((size_t)i * p.dim_in_1 + j) : 0;
     unsigned rays = 0;
+    TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.w_nodes = 0; tc.w_leaves = 0;
     if (in_dom) {
         if (p.mask[cell] != 1) {                                   // shadow_comp.cpp:480-484 / :594-598
             if (p.which == 0) p.out_u8[cell] = 3; else p.out_f32[cell] = p.fill;
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
             if (p.which == 0) {                                    // :451-478
                 if (dot_prod_ts > 0.0f) {
                     rays = 1;
-                    const bool h = occluded(p.sv, stack, tid, ox, oy, oz, sun_x, sun_y, sun_z, inf);
+                    const bool h = occluded<COUNT>(p.sv, stack, tid, ox, oy, oz, sun_x, sun_y, sun_z, inf, tc);
                     p.out_u8[cell] = h ? 2 : 0;
                 } else {
                     p.out_u8[cell] = 1;
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
             } else {                                               // :561-592
                 if (dot_prod_ts > p.dot_prod_min) {
                     rays = 1;
-                    const bool h = occluded(p.sv, stack, tid, ox, oy, oz, sun_x, sun_y, sun_z, inf);
+                    const bool h = occluded<COUNT>(p.sv, stack, tid, ox, oy, oz, sun_x, sun_y, sun_z, inf, tc);
                     if (h) p.out_f32[cell] = 0.0f;
                     else {
                         if (dot_prod_ns < p.dot_prod_min) dot_prod_ns = p.dot_prod_min;
@@ -144,6 +147,16 @@ __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
     unsigned long long r = rays;
     for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off);
     if (lane == 0 && r) atomicAdd(&p.counters[0], r);
+    if (COUNT) {
+        unsigned long long nc = tc.nodes, tn = tc.tris, wn = tc.w_nodes, wl = tc.w_leaves;
+        for (int off = 32; off > 0; off >>= 1) {
+            nc += __shfl_xor(nc, off); tn += __shfl_xor(tn, off); wn += __shfl_xor(wn, off); wl += __shfl_xor(wl, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&p.counters[1], nc); atomicAdd(&p.counters[2], tn);
+            atomicAdd(&p.counters[3], wn); atomicAdd(&p.counters[4], wl);
+        }
+    }
 }
 
 int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st) {
@@ -166,9 +179,15 @@ int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st) {
     p.counters = a.counters;
     const size_t lds = (size_t)p.stack_bytes;
     const int grid = p.tm.per_xcd * 8;
-    HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shadow),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(k_shadow, dim3(grid), dim3(HZ_TPB), lds, st, p);
+    if (a.count_work) {
+        HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shadow<true>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(HZ_TPB), lds, st, p);
+    } else {
+        HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shadow<false>),
+                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(HZ_TPB), lds, st, p);
+    }
     HZ_HIP(hipGetLastError());
     return HZ_OK;
 }

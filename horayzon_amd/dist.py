@@ -16,24 +16,90 @@ import time
 import numpy as np
 
 
-def row_slabs(mask_or_rows, world_size):
-    """Split rows into ``world_size`` contiguous slabs balanced by the number of cells
-    to compute (``mask == 1`` per row).  Accepts a 2-D mask or a row count.
-    Returns [(begin, end)] * world_size; slabs may be empty when rows < world_size."""
-    if np.ndim(mask_or_rows) == 0:
-        w = np.ones(int(mask_or_rows), np.int64)
+def row_slabs(mask_or_rows, world_size, cost=None):
+    """Split rows into ``world_size`` contiguous slabs balanced by work.  The work of a row is the number of
+    cells to compute (``mask == 1``; accepts a 2-D mask or a row count) or, when ``cost`` (one non-negative
+    weight per row, e.g. from ``estimate_row_cost``) is given, that weight: rows over rough terrain cost more rays
+    and node visits than rim rows whose rays leave the DEM early.  Returns [(begin, end)] * world_size; slabs may
+    be empty when rows < world_size."""
+    if cost is not None:
+        w = np.asarray(cost, np.float64)
+        if w.ndim != 1 or (w < 0).any() or not np.isfinite(w).all():
+            raise ValueError("'cost' must be one finite non-negative weight per row")
+        if np.ndim(mask_or_rows) != 0 and np.asarray(mask_or_rows).shape[0] != w.shape[0]:
+            raise ValueError("'cost' and the mask disagree on the number of rows")
+    elif np.ndim(mask_or_rows) == 0:
+        w = np.ones(int(mask_or_rows), np.float64)
     else:
-        w = (np.asarray(mask_or_rows) == 1).sum(axis=1).astype(np.int64)
+        w = (np.asarray(mask_or_rows) == 1).sum(axis=1).astype(np.float64)
     n = w.shape[0]
-    cum = np.concatenate([[0], np.cumsum(w)])
+    cum = np.concatenate([[0.0], np.cumsum(w)])
     total = cum[-1]
     bounds = [0]
     for r in range(1, world_size):
         target = total * r / world_size
         b = int(np.searchsorted(cum, target, side="left"))
+        # the boundary that leaves the smaller error (searchsorted alone always rounds up)
+        if b > 0 and b <= n and abs(cum[b - 1] - target) <= abs(cum[min(b, n)] - target):
+            b -= 1
         bounds.append(min(max(b, bounds[-1]), n))
     bounds.append(n)
     return [(bounds[r], bounds[r + 1]) for r in range(world_size)]
+
+
+def sample_rows(n_rows, n_samples):
+    """``n_samples`` row indices spread evenly over [0, n_rows) (centres of equal strata), without duplicates."""
+    n_samples = max(1, min(int(n_samples), int(n_rows)))
+    idx = ((np.arange(n_samples) + 0.5) * n_rows / n_samples).astype(np.int64)
+    return np.unique(np.clip(idx, 0, n_rows - 1))
+
+
+def estimate_row_cost(mask_or_rows, probe, *, samples=32, group=None):
+    """Per-row cost weights for ``row_slabs(..., cost=...)`` from a cheap sampled pre-pass.
+
+    ``probe(row) -> float`` measures the cost of ONE inner-domain row (e.g. weighted node visits / triangle tests /
+    rays of a one-row ``count_work`` call with a reduced azimuth count; any unit).  The ``samples`` probe rows are
+    split over the ranks of ``group`` (rank r takes samples r, r + world, ...; one small all_gather joins them; no
+    process group: this process probes all of them), converted to a cost per cell, interpolated linearly between the
+    sampled rows and multiplied by every row's cell count.  Deterministic on every rank: all ranks derive the same
+    slabs without exchanging them."""
+    if np.ndim(mask_or_rows) == 0:
+        cells = np.ones(int(mask_or_rows), np.float64)
+    else:
+        cells = (np.asarray(mask_or_rows) == 1).sum(axis=1).astype(np.float64)
+    n = cells.shape[0]
+    rows = sample_rows(n, samples)
+    rank, world, dist = 0, 1, None
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+    except ImportError:
+        dist = None
+    local = np.zeros(rows.shape[0], np.float64)
+    for k in range(rank, rows.shape[0], world):
+        local[k] = float(probe(int(rows[k])))
+    if world > 1:
+        import torch
+        t = torch.from_numpy(local)
+        if dist.get_backend(group) != "gloo":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)     # disjoint supports: the sum joins the shares
+        local = t.cpu().numpy()
+    per_cell = local / np.maximum(cells[rows], 1.0)
+    ok = cells[rows] > 0
+    if not ok.any() or not (per_cell[ok] > 0).any():
+        return cells                                              # nothing measured: fall back to the cell count
+    dense = np.interp(np.arange(n), rows[ok], per_cell[ok])
+    return dense * cells
+
+
+def predicted_imbalance(slabs, cost):
+    """max / mean of the slabs' summed cost (over the non-empty slabs), the figure ``sharded_rows`` measures as
+    slowest rank / mean rank."""
+    c = np.asarray(cost, np.float64)
+    w = [float(c[b:e].sum()) for b, e in slabs if e > b]
+    return max(w) / (sum(w) / len(w)) if w and sum(w) > 0 else 1.0
 
 
 def broadcast_blob(buf, nbytes_if_src, device, src=0, group=None):
@@ -57,18 +123,30 @@ def broadcast_blob(buf, nbytes_if_src, device, src=0, group=None):
     return buf
 
 
-def _hip_blob_tensor(scene, device):
-    """The scene's blob copied into a torch uint8 CUDA tensor (send buffer of the broadcast)."""
-    import ctypes as C
+class _DeviceBytes:
+    """A raw HBM range as an object torch can wrap without copying (__cuda_array_interface__, version 2)."""
+
+    def __init__(self, ptr, nbytes, owner=None):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+        self._owner = owner
+
+
+def device_bytes_tensor(ptr, nbytes, device, owner=None):
+    """uint8 torch tensor over [ptr, ptr + nbytes) of GPU ``device`` -- no copy; ``owner`` is kept alive with it."""
     import torch
-    from . import _lib
+    t = torch.as_tensor(_DeviceBytes(ptr, nbytes, owner), device="cuda:%d" % device)
+    if t.data_ptr() != int(ptr) or t.numel() != int(nbytes):
+        raise RuntimeError("torch copied the device range instead of wrapping it")
+    t._hz_owner = owner
+    return t
+
+
+def _hip_blob_tensor(scene, device):
+    """The scene's blob AS a torch uint8 CUDA tensor: the send buffer of the broadcast is the blob allocation itself
+    (no second copy of a 17.7 GB blob on the source rank)."""
     p, n = scene.blob()
-    buf = torch.empty(n, dtype=torch.uint8, device="cuda:%d" % device)
-    hiprt = C.CDLL("libamdhip64.so")   # already mapped; device-to-device copy
-    rc = hiprt.hipMemcpy(C.c_void_p(buf.data_ptr()), C.c_void_p(p), C.c_size_t(n), 3)
-    if rc != 0:
-        raise _lib.HorayzonHipError("hipMemcpy of the scene blob failed (%d)" % rc)
-    return buf, n
+    return device_bytes_tensor(p, n, device, owner=scene), n
 
 
 def broadcast_scene(scene, device, src=0, group=None, *, to_tensor=None, adopt=None, torch_device=None):
@@ -130,19 +208,20 @@ def gather_rows(local, slabs, dst=0, group=None):
     return torch.cat([out[r][:slabs[r][1] - slabs[r][0]] for r in range(world)], dim=0).to(dev)
 
 
-def sharded_rows(mask, compute, *, sync=None, dst=0, group=None, gather=True):
+def sharded_rows(mask, compute, *, sync=None, dst=0, group=None, gather=True, cost=None):
     """Per-rank body of a row-sharded job: split the inner-domain rows by ``row_slabs(mask,
-    world)``, run ``compute(begin, end) -> tensor[end - begin, ...]`` on this rank's slab (no collective
-    in there), then gather the per-rank results on ``dst``.
+    world, cost)``, run ``compute(begin, end) -> tensor[end - begin, ...]`` on this rank's slab (no collective
+    in there), then gather the per-rank results on ``dst``.  ``mask`` may be a 2-D mask or a row count.
 
     ``sync()`` is called after ``compute`` before the clock stops (torch.cuda.synchronize on GPUs).
     Returns a dict: ``full`` (the gathered array on ``dst``, else None), ``slabs``, ``t_compute`` (this
-    rank's seconds), ``t_ranks`` (all ranks' seconds), ``imbalance`` (slowest rank / mean rank)."""
+    rank's seconds), ``t_ranks`` (all ranks' seconds), ``imbalance`` (slowest rank / mean rank, measured) and
+    ``imbalance_predicted`` (the same ratio of the slabs' cost weights; None without ``cost``)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    slabs = row_slabs(mask, world)
+    slabs = row_slabs(mask, world, cost)
     b, e = slabs[rank]
     t0 = time.perf_counter()
     local = compute(b, e)
@@ -156,4 +235,5 @@ def sharded_rows(mask, compute, *, sync=None, dst=0, group=None, gather=True):
     busy = [x for x, (sb, se) in zip(t_ranks, slabs) if se > sb]
     imbalance = max(busy) / (sum(busy) / len(busy)) if busy else 1.0
     full = gather_rows(local, slabs, dst=dst, group=group) if gather else None
-    return dict(full=full, slabs=slabs, t_compute=t_compute, t_ranks=t_ranks, imbalance=imbalance)
+    return dict(full=full, slabs=slabs, t_compute=t_compute, t_ranks=t_ranks, imbalance=imbalance,
+                imbalance_predicted=predicted_imbalance(slabs, cost) if cost is not None else None)

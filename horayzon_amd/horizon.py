@@ -138,7 +138,8 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
     opts.regroup = _regroup
     opts.no_hit_cache = 0 if _hit_cache else 1
     opts.chunk_rows = _chunk_rows
-    opts.no_near_skip = 0 if _near_skip else 1
+    # True: certificates when the scene allows them; False: never; "force": even for a mesh that is not a height field (tests)
+    opts.no_near_skip = -1 if _near_skip == "force" else (0 if _near_skip else 1)
     opts.level_stack = int(_level_stack)      # True / 1: level stack from the start; -n: fast stack of n entries (tests)
     opts.verify_near = int(bool(_verify_near))
     opts.skip_hori = 1 if svf_only else 0

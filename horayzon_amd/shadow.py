@@ -162,6 +162,10 @@ class Terrain:
                                                     ptr(sw_dir_cor_buffer), C.byref(st)))
         self.last_stats = st.as_dict()
 
+    def count_work(self, on=True):
+        """Additive: later calls also count BVH node visits / triangle tests (``last_stats``; slower)."""
+        _lib.check(_lib.lib().hz_terrain_count_work(self._h, int(bool(on))))
+
     # --- additive batch API (not in the reference): many sun positions, one call ------
     @staticmethod
     def _batch_out(buf, np_dtype, name):

@@ -39,10 +39,11 @@ extern "C" {
 typedef struct hz_opts {
     int32_t device;        /* HIP device ordinal                               */
     int32_t verbose;       /* 1: print the reference's stdout report           */
-    int32_t row_begin;     /* inner-domain row slab [row_begin, row_end) to compute: row_begin <= 0 means 0,      */
-    int32_t row_end;       /*   row_end <= 0 or > dim_in_0 means dim_in_0 (so a zeroed struct = whole domain);   */
-                           /*   an empty slab (row_begin >= row_end after that) is an error.  The Python mirror  */
-                           /*   validates 0 <= begin < end <= dim_in_0 before it gets here                       */
+    int32_t row_begin;     /* inner-domain row slab [row_begin, row_end) to compute.  {0, 0} (a zeroed struct) = the   */
+    int32_t row_end;       /*   whole inner domain; row_end == -1 = dim_in_0 (explicit sentinel); every other pair    */
+                           /*   must satisfy 0 <= row_begin <= row_end <= dim_in_0, else HZ_ERR_ARG (negative or        */
+                           /*   out-of-range slabs are rejected, not clamped).  row_begin == row_end (> 0) is an empty  */
+                           /*   slab: the call succeeds and computes nothing (a rank without rows)                      */
     int32_t top_nodes;     /* > 0: stage that many top-of-tree BVH nodes in LDS (guess_constant;   */
                            /*   measured 2 % slower than L1 reads, so <= 0 means none)            */
     int32_t regroup;       /* wave regroup threshold in lanes (-1 auto)        */
@@ -61,12 +62,18 @@ typedef struct hz_opts {
     int32_t hori_is_slab;  /* 0: hori_buffer (and svf) address inner-domain row 0 (reference layout, [dim_in_0][..]); */
                            /*   1: they address row_begin, i.e. hold only the slab [row_end - row_begin][dim_in_1].. */
                            /*   -- the form for resident HBM slab buffers (the caller never forms an address        */
-                           /*   outside its allocation).  Inputs (vec_norm, vec_north, mask, vec_tilt) always cover  */
-                           /*   the whole inner domain                                                               */
+                           /*   outside its allocation).  For the inputs see inputs_are_slab                         */
     int32_t no_near_skip;  /* 1: do not compute / use the near-field certificates (hz_near.hip): every ray starts at   */
-                           /*   parameter 0.  Results are the same either way; the default is faster                   */
+                           /*   parameter 0.  Results are the same either way; the default (0) is faster and is only   */
+                           /*   active for a DEM mesh that IS a height field over the world (x, y) plane (checked by   */
+                           /*   the scene build, hz_stats.height_field); -1 (tests): certificates even if it is not    */
     int32_t verify_near;   /* 1 (with count_work): re-trace every shortened ray over its full length and count         */
                            /*   disagreeing hit decisions in hz_stats.near_violations (must stay 0)                     */
+    int32_t inputs_are_slab; /* 0: vec_norm, vec_north, mask (and opts.vec_tilt) address inner-domain row 0 (reference   */
+                           /*   layout; only the slab's rows are read or uploaded); 1: they address row_begin, i.e. the */
+                           /*   caller holds only its slab [row_end - row_begin][dim_in_1] of each -- the form for a    */
+                           /*   rank of a row-sharded job                                                                */
+    int32_t reserved_;
 } hz_opts;
 
 /* Run-time self report (the quantities the reference prints,                  */
@@ -96,6 +103,10 @@ typedef struct hz_stats {
     double t_near_s;       /* certificate pre-pass (hz_near.hip)                */
     uint64_t stack_redo_blocks; /* 8 x 8 blocks repeated one by one after such an overflow (few: deep trees overflow in    */
                                /*   a few places; many overflows repeat the launch and switch the scene for good)        */
+    uint64_t guard_cells;  /* cells with at least one guard event (the reference's search would not terminate there,     */
+                           /*   horizon_comp.cpp:474-488)                                                                 */
+    int32_t height_field;  /* 1: the scene's DEM mesh is a height field over the world (x, y) plane                      */
+    int32_t near_used;     /* 1: the near-field certificates were active in this call                                    */
 } hz_stats;
 
 const char *hz_last_error(void);
@@ -120,6 +131,10 @@ int hz_scene_create(const float *vert_grid, int dem_dim_0, int dem_dim_1,
                     int device, hz_scene **scene, hz_stats *stats);
 /* the blob: position independent, valid on any gfx950 device                  */
 int hz_scene_blob(const hz_scene *scene, void **device_ptr, size_t *nbytes);
+/* the vertex array inside the blob (f32[dem_dim_0 * dem_dim_1][3], the caller's vert_grid without padding): lets a   */
+/* rank that received the blob derive per-cell inputs of its slab on the device without the host arrays               */
+int hz_scene_vertices(const hz_scene *scene, const float **device_ptr, int *dem_dim_0, int *dem_dim_1,
+                      int *height_field);
 /* wrap a blob that already sits in HBM of `device` (e.g. received by an RCCL  */
 /* broadcast into caller-owned memory); the scene does not own the memory      */
 int hz_scene_adopt(void *device_ptr, size_t nbytes, int device, hz_scene **scene);
@@ -286,6 +301,9 @@ int hz_terrain_shadow_batch(hz_terrain *terrain, const float *sun_positions,
                             int num_sun, uint8_t *shadow_buffers, hz_stats *stats);
 int hz_terrain_sw_dir_cor_batch(hz_terrain *terrain, const float *sun_positions,
                                 int num_sun, float *sw_dir_cor_buffers, hz_stats *stats);
+/* additive: 1 = later shadow / sw_dir_cor calls run the counting instantiation and also fill   */
+/* hz_stats.nodes_visited / tris_tested / wave_*_iters (slower; for the roofline's B_trav)      */
+int hz_terrain_count_work(hz_terrain *terrain, int on);
 /* CppTerrain::~CppTerrain, shadow_comp.cpp:310-316 */
 int hz_terrain_destroy(hz_terrain *terrain);
 

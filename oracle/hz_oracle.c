@@ -151,8 +151,8 @@ static inline const float *vtx(const orc_scene *s, int i, int j) {
 /* ------------------------------------------------------------------------- */
 
 /* returns 1 if the ray (o, d, [0, tfar]) hits triangle (p0, p1, p2)          */
-static inline int tri_hit_f(const float *o, const float *d, float tfar,
-                            const float *p0, const float *p1, const float *p2) {
+static inline int tri_hit_plain(const float *o, const float *d, float tfar,
+                                const float *p0, const float *p1, const float *p2) {
     const float v0x = p0[0] - o[0], v0y = p0[1] - o[1], v0z = p0[2] - o[2];
     const float v1x = p1[0] - o[0], v1y = p1[1] - o[1], v1z = p1[2] - o[2];
     const float v2x = p2[0] - o[0], v2y = p2[1] - o[1], v2z = p2[2] - o[2];
@@ -193,6 +193,106 @@ static inline int tri_hit_f(const float *o, const float *d, float tfar,
     if (!(Ts >= 0.0f)) return 0;
     if (!(Ts <= tfar * ad)) return 0;
     return 1;
+}
+
+/* ------------------------------------------------------------------------- */
+/* SENSITIVITY VARIANTS of the triangle test (diagnostics only, never the contract).                       */
+/* The reference's hit decisions are Embree's (horizon_comp.cpp:106 ROBUST flag, :258 rtcOccluded1;         */
+/* shadow_comp.cpp:466, :576); Embree is not available here, so how far its evaluation can sit from        */
+/* tri_hit_plain is BOUNDED by running the same workloads with the evaluations Embree plausibly uses:       */
+/*   mode 1 "embree_fma_rcp": the Pluecker test of Embree's robust intersector as its SIMD code evaluates  */
+/*           it on an FMA machine -- cross(a, b) = (msub(a.y, b.z, a.z b.y), ...), dot(a, b) = madd(a.x,   */
+/*           b.x, madd(a.y, b.y, a.z b.z)), the geometric normal by `stable_triangle_normal` (per          */
+/*           component the cross product of the edge pair with the smaller products), den and T doubled,   */
+/*           depth test 0 <= rcp(den) T <= tfar with rcp = hardware reciprocal estimate + one Newton step  */
+/*           (restated from the published Embree 3.13 / 4 sources, kernels/geometry/                        */
+/*           triangle_intersector_pluecker.h and common/math/vec3.h, from memory: that tree is not in the  */
+/*           image);                                                                                        */
+/*   mode 2 "moeller_trumbore": the classic Moeller-Trumbore test north_star names, two-sided, float32, no */
+/*           FMA, u / v / t through one reciprocal of the determinant, no epsilon other than det == 0.     */
+/* orc_set_tri_mode selects the test every query uses; orc_set_tri_compare(m) keeps the shipped decisions   */
+/* but ALSO evaluates every ray with mode m and counts the rays whose decision differs.                     */
+/* ------------------------------------------------------------------------- */
+#include <xmmintrin.h>
+static inline float rcp_nr(float a) {          /* Embree rcp(): rcpss estimate, one Newton-Raphson step (AVX2 form) */
+    const float r = _mm_cvtss_f32(_mm_rcp_ss(_mm_set_ss(a)));
+    return __builtin_fmaf(r, __builtin_fmaf(-a, r, 1.0f), r);
+}
+#define MSUB(a, b, c) __builtin_fmaf((a), (b), -(c))
+#define MADD(a, b, c) __builtin_fmaf((a), (b), (c))
+static inline int tri_hit_embree_fma(const float *o, const float *d, float tfar,
+                                     const float *p0, const float *p1, const float *p2) {
+    const float v0[3] = {p0[0] - o[0], p0[1] - o[1], p0[2] - o[2]};
+    const float v1[3] = {p1[0] - o[0], p1[1] - o[1], p1[2] - o[2]};
+    const float v2[3] = {p2[0] - o[0], p2[1] - o[1], p2[2] - o[2]};
+    float e0[3], e1[3], e2[3], s0[3], s1[3], s2[3];
+    for (int k = 0; k < 3; k++) {
+        e0[k] = v2[k] - v0[k]; e1[k] = v0[k] - v1[k]; e2[k] = v1[k] - v2[k];
+        s0[k] = v2[k] + v0[k]; s1[k] = v0[k] + v1[k]; s2[k] = v1[k] + v2[k];
+    }
+#define CROSS(r, a, b) do { (r)[0] = MSUB((a)[1], (b)[2], (a)[2] * (b)[1]); (r)[1] = MSUB((a)[2], (b)[0], (a)[0] * (b)[2]); \
+                            (r)[2] = MSUB((a)[0], (b)[1], (a)[1] * (b)[0]); } while (0)
+#define DOT(a, b) MADD((a)[0], (b)[0], MADD((a)[1], (b)[1], (a)[2] * (b)[2]))
+    float c0[3], c1[3], c2[3];
+    CROSS(c0, e0, s0); CROSS(c1, e1, s1); CROSS(c2, e2, s2);
+    const float U = DOT(c0, d), V = DOT(c1, d), W = DOT(c2, d);
+    const float UVW = (U + V) + W;
+    const float eps = FLT_EPSILON * fabsf(UVW);
+    const float mn = fminf(U, fminf(V, W)), mx = fmaxf(U, fmaxf(V, W));
+    if (!((mn >= -eps) || (mx <= eps))) return 0;
+    /* stable_triangle_normal(e0, e1, e2): per component cross(e0, e1) or cross(e1, e2), whichever has the smaller
+     * subtracted product (both are the same vector in exact arithmetic: -(e1 x e0)) */
+    float ng[3];
+    {
+        const float ab_x = e0[2] * e1[1], ab_y = e0[0] * e1[2], ab_z = e0[1] * e1[0];
+        const float bc_x = e1[2] * e2[1], bc_y = e1[0] * e2[2], bc_z = e1[1] * e2[0];
+        const float cab[3] = {MSUB(e0[1], e1[2], ab_x), MSUB(e0[2], e1[0], ab_y), MSUB(e0[0], e1[1], ab_z)};
+        const float cbc[3] = {MSUB(e1[1], e2[2], bc_x), MSUB(e1[2], e2[0], bc_y), MSUB(e1[0], e2[1], bc_z)};
+        ng[0] = (fabsf(ab_x) < fabsf(bc_x)) ? cab[0] : cbc[0];
+        ng[1] = (fabsf(ab_y) < fabsf(bc_y)) ? cab[1] : cbc[1];
+        ng[2] = (fabsf(ab_z) < fabsf(bc_z)) ? cab[2] : cbc[2];
+    }
+    const float dn = DOT(ng, d), tn = DOT(v0, ng);
+    const float den = dn + dn, T = tn + tn;            /* twice() */
+    if (den == 0.0f) return 0;
+    const float t = rcp_nr(den) * T;
+    return (0.0f <= t) && (t <= tfar);
+#undef CROSS
+#undef DOT
+}
+#undef MSUB
+#undef MADD
+
+static inline int tri_hit_mt(const float *o, const float *d, float tfar,
+                             const float *p0, const float *p1, const float *p2) {
+    const float e1x = p1[0] - p0[0], e1y = p1[1] - p0[1], e1z = p1[2] - p0[2];
+    const float e2x = p2[0] - p0[0], e2y = p2[1] - p0[1], e2z = p2[2] - p0[2];
+    const float px = d[1] * e2z - d[2] * e2y, py = d[2] * e2x - d[0] * e2z, pz = d[0] * e2y - d[1] * e2x;
+    const float det = (e1x * px + e1y * py) + e1z * pz;
+    if (det == 0.0f) return 0;
+    const float inv = 1.0f / det;
+    const float tx = o[0] - p0[0], ty = o[1] - p0[1], tz = o[2] - p0[2];
+    const float u = ((tx * px + ty * py) + tz * pz) * inv;
+    if (!(u >= 0.0f && u <= 1.0f)) return 0;
+    const float qx = ty * e1z - tz * e1y, qy = tz * e1x - tx * e1z, qz = tx * e1y - ty * e1x;
+    const float v = ((d[0] * qx + d[1] * qy) + d[2] * qz) * inv;
+    if (!(v >= 0.0f && u + v <= 1.0f)) return 0;
+    const float t = ((e2x * qx + e2y * qy) + e2z * qz) * inv;
+    return (t >= 0.0f) && (t <= tfar);
+}
+
+static int g_tri_mode = 0, g_tri_compare = -1;
+static _Thread_local int tl_tri_mode = 0;
+static uint64_t g_cmp_rays = 0, g_cmp_flips = 0;
+void orc_set_tri_mode(int mode) { g_tri_mode = mode; }
+void orc_set_tri_compare(int mode) { g_tri_compare = mode; g_cmp_rays = 0; g_cmp_flips = 0; }
+void orc_tri_compare_counts(uint64_t *out) { out[0] = g_cmp_rays; out[1] = g_cmp_flips; }
+
+static inline int tri_hit_f(const float *o, const float *d, float tfar,
+                            const float *p0, const float *p1, const float *p2) {
+    if (tl_tri_mode == 1) return tri_hit_embree_fma(o, d, tfar, p0, p1, p2);
+    if (tl_tri_mode == 2) return tri_hit_mt(o, d, tfar, p0, p1, p2);
+    return tri_hit_plain(o, d, tfar, p0, p1, p2);
 }
 
 /* closest-hit variant (rtcIntersect1, horizon_comp.cpp:268-292): same acceptance test, and the
@@ -440,8 +540,23 @@ void orc_scene_destroy(orc_scene *s) {
 }
 
 /* mode 0: BVH + float test; 1: brute force + float test; 2: brute force + double test */
+static int occluded_impl(const orc_scene *s, const float *o, const float *d, float tfar,
+                         int mode, orc_counters *cnt);
 static int occluded(const orc_scene *s, const float *o, const float *d, float tfar,
                     int mode, orc_counters *cnt) {
+    tl_tri_mode = g_tri_mode;
+    const int hit = occluded_impl(s, o, d, tfar, mode, cnt);
+    if (g_tri_compare >= 0) {                          /* sensitivity run: the same ray with another triangle test */
+        tl_tri_mode = g_tri_compare;
+        const int other = occluded_impl(s, o, d, tfar, mode, NULL);
+        tl_tri_mode = g_tri_mode;
+        __atomic_fetch_add(&g_cmp_rays, 1, __ATOMIC_RELAXED);
+        if (other != hit) __atomic_fetch_add(&g_cmp_flips, 1, __ATOMIC_RELAXED);
+    }
+    return hit;
+}
+static int occluded_impl(const orc_scene *s, const float *o, const float *d, float tfar,
+                         int mode, orc_counters *cnt) {
     if (mode == 0) {
         ray_t r; ray_init(&r, o, d, tfar);
         int stack[128]; int sp = 0;
@@ -485,6 +600,7 @@ static int occluded(const orc_scene *s, const float *o, const float *d, float tf
  * not depend on the visiting order); mode 0 = BVH, 1 = brute force.  Returns 1 when hit.        */
 static int closest(const orc_scene *s, const float *o, const float *d, float tfar, int mode, float *dist) {
     float best = INFINITY; int any = 0; float t;
+    tl_tri_mode = g_tri_mode;
 #define TRY_QUAD(i, j) do { \
         const float *a = vtx(s, (i), (j)), *b = vtx(s, (i), (j) + 1); \
         const float *c = vtx(s, (i) + 1, (j)), *e = vtx(s, (i) + 1, (j) + 1); \

@@ -93,6 +93,33 @@ def set_libm(platform):
     lib().orc_set_libm(int(bool(platform)))
 
 
+TRI_MODES = {"plain": 0, "embree_fma_rcp": 1, "moeller_trumbore": 2}
+
+
+def set_tri_mode(mode="plain"):
+    """Triangle test every later query uses (sensitivity diagnostics; "plain" is the contract)."""
+    L = lib()
+    L.orc_set_tri_mode.argtypes = [C.c_int]
+    L.orc_set_tri_mode(TRI_MODES[mode])
+
+
+def set_tri_compare(mode=None):
+    """Keep the active test's decisions but also evaluate every ray with ``mode`` and count the rays whose
+    decision differs (``tri_compare_counts``); ``None`` switches the comparison off.  Resets the counts."""
+    L = lib()
+    L.orc_set_tri_compare.argtypes = [C.c_int]
+    L.orc_set_tri_compare(-1 if mode is None else TRI_MODES[mode])
+
+
+def tri_compare_counts():
+    """(rays compared, rays whose hit decision differed)."""
+    L = lib()
+    out = (C.c_uint64 * 2)()
+    L.orc_tri_compare_counts.argtypes = [C.POINTER(C.c_uint64)]
+    L.orc_tri_compare_counts(out)
+    return int(out[0]), int(out[1])
+
+
 def set_quad_order(embree_quad):
     """False (default): second triangle of a DEM quad as (b, d, c), the explicit "triangle" topology
     (horizon_comp.cpp:142-148).  True: as (d, c, b), the order Embree's quad / grid intersector forms from the quad

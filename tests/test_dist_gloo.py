@@ -46,6 +46,17 @@ def _worker(rank, world, port, q):
             return torch.from_numpy(orc.sky_view_factor(azim, h, np.ascontiguousarray(vec_tilt[b:e])))
 
         res = sharded_rows(mask, compute, dst=0)
+        # cost-balanced variant: a sampled pre-pass whose probe rows are split over the two ranks (one all_reduce
+        # joins the shares); the probe here is a stand-in (row index as cost per cell), the machinery is the product's
+        from horayzon_amd.dist import estimate_row_cost, row_slabs, predicted_imbalance
+        probed = []
+        cost = estimate_row_cost(mask, lambda r: (probed.append(r), (1.0 + r) * float(mask[r].sum()))[1], samples=9)
+        assert 4 <= len(probed) <= 5 and cost.shape == (mask.shape[0],) and np.all(cost[:10] == 0.0)
+        res_c = sharded_rows(mask, compute, dst=0, cost=cost)
+        assert res_c["slabs"] == row_slabs(mask, world, cost) and res_c["slabs"] != res["slabs"]
+        assert res_c["imbalance_predicted"] == predicted_imbalance(res_c["slabs"], cost) < predicted_imbalance(res["slabs"], cost)
+        if rank == 0:
+            assert np.array_equal(res_c["full"].numpy(), res["full"].numpy())     # any partition, same result
         if rank == 0:
             h, azim = orc.horizon_gridded(**kw, dist_search=1.0, azim_num=12, elev_ang_low_lim=-60.0,
                                           mask=mask, hori_fill=-2.0)
@@ -75,6 +86,22 @@ def test_sharded_equals_unsharded_gloo():
     assert tag == "ok" and equal
     assert slabs[0][1] > 17                             # mask-balanced, not an even row split
     assert len(t_ranks) == 2 and all(t > 0 for t in t_ranks) and 1.0 <= imbalance <= 2.0
+
+
+def test_cost_balanced_slabs():
+    from horayzon_amd.dist import row_slabs, estimate_row_cost, predicted_imbalance, sample_rows
+    cost = np.concatenate([np.ones(60), 4.0 * np.ones(40)])         # the last 40 rows cost four times as much
+    by_cost, by_cells = row_slabs(100, 4, cost), row_slabs(100, 4)
+    assert by_cells == [(0, 25), (25, 50), (50, 75), (75, 100)]
+    assert by_cost[0][0] == 0 and by_cost[-1][1] == 100 and all(by_cost[i][1] == by_cost[i + 1][0] for i in range(3))
+    assert predicted_imbalance(by_cost, cost) < 1.05 < 1.5 < predicted_imbalance(by_cells, cost)
+    assert list(sample_rows(10, 4)) == [1, 3, 6, 8] and list(sample_rows(3, 8)) == [0, 1, 2]
+    m = np.ones((100, 7), np.uint8); m[:20] = 0                      # masked rows cost nothing whatever the probe says
+    c = estimate_row_cost(m, lambda r: 7.0 * (1.0 + (r >= 60) * 3.0), samples=10)     # no process group: all probes here
+    assert np.all(c[:20] == 0) and np.allclose(c[20:50], 7.0) and np.allclose(c[70:], 28.0)
+    assert np.array_equal(estimate_row_cost(5, lambda r: 0.0), np.ones(5))           # nothing measured: cell count
+    with pytest.raises(ValueError):
+        row_slabs(10, 2, cost=np.ones(9) * -1)
 
 
 def test_row_slabs_edge_cases():

@@ -214,6 +214,52 @@ def test_row_slab(hip, orc):
     assert np.isnan(part[:17]).all() and np.isnan(part[40:]).all()
 
 
+def test_row_slab_c_abi_semantics(hip):
+    """C ABI (include/horayzon_hip.h): {0, 0} = whole domain, row_end = -1 = dim_in_0, negative / out-of-range /
+    reversed slabs are rejected (not clamped), begin == end is an empty slab that succeeds and writes nothing; with
+    opts.inputs_are_slab the per-cell inputs hold only the slab's rows."""
+    import ctypes as C
+    from horayzon_amd import _lib
+    L = _lib.lib()
+    g = cases.rough_terrain(40, 37, seed=21, offset=2)
+    kw = cases.grid_kwargs(g)
+    in0, in1 = kw["vec_norm"].shape[:2]
+    A = 8
+    sc = hip.Scene.create(kw["vert_grid"], 40, 37)
+    mask = np.ones((in0, in1), np.uint8); mask[5:9, 3:20] = 0
+    tilt = np.zeros((in0, in1, 3), np.float32); tilt[..., 2] = 1.0
+
+    def call(rb, re, norm=kw["vec_norm"], north=kw["vec_north"], m=mask, t=tilt, slab_in=0, slab_out=0):
+        rows = in0 if slab_out == 0 else max(re - rb, 1)
+        hori = np.full((rows, in1, A), np.nan, np.float32)
+        svf = np.full((rows, in1), np.nan, np.float32)
+        o = _lib.hz_opts(); o.row_begin, o.row_end = rb, re
+        o.inputs_are_slab, o.hori_is_slab = slab_in, slab_out
+        o.svf, o.vec_tilt = svf.ctypes.data, t.ctypes.data
+        st = _lib.hz_stats()
+        rc = L.hz_horizon_gridded_scene(sc._h, norm.ctypes.data, north.ctypes.data, 2, 2, hori.ctypes.data, in0, in1, A,
+                                        2.0, 1.0, b"guess_constant", -30.0, m.ctypes.data, -1.0, 0.01, C.byref(o), C.byref(st))
+        return rc, hori, svf, st
+
+    rc, full, svf_full, st = call(0, 0)
+    assert rc == 0 and not np.isnan(full).any() and st.num_cells == int(mask.sum())
+    rc, h, _, _ = call(0, -1)
+    assert rc == 0 and np.array_equal(h, full)
+    rc, h, _, _ = call(7, -1)
+    assert rc == 0 and np.array_equal(h[7:], full[7:]) and np.isnan(h[:7]).all()
+    for rb, re in ((-1, 5), (3, -2), (0, in0 + 1), (9, 4), (-3, -1)):
+        rc, h, _, _ = call(rb, re)
+        assert rc == 1 and b"row slab" in L.hz_last_error() and np.isnan(h).all(), (rb, re)
+    rc, h, s, st = call(6, 6)                                   # empty slab: a rank without rows
+    assert rc == 0 and np.isnan(h).all() and np.isnan(s).all() and st.num_cells == 0 and st.num_rays == 0
+    # slab-local inputs (and outputs): the caller holds rows [11, 29) only
+    rb, re = 11, 29
+    cut = lambda a: np.ascontiguousarray(a[rb:re])
+    rc, h, s, st = call(rb, re, cut(kw["vec_norm"]), cut(kw["vec_north"]), cut(mask), cut(tilt), slab_in=1, slab_out=1)
+    assert rc == 0 and np.array_equal(h, full[rb:re]) and np.array_equal(s, svf_full[rb:re])
+    assert st.num_cells == int(mask[rb:re].sum())
+
+
 @pytest.mark.parametrize("chunk", (1, 7, 16, 1000))
 def test_streamed_host_output(hip, chunk):
     """Host `hori`: chunks of rows are double buffered on the device and copied out while the next
@@ -444,6 +490,40 @@ def test_shadow_and_sw_dir_cor(hip, orc, refrac):
         assert np.all(sg[mask == 0] == 3) and np.all(fg[mask == 0] == np.float32(-9.0))
         n_shaded += int((sg == 2).sum())
     assert n_shaded > 0
+
+
+def test_refraction_against_platform_libm(hip, orc):
+    """The refraction branch's five float libm calls (shadow_comp.cpp:135-159, :430-446) are glibc's in the reference;
+    product and oracle both use the correctly rounded hz_crmath.h, so their equality (test above) holds by
+    construction.  This test is the independent one: the oracle switched to the PLATFORM's acosf / tanf / powf / cosf /
+    sinf (orc.set_libm(True)).  The contract is then a tolerance, not equality: a last-bit difference in the refraction
+    angle may move a sun direction by one ulp, flip a grazing ray and change sw_dir_cor in the last digits."""
+    from horayzon_amd import synth
+    g = cases.c2_hill(height=1500.0)
+    vec_tilt, vec_norm, enl, elev, mask = cases.terrain_inputs(g)
+    tg, tc = hip.shadow.Terrain(), orc.Terrain()
+    args = (g["vert_grid"], 200, 200, 10, 10, vec_tilt, vec_norm, enl, elev, mask)
+    tg.initialise(*args, refrac_cor=True, sw_dir_cor_fill=-9.0)
+    tc.initialise(*args, refrac_cor=True, sw_dir_cor_fill=-9.0)
+    suns, alt, _ = synth.sun_positions(num=24)
+    suns = suns + np.array([5000.0, 5000.0, 0.0], np.float32)
+    orc.set_libm(True)
+    try:
+        n, flips, worst = 0, 0, 0.0
+        for s in range(suns.shape[0]):
+            sg = np.full(mask.shape, 255, np.uint8); sc = sg.copy()
+            tg.shadow(suns[s], sg); tc.shadow(suns[s], sc)
+            fg = np.full(mask.shape, np.nan, np.float32); fc = fg.copy()
+            tg.sw_dir_cor(suns[s], fg); tc.sw_dir_cor(suns[s], fc)
+            same = sg == sc
+            n += sg.size; flips += int((~same).sum())
+            if same.any():
+                d = np.abs(fg[same] - fc[same]) / np.maximum(np.abs(fc[same]), 1.0)
+                worst = max(worst, float(d.max()))
+    finally:
+        orc.set_libm(False)
+    assert flips <= 1e-3 * n, (flips, n)              # measured: <= 1e-4 of the shadow codes move with the libm
+    assert worst <= 1e-4, worst                       # sw_dir_cor where the classification agrees
 
 
 def test_shadow_batch_matches_single(hip):
