@@ -40,8 +40,10 @@ def test_rotated_frame_is_not_a_height_field_and_certificates_stay_off(hip, orc)
     h0, _ = hip.horizon.horizon_gridded(**cases.grid_kwargs(g), **par, count_work=True)
     st0 = dict(hip.horizon.last_stats)
     assert st0["height_field"] == 1 and st0["near_used"] == 1 and st0["rays_shortened"] > 0.3 * st0["num_rays"]
-    # and both describe the same terrain: the horizons agree to the table resolution (different float roundings)
-    assert np.abs(h - h0).max() <= np.deg2rad(0.25) * 1.01
+    # and both describe the same terrain: different float roundings of the rotated coordinates move a few grazing
+    # rays, i.e. a result by one search step (10 table entries = 0.5 deg) at most
+    d = np.abs(h - h0)
+    assert d.max() <= np.deg2rad(0.5) * 1.01 and (d > 0).mean() < 0.01
 
 
 def _folded_sheet(n=64, dx=50.0, gap=3.0):
