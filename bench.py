@@ -67,7 +67,9 @@ def parse():
     ap.add_argument("--suns", type=int, default=144, help="c4: sun positions per step")
     ap.add_argument("--refrac", type=int, default=0, help="c4: atmospheric refraction on (1) / off (0)")
     ap.add_argument("--which", choices=("shadow", "sw_dir_cor"), default="shadow", help="c4: output kind")
-    ap.add_argument("--balance", choices=("cost", "cells"), default="cost", help="c5: how the row slabs are balanced")
+    ap.add_argument("--balance", choices=("cost", "cells"), default="cells",
+                    help="c5: row slabs balanced by cell count (default) or by the sampled cost pre-pass (measured on the "
+                         "synthetic mosaic, 8 emulated ranks: 1.054 against 1.061 max/mean, less than the pre-pass costs)")
     ap.add_argument("--cost-samples", type=int, default=0, help="c5: probe rows of the cost pre-pass (0: max(16, 4 x ranks))")
     ap.add_argument("--emulate-ranks", type=int, default=0, help="c5, one GPU: time the slabs of an R-rank partition one by one")
     ap.add_argument("--dump-svf-rows", default="", help="c5: comma separated inner-domain rows of the gathered SVF to save")
@@ -464,19 +466,25 @@ def run_c5(ctx):
     def compute(b, e):
         return run_slab(b, e, stats)
 
-    # cost of one row: wave-level VALU work of a counting launch with an eighth of the azimuths
+    # cost of a row: the wave-level VALU work (calibrated instructions per wave iteration x the wave-iteration counters
+    # of the counting instantiation) of the 16-row tile row that holds it, with an eighth of the azimuths.  Full 8 x 8
+    # blocks per wave, as in the real launch: the SIMT cost is what is measured, not lane-level ray / node counts
+    # (round 3: one-row probes with lane counts predicted the slab times WORSE than the plain cell count).
     a_probe = max(8, (A // 8) // 4 * 4)
     probe_s = [0.0]
 
     def probe(row):
         t0 = time.perf_counter()
         st = _lib.hz_stats()
-        run_slab(row, row + 1, st, azim=a_probe, count=True)
+        rb = min(row // 16 * 16, max(in0 - 16, 0))
+        re = min(rb + 16, in0)
+        run_slab(rb, re, st, azim=a_probe, count=True)
         probe_s[0] += time.perf_counter() - t0
         m = VALU_MODEL_DEFAULT
-        return m["node_iter"] * st.nodes_visited + 0.5 * m["leaf_iter"] * st.tris_tested + m["refill_iter"] * st.num_rays
+        w = m["node_iter"] * st.wave_node_iters + m["leaf_iter"] * st.wave_leaf_iters + m["refill_iter"] * st.wave_refills
+        return w * in1 / max(st.num_cells, 1)          # cost of one row of in1 cells
 
-    n_samples = args.cost_samples or max(16, 4 * max(world, args.emulate_ranks))
+    n_samples = args.cost_samples or max(32, 8 * max(world, args.emulate_ranks))
 
     slab0 = row_slabs(in0, world)[rank]
     for w in range(warmup):      # a short slab of this rank's rows: clocks, allocator

@@ -59,7 +59,7 @@ SYMBOLS = (
     "hz_slope_plane_meth", "hz_slope_vector_meth", "hz_lonlat2ecef", "hz_ecef2enu", "hz_wgs2swiss", "hz_swiss2wgs",
     "hz_ecef2enu_vector", "hz_surf_norm", "hz_north_dir", "hz_vert_grid_len", "hz_pack_vertices",
     "hz_debug_sort_pairs", "hz_debug_exclusive_scan",
-    "hz_debug_valu_peak", "hz_debug_copy_peak",
+    "hz_debug_valu_peak", "hz_debug_copy_peak", "hz_debug_inst_rate",
     "hz_terrain_create", "hz_terrain_initialise", "hz_terrain_initialise_scene",
     "hz_terrain_shadow", "hz_terrain_sw_dir_cor", "hz_terrain_shadow_batch",
     "hz_terrain_sw_dir_cor_batch", "hz_terrain_count_work", "hz_terrain_destroy",
@@ -143,6 +143,7 @@ def lib():
     L.hz_debug_exclusive_scan.argtypes = [vp, vp, C.c_size_t, ip]
     L.hz_debug_valu_peak.argtypes = [ip, ip, ip, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.hz_debug_copy_peak.argtypes = [ip, C.c_size_t, C.POINTER(C.c_double)]
+    L.hz_debug_inst_rate.argtypes = [ip, ip, C.POINTER(C.c_double)]
     L.hz_terrain_create.argtypes = [ip, C.POINTER(vp)]
     L.hz_terrain_initialise.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, ip, ip, vp, vp, vp,
                                         C.c_char_p, C.c_float, C.c_float, ip, C.POINTER(hz_stats)]

@@ -933,6 +933,12 @@ int hz_debug_valu_peak(int device, int packed, int waves_per_simd, double *winst
     return bench_valu_peak(packed, waves_per_simd, winst_per_s_per_simd, clock_ghz, simds);
 }
 
+int hz_debug_inst_rate(int device, int op, double *cycles_per_inst) {
+    int rc = select_device(device);
+    if (rc) return rc;
+    return bench_inst_rate(op, cycles_per_inst);
+}
+
 int hz_debug_copy_peak(int device, size_t bytes, double *gbs) {
     int rc = select_device(device);
     if (rc) return rc;

@@ -290,12 +290,28 @@ __device__ __forceinline__ bool hz_qbox_hit(const NodeRay &n, const RayBox &r, f
     const float tnz = __builtin_fmaf(zn, n.az, n.bz), tfz = __builtin_fmaf(zf, n.az, n.bz);
     const float tmin = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));
     const float tmax = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tfar));
+#ifdef HZ_PROBE_NO_SLACK      // measurement probe: how much does the relative slack cost?
+    return tmin <= tmax;
+#else
     return tmin <= tmax * 1.000001f;
+#endif
 }
 
 // One 64 B node = 4 x 16 B global loads issued back to back and waited for once.
 // (hipcc was seen to put an s_waitcnt between the halves of the plain C++ form.)
 __device__ __forceinline__ void hz_load_node(const Node *n, float4 &n0, uint4 &n1, uint4 &n2, float4 &n3) {
+#ifdef HZ_PROBE_EXTRA_LOADS   // measurement probe (scripts/build_variant.sh): two more 16 B loads of the same node per visit
+    float4 x0, x1;          // the other half of the node's 128 B cache line: what a 128 B node would touch
+    const Node *n_other = reinterpret_cast<const Node *>(reinterpret_cast<size_t>(n) ^ (size_t)64);
+#if HZ_PROBE_EXTRA_LOADS >= 2
+    asm volatile("global_load_dwordx4 %0, %2, off\n\t"
+                 "global_load_dwordx4 %1, %2, off offset:16"
+                 : "=&v"(x0), "=&v"(x1) : "v"(n_other) : "memory");
+#else
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(x0) : "v"(n_other) : "memory");
+    (void)x1;
+#endif
+#endif
     asm volatile("global_load_dwordx4 %0, %4, off\n\t"
                  "global_load_dwordx4 %1, %4, off offset:16\n\t"
                  "global_load_dwordx4 %2, %4, off offset:32\n\t"

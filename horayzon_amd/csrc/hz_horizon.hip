@@ -316,23 +316,125 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
 //   KIND 0  sky view factor        _sky_view_factor_cy        :412-460
 //   KIND 1  visible sky fraction   _visible_sky_fraction_cy   :499-543
 //   KIND 2  topographic openness   _topographic_openness_cy   :577-603
-// One lane per cell, float32 accumulator and float64 libm calls as the Cython code has them
-// (HBM bound: 4*A (+12) B in, 4 B out per cell).
+//
+// k_topo: one lane per cell for the arithmetic, one wave per 64 consecutive cells for the memory: the wave loads a
+// [64 cells] x [32 azimuths] block of `hori` with 128 B contiguous per half wave into LDS (row stride 33 floats: the
+// transposed reads are conflict free) and every lane then walks ITS cell's 32 values in azimuth order.  The float32
+// accumulator with a float64 add per azimuth is the reference's (topo_param.pyx:446-458: the order of the additions is
+// kept).  (Round 2 read `hori` with one lane per cell straight from HBM: 4 B loads at a stride of 4 A bytes, 1.7 - 3.4 x
+// over-fetch and 31.5 ms per 3601^2 tile for an 18 GB read.)
+//
+// Trigonometry: the Cython code calls libm's float64 atan / cos / sin three times per (cell, azimuth); all arguments
+// lie in [-pi/2, pi/2].  Here ONE float64 sine / cosine pair of the horizon angle (fdlibm's kernel polynomials on the
+// halved argument + the double-angle formulas, |error| < 1e-15) gives cos^2, sin(2 h) / 2 = sin cos and -- through
+// tan(h) >= x  <=>  sin >= x cos -- the comparison with the tilted plane's own horizon atan(x) without an arctangent;
+// the arctangent (float32: the value is rounded to float32 there anyway, :443) is only evaluated where the plane limits.
+// Differences from the libm path are ~1e-7 rad in that branch and ~1e-16 elsewhere; the result is a float32 (the bar is
+// 1e-5, the reference itself is built with -ffast-math).  Each lane prefetches its share of the next block into
+// registers before it reduces the current one.
 // ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void hz_sincos_halfpi(double x, double &s, double &c) {
+    // sin / cos for |x| <= pi/2 (+ a little): kernel polynomials of fdlibm (k_sin.c, k_cos.c; valid on [-pi/4, pi/4])
+    // on y = x / 2, then sin x = 2 sin y cos y, cos x = 1 - 2 sin^2 y
+    const double y = 0.5 * x, z = y * y;
+#define HZ_F(a, b, c_) __builtin_fma((a), (b), (c_))
+    const double ps = HZ_F(z, HZ_F(z, HZ_F(z, HZ_F(z, HZ_F(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                      2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03),
+                      -1.66666666666666324348e-01);
+    const double pc = HZ_F(z, HZ_F(z, HZ_F(z, HZ_F(z, HZ_F(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                      -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03),
+                      4.16666666666666019037e-02);
+    const double sy = HZ_F(y * z, ps, y);
+    const double cy = HZ_F(z * z, pc, HZ_F(-0.5, z, 1.0));
+#undef HZ_F
+    s = 2.0 * sy * cy;
+    c = __builtin_fma(-2.0 * sy, sy, 1.0);
+}
+
+#define HZ_TOPO_CH 32      // azimuths per LDS block
 template <int KIND>
 __global__ __launch_bounds__(256) void k_topo(const float *__restrict__ azim, const float *__restrict__ hori,
                                              const float *__restrict__ vec_tilt, size_t ncell, int A,
                                              float *__restrict__ out) {
-    // sin / cos of the azimuths once per workgroup (float32 of the float64 value, topo_param.pyx:425-426)
-    extern __shared__ float az_tab[];                 // [2 * A] when it fits, else unused
-    const bool tab = (KIND != 2) && (2 * (size_t)A * sizeof(float) <= 48 * 1024);
-    if (tab) {
+    extern __shared__ float topo_lds[];                 // [2 A] sin / cos of the azimuths, then 4 x [64][33] blocks
+    float *az_tab = topo_lds;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    float *tile = topo_lds + 2 * A + wave * (64 * (HZ_TOPO_CH + 1));
+    if (KIND != 2) {                                    // float32 of the float64 value, topo_param.pyx:425-426
         for (int k = threadIdx.x; k < A; k += blockDim.x) {
             az_tab[k] = (float)sin((double)azim[k]);
             az_tab[A + k] = (float)cos((double)azim[k]);
         }
-        __syncthreads();
     }
+    const size_t cell0 = ((size_t)blockIdx.x * 4 + wave) * 64;
+    const size_t c = cell0 + lane;
+    const bool have = c < ncell;
+    float tx = 0.0f, ty = 0.0f, tz = 1.0f;
+    if (KIND != 2 && have) { tx = vec_tilt[3 * c]; ty = vec_tilt[3 * c + 1]; tz = vec_tilt[3 * c + 2]; }
+    // tangent of the tilted plane's own horizon: x = -sin(az) tx / tz - cos(az) ty / tz (:441-443); the two quotients
+    // are formed once per cell (the Cython expression divides per azimuth: same value to a float rounding)
+    const float qx = -tx / tz, qy = -ty / tz;
+    const double half_pi = 3.14159265358979323846 / 2.0;
+    float agg = 0.0f;
+    const int half = lane >> 5, col = lane & 31;
+    // this lane's share of a block: rows half, half + 2, ... of column `col` (128 B contiguous per half wave and row)
+    const size_t n_rows = cell0 < ncell ? min((size_t)64, ncell - cell0) : 0;
+    const float *src = hori + (cell0 + half) * (size_t)A + col;
+    float pre[32];
+    auto fetch = [&](int k0) {
+        const int n = min(HZ_TOPO_CH, A - k0);
+#pragma unroll
+        for (int r = 0; r < 32; r++) {
+            pre[r] = 0.0f;
+            if (col < n && (size_t)(2 * r + half) < n_rows) pre[r] = src[(size_t)(2 * r) * A + k0];
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < A; k0 += HZ_TOPO_CH) {
+        const int n = min(HZ_TOPO_CH, A - k0);
+        __syncthreads();                                // the previous block has been consumed (and az_tab is written)
+#pragma unroll
+        for (int r = 0; r < 32; r++) tile[(2 * r + half) * (HZ_TOPO_CH + 1) + col] = pre[r];
+        if (k0 + HZ_TOPO_CH < A) fetch(k0 + HZ_TOPO_CH);   // the next block's loads fly while this one is reduced
+        __syncthreads();
+        if (!have) continue;
+        const float *row = tile + lane * (HZ_TOPO_CH + 1);
+        for (int kk = 0; kk < n; kk++) {
+            const float hv = row[kk];
+            if (KIND == 2) {
+                agg = (float)(((double)agg + half_pi) - (double)hv);                         // :599
+                continue;
+            }
+            const float as = az_tab[k0 + kk], ac = az_tab[A + k0 + kk];
+            const float xf = as * qx + ac * qy;
+            double sn, cs;
+            hz_sincos_halfpi((double)hv, sn, cs);
+            double he = (double)hv;
+            // hv < atan(x)  <=>  sin < x cos: the tilted plane hides the horizon (:444 takes the larger angle)
+            if (!(sn >= (double)xf * cs)) {
+                const float hp = atanf(xf);
+                if (!(hv >= hp)) { he = (double)hp; hz_sincos_halfpi(he, sn, cs); }
+            }
+            if (KIND == 0) {
+                agg = (float)((double)agg + ((double)(tx * as + ty * ac) * ((half_pi - he) - sn * cs)
+                              + (double)tz * (cs * cs)));                                     // :446-452
+            } else {
+                agg = (float)((double)agg + (1.0 - sn));           // 1 - cos(pi/2 - he), :540
+            }
+        }
+    }
+    if (!have) return;
+    if (KIND == 2) { out[c] = agg / (float)A; return; }                                     // :601
+    const float azim_spac = azim[1] - azim[0];
+    out[c] = (float)(((double)azim_spac / (2.0 * 3.14159265358979323846)) * (double)agg);
+}
+
+// fallback for azimuth counts whose sine / cosine table does not fit in LDS: one lane per cell, libm calls as the
+// Cython code has them (the round-2 kernel)
+template <int KIND>
+__global__ __launch_bounds__(256) void k_topo_wide(const float *__restrict__ azim, const float *__restrict__ hori,
+                                                  const float *__restrict__ vec_tilt, size_t ncell, int A,
+                                                  float *__restrict__ out) {
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncell) return;
     float tx = 0.0f, ty = 0.0f, tz = 1.0f;
@@ -342,11 +444,11 @@ __global__ __launch_bounds__(256) void k_topo(const float *__restrict__ azim, co
     for (int k = 0; k < A; k++) {
         const float hv = h[k];
         if (KIND == 2) {
-            agg = (float)(((double)agg + (3.14159265358979323846 / 2.0)) - (double)hv);     // :599
+            agg = (float)(((double)agg + (3.14159265358979323846 / 2.0)) - (double)hv);
             continue;
         }
-        const float as = tab ? az_tab[k] : (float)sin((double)azim[k]);
-        const float ac = tab ? az_tab[A + k] : (float)cos((double)azim[k]);
+        const float as = (float)sin((double)azim[k]);
+        const float ac = (float)cos((double)azim[k]);
         const float hori_plane = (float)atan((double)(-as * tx / tz - ac * ty / tz));
         const float he = (hv >= hori_plane) ? hv : hori_plane;
         if (KIND == 0) {
@@ -355,10 +457,10 @@ __global__ __launch_bounds__(256) void k_topo(const float *__restrict__ azim, co
                           * ((3.14159265358979323846 / 2.0) - (double)he - (sin(2.0 * (double)he) / 2.0))
                           + (double)tz * (ce * ce)));
         } else {
-            agg = (float)((double)agg + (1.0 - cos((3.14159265358979323846 / 2.0) - (double)he)));   // :540
+            agg = (float)((double)agg + (1.0 - cos((3.14159265358979323846 / 2.0) - (double)he)));
         }
     }
-    if (KIND == 2) { out[c] = agg / (float)A; return; }                                     // :601
+    if (KIND == 2) { out[c] = agg / (float)A; return; }
     const float azim_spac = azim[1] - azim[0];
     out[c] = (float)(((double)azim_spac / (2.0 * 3.14159265358979323846)) * (double)agg);
 }
@@ -367,12 +469,18 @@ int topo_launch(int kind, const float *azim, const float *hori, const float *vec
                 int len_2, float *out, hipStream_t st) {
     const size_t ncell = (size_t)len_0 * len_1;
     if (ncell == 0) return HZ_OK;
-    const dim3 grid((unsigned)((ncell + 255) / 256)), block(256);
-    const size_t tab_bytes = 2 * (size_t)len_2 * sizeof(float);
-    const size_t lds = (kind != 2 && tab_bytes <= 48 * 1024) ? tab_bytes : 0;
-    if (kind == 0) hipLaunchKernelGGL(k_topo<0>, grid, block, lds, st, azim, hori, vec_tilt, ncell, len_2, out);
-    else if (kind == 1) hipLaunchKernelGGL(k_topo<1>, grid, block, lds, st, azim, hori, vec_tilt, ncell, len_2, out);
-    else hipLaunchKernelGGL(k_topo<2>, grid, block, lds, st, azim, hori, vec_tilt, ncell, len_2, out);
+    const size_t lds = (2 * (size_t)len_2 + 4 * 64 * (HZ_TOPO_CH + 1)) * sizeof(float);
+    if (lds <= 60 * 1024) {
+        const dim3 grid((unsigned)((ncell + 255) / 256)), block(256);
+        if (kind == 0) hipLaunchKernelGGL(k_topo<0>, grid, block, lds, st, azim, hori, vec_tilt, ncell, len_2, out);
+        else if (kind == 1) hipLaunchKernelGGL(k_topo<1>, grid, block, lds, st, azim, hori, vec_tilt, ncell, len_2, out);
+        else hipLaunchKernelGGL(k_topo<2>, grid, block, lds, st, azim, hori, vec_tilt, ncell, len_2, out);
+    } else {
+        const dim3 grid((unsigned)((ncell + 255) / 256)), block(256);
+        if (kind == 0) hipLaunchKernelGGL(k_topo_wide<0>, grid, block, 0, st, azim, hori, vec_tilt, ncell, len_2, out);
+        else if (kind == 1) hipLaunchKernelGGL(k_topo_wide<1>, grid, block, 0, st, azim, hori, vec_tilt, ncell, len_2, out);
+        else hipLaunchKernelGGL(k_topo_wide<2>, grid, block, 0, st, azim, hori, vec_tilt, ncell, len_2, out);
+    }
     HZ_HIP(hipGetLastError());
     return HZ_OK;
 }

@@ -187,6 +187,7 @@ int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *te
 // hz_bench.hip: machine calibration kernels (current device)
 int bench_valu_peak(int packed, int waves_per_simd, double *winst_per_s_per_simd, double *clock_ghz, int *simds);
 int bench_copy_peak(size_t bytes, double *gbs);
+int bench_inst_rate(int op, double *cycles_per_inst);
 
 // hz_prep.hip (device pointers)
 int prep_slope(int which, const float *x, const float *y, const float *z, int len_0, int len_1,

@@ -222,6 +222,8 @@ int hz_debug_exclusive_scan(const uint32_t *in, uint32_t *out, size_t n, int dev
 int hz_debug_valu_peak(int device, int packed, int waves_per_simd, double *winst_per_s_per_simd,
                        double *clock_ghz, int *simds);
 int hz_debug_copy_peak(int device, size_t bytes, double *gbs);
+/* issue rate of one VALU instruction kind (selector list: hz_bench.hip) in cycles per wave64 instruction per SIMD */
+int hz_debug_inst_rate(int device, int op, double *cycles_per_inst);
 
 /* ------------------------------------------------------------------------- */
 /* Steps next to the path: slope and input preparation */

@@ -37,7 +37,7 @@ def test_config5_row_sharding_with_two_ranks():
     """Two ranks: only rank 0 synthesises the DEM, the blob is broadcast out of its own allocation, rank 1 derives its
     slab's inputs from the received vertices (slab-local, opts.inputs_are_slab), the slabs come from the sampled cost
     pre-pass (probe rows split over both ranks, joined by one all_reduce)."""
-    d = _run(29622, "--workload", "c5", "--tile", "801", "--azim", "72")
+    d = _run(29622, "--workload", "c5", "--tile", "801", "--azim", "72", "--balance", "cost")
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     c = d["config"]
     slabs = c["slabs"]
