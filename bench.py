@@ -679,6 +679,28 @@ def cpu_baseline(g, args, A):
     _, _, st = orc.horizon_gridded(**kw, dist_search=args.dist_search, azim_num=A, rows=(rb, rb + args.cpu_rows),
                                    slab_only=True, return_stats=True)
     cells = args.cpu_rows * g["vec_norm"].shape[1]
+    embree = None
+    tpath = os.path.join(ROOT, "tests", "golden", "embree_timing.json")
+    if os.path.exists(tpath):      # recorded by scripts/make_embree_fixtures.py where the reference is installed
+        try:
+            tj = json.load(open(tpath))
+            c3 = tj.get("c3_tile") or {}
+            if c3.get("cells_per_s"):
+                embree = {"kind": "embree", "value": c3["cells_per_s"], "unit": "cells/s", "mray_per_s": c3.get("mray_per_s"),
+                          "cores": (tj.get("environment") or {}).get("logical_cores"),
+                          "recorded_on": tj.get("environment"), "reference_version": tj.get("reference_version"),
+                          "sample": "%s rows of the same 3601^2 tile, the reference's own 'Ray tracing time' "
+                                    "(horizon_comp.cpp:802-810); recorded elsewhere, NOT timed on this node" % c3.get("rows")}
+        except Exception:
+            embree = None
+    base = _cpu_port_line(cells, st, args, g, A, orc)
+    base["embree"] = embree if embree is not None else (
+        "unavailable: Embree 4 / oneTBB are not installed on this node (and not in the build image); "
+        "scripts/make_embree_fixtures.py records the reference's own timing into tests/golden/embree_timing.json where they are")
+    return base
+
+
+def _cpu_port_line(cells, st, args, g, A, orc):
     return {"value": cells / st["t_rays_s"], "unit": "cells/s", "cores": orc.num_threads(), "kind": "port",
             "mray_per_s": st["rays"] / st["t_rays_s"] / 1e6, "bvh_build_s": st["t_build_s"],
             "sample": "%d rows x %d cells x %d azimuths from the middle of the same tile, ray loop only "

@@ -3,7 +3,9 @@
 conda environment of its README) on the parity configurations of this repository and write its outputs to
 tests/golden/embree_*.npz.  `pytest -m gpu tests/test_gpu_embree_pin.py` (HIP kernels) and
 `pytest tests/test_oracle.py -k embree` (CPU oracle) then compare against those files and report the mismatch
-fraction against the north-star bar (1e-4 rad horizon, 1e-5 SVF).
+fraction against the north-star bar (1e-4 rad horizon, 1e-5 SVF).  It also records the reference's own printed
+"Ray tracing time" / ray count per case and for a band of the 3601^2 benchmark tile, the Embree / TBB libraries it ran
+with and the core count, in tests/golden/embree_timing.json -- bench.py then reports that as `cpu_baseline.embree`.
 
 The build environment of this repository has neither Embree nor a network, so the files cannot be produced here:
 until a maintainer runs this script once, parity stays "unpinned" for the ray-casting decisions.
@@ -92,17 +94,100 @@ def shadow_case():
     return g, (vec_tilt, vec_norm, enl, elev, mask), suns
 
 
+class CaptureStdout:
+    """The reference reports from C++ (printf, horizon_comp.cpp:225-227, :802-810): capture file descriptor 1."""
+
+    def __enter__(self):
+        import tempfile
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        self._tmp = tempfile.TemporaryFile(mode="w+b")
+        os.dup2(self._tmp.fileno(), 1)
+        return self
+
+    def __exit__(self, *exc):
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        self._tmp.seek(0)
+        self.text = self._tmp.read().decode("utf-8", "replace")
+        self._tmp.close()
+        sys.stdout.write(self.text)
+        return False
+
+
+def parse_report(text):
+    """"BVH build time", "Ray tracing time", "Number of rays shot", cell count from the reference's stdout."""
+    import re
+    out = {}
+    for key, pat in (("bvh_build_s", r"BVH build time:\s*([0-9.eE+-]+)"), ("ray_tracing_s", r"Ray tracing time:\s*([0-9.eE+-]+)"),
+                     ("rays", r"Number of rays shot:\s*([0-9]+)"), ("cells", r"horizon is computed:\s*([0-9]+)"),
+                     ("total_run_s", r"Total run time:\s*([0-9.eE+-]+)")):
+        m = re.search(pat, text)
+        if m:
+            out[key] = float(m.group(1)) if key not in ("rays", "cells") else int(m.group(1))
+    return out
+
+
+def environment():
+    """What the timings were taken on: CPU model, logical cores, the Embree / TBB libraries mapped into this process."""
+    import platform
+    env = {"host": platform.node(), "logical_cores": os.cpu_count(), "python": platform.python_version()}
+    try:
+        with open("/proc/cpuinfo") as f:
+            env["cpu_model"] = next((l.split(":", 1)[1].strip() for l in f if l.startswith("model name")), None)
+    except OSError:
+        pass
+    try:
+        with open("/proc/self/maps") as f:
+            libs = sorted({l.split()[-1] for l in f if ("embree" in l or "libtbb" in l) and "/" in l})
+        env["embree_tbb_libraries"] = [os.path.realpath(x) for x in libs]
+    except OSError:
+        pass
+    return env
+
+
+def bench_tile(hz, n=3601, rows=64):
+    """The headline configuration (BASELINE.json config 3: 3601^2 synthetic tile, 360 azimuths, guess_constant,
+    dist_search 50 km) with the reference itself, restricted by `mask` to `rows` rows in the middle of the tile (the
+    reference has no row-slab argument; rim cells are avoided because its search does not terminate there,
+    horizon_comp.cpp:474-488).  Returns the reference's own "Ray tracing time" and ray count for those cells."""
+    sys.path.insert(0, ROOT)
+    from horayzon_amd import synth
+    off = 16
+    g = synth.fractal_tile(n=n, offset=off)
+    in0 = n - 2 * off
+    mask = np.zeros((in0, in0), np.uint8)
+    mask[in0 // 2:in0 // 2 + rows] = 1
+    with CaptureStdout() as cap:
+        hz.horizon_gridded(g["vert_grid"], n, n, g["vec_norm"], g["vec_north"], off, off, 50.0, azim_num=360, mask=mask)
+    rep = parse_report(cap.text)
+    rep.update(tile=n, rows=rows, cells_expected=rows * in0, azim_num=360, dist_search_km=50.0, ray_algorithm="guess_constant")
+    if rep.get("ray_tracing_s") and rep.get("rays"):
+        rep["mray_per_s"] = rep["rays"] / rep["ray_tracing_s"] / 1e6
+        rep["cells_per_s"] = rep.get("cells", rows * in0) / rep["ray_tracing_s"]
+    return rep
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--bench-rows", type=int, default=64, help="rows of the 3601^2 tile timed with the reference (0: skip)")
     args = ap.parse_args()
     ref, hz, sh, tp = import_reference()
     os.makedirs(args.out, exist_ok=True)
     store = {}
+    timing = {"reference_version": getattr(ref, "__version__", "unknown"), "cases": {}}
     for name, kw, par in pin_cases():
         print("reference horizon_gridded:", name, flush=True)
-        hori, azim = hz.horizon_gridded(kw["vert_grid"], kw["dem_dim_0"], kw["dem_dim_1"], kw["vec_norm"], kw["vec_north"],
-                                        kw["offset_0"], kw["offset_1"], **par)
+        with CaptureStdout() as cap:
+            hori, azim = hz.horizon_gridded(kw["vert_grid"], kw["dem_dim_0"], kw["dem_dim_1"], kw["vec_norm"], kw["vec_north"],
+                                            kw["offset_0"], kw["offset_1"], **par)
+        timing["cases"][name] = parse_report(cap.text)       # the reference's printed "Ray tracing time" / ray count
         store["hori__" + name] = hori
         store["azim__" + name] = azim
     # SVF of the first case through the reference's own topo_param (pins the fused SVF too)
@@ -124,7 +209,17 @@ def main():
             sstore["shadow__%s_refrac%d" % (geom, int(refrac))] = shm
             sstore["sw_dir_cor__%s_refrac%d" % (geom, int(refrac))] = swc
     np.savez_compressed(os.path.join(args.out, "embree_shadow.npz"), **sstore)
-    print("wrote", os.path.join(args.out, "embree_horizon.npz"), "and embree_shadow.npz")
+    # the CPU baseline north_star asks for: the reference's own TBB / Embree path on this machine's cores.  bench.py
+    # reports it as cpu_baseline.embree when tests/golden/embree_timing.json exists (labelled with the host it was
+    # recorded on -- the GPU box has no Embree).
+    timing["environment"] = environment()
+    if args.bench_rows > 0:
+        print("reference horizon_gridded: 3601^2 tile, %d rows (timing)" % args.bench_rows, flush=True)
+        timing["c3_tile"] = bench_tile(hz, rows=args.bench_rows)
+    import json
+    with open(os.path.join(args.out, "embree_timing.json"), "w") as f:
+        json.dump(timing, f, indent=1)
+    print("wrote", os.path.join(args.out, "embree_horizon.npz"), ", embree_shadow.npz and embree_timing.json")
 
 
 if __name__ == "__main__":

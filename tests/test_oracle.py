@@ -428,3 +428,54 @@ def test_embree_pin_harness_is_consistent(orc):
 
 
 _orig_harness = embree_pin._harness
+
+
+def test_triangle_test_sensitivity_variants(orc):
+    """oracle/hz_oracle.c "SENSITIVITY VARIANTS": how far can Embree's FMA / rcp evaluation of the robust Pluecker test
+    sit from the plain-IEEE one that is the contract?  (scripts/embree_sensitivity.py runs the full workloads; this
+    keeps the machinery honest: the comparison pass does not disturb the result, the FMA / rcp variant flips at most a
+    few rays per million, Moeller-Trumbore -- not watertight along shared edges -- flips orders of magnitude more on
+    the grid-aligned hill.)"""
+    g = cases.rough_terrain(80, 70, seed=8, offset=5, relief=700.0, tilt_frames=True, origin=(2.6e6, 1.2e6))
+    kw = cases.grid_kwargs(g)
+    par = dict(dist_search=3.0, azim_num=24, hori_acc=0.25, elev_ang_low_lim=-45.0)
+    try:
+        base, _, so = orc.horizon_gridded(**kw, **par, return_stats=True)
+        orc.set_tri_compare("embree_fma_rcp")
+        again, _ = orc.horizon_gridded(**kw, **par)
+        n, flips = orc.tri_compare_counts()
+        orc.set_tri_compare(None)
+        assert np.array_equal(again, base) and n == so["rays"]
+        assert flips <= 5e-6 * n + 2, (flips, n)
+        orc.set_tri_mode("embree_fma_rcp")
+        var, _ = orc.horizon_gridded(**kw, **par)
+        orc.set_tri_mode("plain")
+        assert (var != base).mean() <= 1e-4 and np.abs(var - base).max() <= np.deg2rad(0.5) * 1.01
+        # the grid-aligned hill: rays along grid lines and diagonals pass exactly through shared edges
+        h = cases.grid_kwargs(cases.c2_hill())
+        orc.set_tri_compare("moeller_trumbore")
+        orc.horizon_gridded(**h, dist_search=10.0, azim_num=8, rows=(80, 100), slab_only=True)
+        n_mt, flips_mt = orc.tri_compare_counts()
+        orc.set_tri_compare("embree_fma_rcp")
+        orc.horizon_gridded(**h, dist_search=10.0, azim_num=8, rows=(80, 100), slab_only=True)
+        n_e, flips_e = orc.tri_compare_counts()
+        assert n_mt == n_e and flips_mt > 100 * max(flips_e, 1)
+    finally:
+        orc.set_tri_compare(None)
+        orc.set_tri_mode("plain")
+
+
+def test_embree_fixture_script_parses_the_reference_report():
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("mef", os.path.join(os.path.dirname(os.path.dirname(__file__)), "scripts",
+                                                                      "make_embree_fixtures.py"))
+    mef = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mef)
+    text = ("BVH build time: 0.731 s\nHorizon detection algorithm: guess horizon from previous azimuth direction\n"
+            "Number of grid cells for which horizon is computed: 228416 \nRay tracing time: 12.5 s\n"
+            "Number of rays shot: 177000000\nTotal run time: 14.1 s\n")
+    rep = mef.parse_report(text)
+    assert rep == {"bvh_build_s": 0.731, "ray_tracing_s": 12.5, "rays": 177000000, "cells": 228416, "total_run_s": 14.1}
+    env = mef.environment()
+    assert env["logical_cores"] >= 1 and "host" in env
