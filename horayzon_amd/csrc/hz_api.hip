@@ -1228,14 +1228,18 @@ static int terrain_run(Terrain *t, const float *sun_positions, int num_sun, int 
     float ms = 0.0f;
     unsigned long long cnt[16];
     {
+        // the sun positions go to the device once; one launch computes up to 32768 of them (grid.y)
+        DevIn<float> d_sun;
+        if ((rc = d_sun.bind(sun.data(), sun.size(), st))) return rc;
         HZ_HIP(hipMemsetAsync(t->counters, 0, 16 * sizeof(unsigned long long), st));
         hipEvent_t e0, e1;
         HZ_HIP(hipEventCreate(&e0)); HZ_HIP(hipEventCreate(&e1));
         HZ_HIP(hipEventRecord(e0, st));
-        for (int s = 0; s < num_sun; s++) {
-            a.sun[0] = sun[3 * (size_t)s]; a.sun[1] = sun[3 * (size_t)s + 1]; a.sun[2] = sun[3 * (size_t)s + 2];
-            a.out_u8 = d_u8.dev ? d_u8.dev + nc * (size_t)s : nullptr;
-            a.out_f32 = d_f32.dev ? d_f32.dev + nc * (size_t)s : nullptr;
+        for (int s0 = 0; s0 < num_sun; s0 += 32768) {
+            a.suns = d_sun.dev + 3 * (size_t)s0;
+            a.num_sun = std::min(32768, num_sun - s0);
+            a.out_u8 = d_u8.dev ? d_u8.dev + nc * (size_t)s0 : nullptr;
+            a.out_f32 = d_f32.dev ? d_f32.dev + nc * (size_t)s0 : nullptr;
             if ((rc = shadow_launch(t->scene, a, st))) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); return rc; }
         }
         HZ_HIP(hipEventRecord(e1, st));

@@ -165,7 +165,8 @@ struct ShadowArgs {
     const float *vec_tilt, *vec_norm, *surf_enl_fac, *elevation;   // device
     const uint8_t *mask;
     int offset_0, offset_1, dim_in_0, dim_in_1;
-    float sun[3];
+    const float *suns;                   // device f32[num_sun][3]
+    int num_sun;                         // positions computed by ONE launch (grid.y); outputs [num_sun][dim_in_0][dim_in_1]
     float sw_dir_cor_fill, dot_prod_min;
     int refrac_cor;
     int which;                           // 0 shadow (u8), 1 sw_dir_cor (f32)

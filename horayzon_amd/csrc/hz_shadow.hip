@@ -7,6 +7,7 @@
 // kernel; the BVH is persistent in the Terrain handle (built once, :318-380).
 #include "hz_internal.h"
 #include "hz_crmath.h"
+#include <cstdlib>
 
 namespace hz {
 
@@ -21,11 +22,13 @@ struct ShadowParams {
     const uint8_t *mask;
     int offset_0, offset_1, dim_in_0, dim_in_1;
     TileMap tm;
-    float sun_x, sun_y, sun_z;
+    const float *suns;       // device f32[num_sun][3]; blockIdx.y selects the position
+    size_t out_stride;       // cells per sun position (outputs of position s start at s * out_stride)
     float fill, dot_prod_min;
     int refrac, which;
     uint8_t *out_u8; float *out_f32;
     int top_nodes, stack_bytes;
+    int nb;                  // k_shadow_refill: 8 x 8 blocks per wave
     unsigned long long *counters;
 };
 
@@ -62,88 +65,20 @@ template <bool COUNT>
 __device__ __forceinline__ bool occluded(const SceneView &sv, int *stack, int tid,
                                          float ox, float oy, float oz, float dx, float dy, float dz,
                                          float tfar, TravCounters &tc) {
+#ifdef HZ_PROBE_SHADOW_TN     // measurement probe (results NOT valid): every ray's box tests start HZ_PROBE_SHADOW_TN metres out
+    const float tn_ = (float)HZ_PROBE_SHADOW_TN;
+    const RayBox rb = hz_raybox(ox - sv.cx + tn_ * dx, oy - sv.cy + tn_ * dy, oz - sv.cz + tn_ * dz, dx, dy, dz);
+#else
     const RayBox rb = hz_raybox(ox - sv.cx, oy - sv.cy, oz - sv.cz, dx, dy, dz);
+#endif
     TravState ts; hz_trav_reset(ts);
     unsigned overflow = 0;      // unused: the one-entry-per-level stack cannot overflow
     return hz_trace<HZ_TPB, COUNT>(sv.nodes, sv.prims, nullptr, 0, stack, tid, ox, oy, oz, dx, dy, dz, tfar, rb,
                                    ts, 0, HZ_SHADOW_LEAF_BIAS, tc, 0, overflow) == 1;
 }
 
-// COUNT: also count node visits / triangle tests / wave-level steps (Terrain count_work; the roofline's B_trav)
 template <bool COUNT>
-__global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int *stack = reinterpret_cast<int *>(smem);
-    const int tid = threadIdx.x;
-    int ti = 0, tj = 0;
-    const bool has_tile = hz_tile_of_block(p.tm, blockIdx.x, &ti, &tj);
-    const int wave = tid >> 6, lane = tid & 63;
-    const int i = ti * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const int j = tj * 16 + (wave & 1) * 8 + (lane & 7);
-    const bool in_dom = has_tile && (i < p.dim_in_0) && (j < p.dim_in_1);
-    const size_t cell = in_dom ? ((size_t)i * p.dim_in_1 + j) : 0;
-    unsigned rays = 0;
-    TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.w_nodes = 0; tc.w_leaves = 0;
-    if (in_dom) {
-        if (p.mask[cell] != 1) {                                   // shadow_comp.cpp:480-484 / :594-598
-            if (p.which == 0) p.out_u8[cell] = 3; else p.out_f32[cell] = p.fill;
-        } else {
-            const float tilt_x = p.vec_tilt[3 * cell], tilt_y = p.vec_tilt[3 * cell + 1], tilt_z = p.vec_tilt[3 * cell + 2];
-            const float norm_x = p.vec_norm[3 * cell], norm_y = p.vec_norm[3 * cell + 1], norm_z = p.vec_norm[3 * cell + 2];
-            const float ray_org_elev = 0.05f;                      // :388, :497
-            const float *v = p.sv.verts + 3 * ((size_t)(i + p.offset_0) * p.sv.d1 + (size_t)(j + p.offset_1));
-            const float ox = v[0] + norm_x * ray_org_elev;
-            const float oy = v[1] + norm_y * ray_org_elev;
-            const float oz = v[2] + norm_z * ray_org_elev;
-            float sun_x = p.sun_x - ox, sun_y = p.sun_y - oy, sun_z = p.sun_z - oz;   // :422-425
-            vec_unit(sun_x, sun_y, sun_z);
-            float dot_prod_ns = (norm_x * sun_x + norm_y * sun_y) + norm_z * sun_z;
-            if (p.refrac == 1) {                                   // :430-446
-                const float elev_ang_true = (float)(90.0 - (double)rad2deg_f(f_acos(dot_prod_ns)));
-                const float temperature_ref = 283.15f, pressure_ref = 101.0f, lapse_rate = 0.0065f;
-                const float g = 9.81f, R_d = 287.0f;
-                const float expo = g / (R_d * lapse_rate);         // :353-354
-                const float temperature = temperature_ref - (lapse_rate * p.elevation[cell]);
-                const float pressure = pressure_ref * f_pow(temperature / temperature_ref, expo);
-                const float refrac_cor = atmos_refrac(elev_ang_true, (float)((double)temperature - 273.15), pressure);
-                float k_x = sun_y * norm_z - sun_z * norm_y;
-                float k_y = sun_z * norm_x - sun_x * norm_z;
-                float k_z = sun_x * norm_y - sun_y * norm_x;
-                vec_unit(k_x, k_y, k_z);
-                const float theta = deg2rad_f(refrac_cor);        // vec_rot, :109-132
-                const float ct = f_cos(theta), st = f_sin(theta);
-                const float part = (float)((double)((k_x * sun_x + k_y * sun_y) + k_z * sun_z) * (1.0 - (double)ct));
-                const float rx = (sun_x * ct + (k_y * sun_z - k_z * sun_y) * st) + k_x * part;
-                const float ry = (sun_y * ct + (k_z * sun_x - k_x * sun_z) * st) + k_y * part;
-                const float rz = (sun_z * ct + (k_x * sun_y - k_y * sun_x) * st) + k_z * part;
-                sun_x = rx; sun_y = ry; sun_z = rz;
-                dot_prod_ns = (norm_x * sun_x + norm_y * sun_y) + norm_z * sun_z;
-            }
-            const float dot_prod_ts = (tilt_x * sun_x + tilt_y * sun_y) + tilt_z * sun_z;
-            const float inf = __builtin_inff();
-            if (p.which == 0) {                                    // :451-478
-                if (dot_prod_ts > 0.0f) {
-                    rays = 1;
-                    const bool h = occluded<COUNT>(p.sv, stack, tid, ox, oy, oz, sun_x, sun_y, sun_z, inf, tc);
-                    p.out_u8[cell] = h ? 2 : 0;
-                } else {
-                    p.out_u8[cell] = 1;
-                }
-            } else {                                               // :561-592
-                if (dot_prod_ts > p.dot_prod_min) {
-                    rays = 1;
-                    const bool h = occluded<COUNT>(p.sv, stack, tid, ox, oy, oz, sun_x, sun_y, sun_z, inf, tc);
-                    if (h) p.out_f32[cell] = 0.0f;
-                    else {
-                        if (dot_prod_ns < p.dot_prod_min) dot_prod_ns = p.dot_prod_min;
-                        p.out_f32[cell] = (dot_prod_ts / dot_prod_ns) * p.surf_enl_fac[cell];
-                    }
-                } else {
-                    p.out_f32[cell] = 0.0f;
-                }
-            }
-        }
-    }
+__device__ __forceinline__ void shadow_counters(const ShadowParams &p, unsigned rays, const TravCounters &tc, int lane) {
     unsigned long long r = rays;
     for (int off = 32; off > 0; off >>= 1) r += __shfl_xor(r, off);
     if (lane == 0 && r) atomicAdd(&p.counters[0], r);
@@ -159,6 +94,166 @@ __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
     }
 }
 
+// Per-cell set-up shared by both kernels: classification without a ray (masked / self-shaded / outside ang_max) is
+// written at once; otherwise the ray (origin, direction) and the two dot products come back and 1 is returned.
+struct ShadowRay { float ox, oy, oz, dx, dy, dz, dot_ts, dot_ns; };
+
+__device__ __forceinline__ int shadow_setup(const ShadowParams &p, int i, int j, float p_sun_x, float p_sun_y, float p_sun_z,
+                                            uint8_t *out_u8, float *out_f32, ShadowRay &r) {
+    const size_t cell = (size_t)i * p.dim_in_1 + j;
+    if (p.mask[cell] != 1) {                                       // shadow_comp.cpp:480-484 / :594-598
+        if (p.which == 0) out_u8[cell] = 3; else out_f32[cell] = p.fill;
+        return 0;
+    }
+    const float tilt_x = p.vec_tilt[3 * cell], tilt_y = p.vec_tilt[3 * cell + 1], tilt_z = p.vec_tilt[3 * cell + 2];
+    const float norm_x = p.vec_norm[3 * cell], norm_y = p.vec_norm[3 * cell + 1], norm_z = p.vec_norm[3 * cell + 2];
+    const float ray_org_elev = 0.05f;                              // :388, :497
+    const float *v = p.sv.verts + 3 * ((size_t)(i + p.offset_0) * p.sv.d1 + (size_t)(j + p.offset_1));
+    const float ox = v[0] + norm_x * ray_org_elev;
+    const float oy = v[1] + norm_y * ray_org_elev;
+    const float oz = v[2] + norm_z * ray_org_elev;
+    float sun_x = p_sun_x - ox, sun_y = p_sun_y - oy, sun_z = p_sun_z - oz;   // :422-425
+    vec_unit(sun_x, sun_y, sun_z);
+    float dot_prod_ns = (norm_x * sun_x + norm_y * sun_y) + norm_z * sun_z;
+    if (p.refrac == 1) {                                           // :430-446
+        const float elev_ang_true = (float)(90.0 - (double)rad2deg_f(f_acos(dot_prod_ns)));
+        const float temperature_ref = 283.15f, pressure_ref = 101.0f, lapse_rate = 0.0065f;
+        const float g = 9.81f, R_d = 287.0f;
+        const float expo = g / (R_d * lapse_rate);                 // :353-354
+        const float temperature = temperature_ref - (lapse_rate * p.elevation[cell]);
+        const float pressure = pressure_ref * f_pow(temperature / temperature_ref, expo);
+        const float refrac_cor = atmos_refrac(elev_ang_true, (float)((double)temperature - 273.15), pressure);
+        float k_x = sun_y * norm_z - sun_z * norm_y;
+        float k_y = sun_z * norm_x - sun_x * norm_z;
+        float k_z = sun_x * norm_y - sun_y * norm_x;
+        vec_unit(k_x, k_y, k_z);
+        const float theta = deg2rad_f(refrac_cor);                // vec_rot, :109-132
+        const float ct = f_cos(theta), st = f_sin(theta);
+        const float part = (float)((double)((k_x * sun_x + k_y * sun_y) + k_z * sun_z) * (1.0 - (double)ct));
+        const float rx = (sun_x * ct + (k_y * sun_z - k_z * sun_y) * st) + k_x * part;
+        const float ry = (sun_y * ct + (k_z * sun_x - k_x * sun_z) * st) + k_y * part;
+        const float rz = (sun_z * ct + (k_x * sun_y - k_y * sun_x) * st) + k_z * part;
+        sun_x = rx; sun_y = ry; sun_z = rz;
+        dot_prod_ns = (norm_x * sun_x + norm_y * sun_y) + norm_z * sun_z;
+    }
+    const float dot_prod_ts = (tilt_x * sun_x + tilt_y * sun_y) + tilt_z * sun_z;
+    if (p.which == 0) {                                            // :451-478
+        if (!(dot_prod_ts > 0.0f)) { out_u8[cell] = 1; return 0; }
+    } else {                                                       // :561-592
+        if (!(dot_prod_ts > p.dot_prod_min)) { out_f32[cell] = 0.0f; return 0; }
+    }
+    r.ox = ox; r.oy = oy; r.oz = oz; r.dx = sun_x; r.dy = sun_y; r.dz = sun_z;
+    r.dot_ts = dot_prod_ts; r.dot_ns = dot_prod_ns;
+    return 1;
+}
+
+__device__ __forceinline__ void shadow_result(const ShadowParams &p, size_t cell, bool hit, const ShadowRay &r,
+                                              uint8_t *out_u8, float *out_f32) {
+    if (p.which == 0) { out_u8[cell] = hit ? 2 : 0; return; }
+    if (hit) { out_f32[cell] = 0.0f; return; }
+    float dot_prod_ns = r.dot_ns;
+    if (dot_prod_ns < p.dot_prod_min) dot_prod_ns = p.dot_prod_min;
+    out_f32[cell] = (r.dot_ts / dot_prod_ns) * p.surf_enl_fac[cell];
+}
+
+// k_shadow: one lane = one cell, one ray, traced to completion (the round-2 kernel; HZ_SHADOW_REFILL=0 selects it).
+// COUNT: also count node visits / triangle tests / wave-level steps (Terrain count_work; the roofline's B_trav)
+template <bool COUNT>
+__global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *stack = reinterpret_cast<int *>(smem);
+    const int tid = threadIdx.x;
+    int ti = 0, tj = 0;
+    const bool has_tile = hz_tile_of_block(p.tm, blockIdx.x, &ti, &tj);
+    const int wave = tid >> 6, lane = tid & 63;
+    const int i = ti * 16 + (wave >> 1) * 8 + (lane >> 3);
+    const int j = tj * 16 + (wave & 1) * 8 + (lane & 7);
+    const bool in_dom = has_tile && (i < p.dim_in_0) && (j < p.dim_in_1);
+    // all sun positions of a batch in ONE launch (grid.y): no launch gap and no draining tail between positions, and
+    // the workgroups of night positions (no rays) make room at once
+    const int sun_idx = blockIdx.y;
+    const float p_sun_x = p.suns[3 * sun_idx], p_sun_y = p.suns[3 * sun_idx + 1], p_sun_z = p.suns[3 * sun_idx + 2];
+    uint8_t *const out_u8 = p.out_u8 ? p.out_u8 + (size_t)sun_idx * p.out_stride : nullptr;
+    float *const out_f32 = p.out_f32 ? p.out_f32 + (size_t)sun_idx * p.out_stride : nullptr;
+    unsigned rays = 0;
+    TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.w_nodes = 0; tc.w_leaves = 0;
+    ShadowRay r;
+    if (in_dom && shadow_setup(p, i, j, p_sun_x, p_sun_y, p_sun_z, out_u8, out_f32, r)) {
+        rays = 1;
+        const bool h = occluded<COUNT>(p.sv, stack, tid, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, __builtin_inff(), tc);
+        shadow_result(p, (size_t)i * p.dim_in_1 + j, h, r, out_u8, out_f32);
+    }
+    shadow_counters<COUNT>(p, rays, tc, lane);
+}
+
+// k_shadow_refill: a wave owns p.nb consecutive 8 x 8 blocks (the same quadrant of nb neighbouring 16 x 16
+// tiles) and hands their cells to its lanes as they become free.  The rays of one sun position are parallel, so a
+// wave's duration in k_shadow is its longest ray while most lanes idle (45 % of the lanes active per VALU
+// instruction, profiles/r02/pmc_shadow_summary.json); here a lane whose ray is finished takes the next cell once
+// fewer than `regroup` lanes are still traversing (the ray compaction of the horizon kernel).  Cells are handed out
+// in block order, so the rays in flight stay neighbours.  Results are those of k_shadow bit for bit.
+#ifndef HZ_SHADOW_REGROUP
+#define HZ_SHADOW_REGROUP 40      // refill when fewer lanes than this are still traversing
+#endif
+template <bool COUNT>
+__global__ __launch_bounds__(HZ_TPB) void k_shadow_refill(ShadowParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int *stack = reinterpret_cast<int *>(smem);
+    const int tid = threadIdx.x;
+    int ti = 0, tj = 0;
+    const bool has_tile = hz_tile_of_block(p.tm, blockIdx.x, &ti, &tj);      // tile map over super tiles (16 x 16 nb cells)
+    const int wave = tid >> 6, lane = tid & 63;
+    const int sun_idx = blockIdx.y;
+    const float p_sun_x = p.suns[3 * sun_idx], p_sun_y = p.suns[3 * sun_idx + 1], p_sun_z = p.suns[3 * sun_idx + 2];
+    uint8_t *const out_u8 = p.out_u8 ? p.out_u8 + (size_t)sun_idx * p.out_stride : nullptr;
+    float *const out_f32 = p.out_f32 ? p.out_f32 + (size_t)sun_idx * p.out_stride : nullptr;
+    unsigned rays = 0;
+    TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.w_nodes = 0; tc.w_leaves = 0;
+    const int i_base = ti * 16 + (wave >> 1) * 8, j_base = tj * (16 * p.nb) + (wave & 1) * 8;
+    const int total = has_tile ? 64 * p.nb : 0;
+    int next = 0;                                   // cells handed out so far (wave uniform)
+    bool ray_active = false;
+    ShadowRay r; r.ox = r.oy = r.oz = 0.0f; r.dx = r.dy = 0.0f; r.dz = 1.0f; r.dot_ts = r.dot_ns = 0.0f;
+    size_t cell = 0;
+    RayBox rb = hz_raybox(0, 0, 0, 0, 0, 1);
+    TravState ts; hz_trav_reset(ts);
+    unsigned overflow = 0;
+    for (;;) {
+        if (next < total) {
+            const unsigned long long need = __ballot(!ray_active);
+            if (need != 0ull) {
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(need >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)need, 0u));
+                const int my = next + rank;
+                next += __popcll(need);
+                if (!ray_active && my < total) {
+                    const int i = i_base + ((my & 63) >> 3), j = j_base + (my >> 6) * 16 + (my & 7);
+                    if (i < p.dim_in_0 && j < p.dim_in_1 && shadow_setup(p, i, j, p_sun_x, p_sun_y, p_sun_z, out_u8, out_f32, r)) {
+                        cell = (size_t)i * p.dim_in_1 + j;
+                        rb = hz_raybox(r.ox - p.sv.cx, r.oy - p.sv.cy, r.oz - p.sv.cz, r.dx, r.dy, r.dz);
+                        hz_trav_reset(ts);
+                        ray_active = true;
+                        rays++;
+                    }
+                }
+            }
+        }
+        if (__ballot(ray_active) == 0ull) {
+            if (next >= total) break;
+            continue;
+        }
+        if (ray_active) {
+            // while cells are left the traversal returns when fewer than 40 lanes are busy (and one finished)
+            const int res = hz_trace<HZ_TPB, COUNT>(p.sv.nodes, p.sv.prims, nullptr, 0, stack, tid, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz,
+                                                    __builtin_inff(), rb, ts, (next < total) ? HZ_SHADOW_REGROUP : 0, HZ_SHADOW_LEAF_BIAS, tc, 0, overflow);
+            if (res != 2) {
+                shadow_result(p, cell, res == 1, r, out_u8, out_f32);
+                ray_active = false;
+            }
+        }
+    }
+    shadow_counters<COUNT>(p, rays, tc, lane);
+}
+
 int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st) {
     ShadowParams p;
     p.sv = scene_view(sc);
@@ -168,26 +263,43 @@ int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st) {
     if (a.dim_in_0 <= 0 || a.dim_in_1 <= 0) return HZ_OK;
     const int tiles_i = (a.dim_in_0 + 15) / 16;
     p.tm = make_tile_map(tiles_i, (a.dim_in_1 + 15) / 16);
-    p.sun_x = a.sun[0]; p.sun_y = a.sun[1]; p.sun_z = a.sun[2];
+    p.suns = a.suns; p.out_stride = (size_t)a.dim_in_0 * (size_t)a.dim_in_1;
+    if (a.num_sun <= 0) return HZ_OK;
     p.fill = a.sw_dir_cor_fill; p.dot_prod_min = a.dot_prod_min;
     p.refrac = a.refrac_cor; p.which = a.which;
     p.out_u8 = a.out_u8; p.out_f32 = a.out_f32;
-    // LDS stack: one entry per tree level (hz_common.h): 12 - 14 KB per workgroup, so the kernel's 59 VGPRs decide
-    // the residency (8 waves per SIMD)
+    // LDS stack: one entry per tree level (hz_common.h): 12 - 14 KB per workgroup, so the VGPRs decide the residency
     p.stack_bytes = std::max(sc->hdr.height, 1) * HZ_TPB * 4;
     p.top_nodes = 0;
     p.counters = a.counters;
     const size_t lds = (size_t)p.stack_bytes;
-    const int grid = p.tm.per_xcd * 8;
-    if (a.count_work) {
-        HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shadow<true>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_shadow<true>, dim3(grid), dim3(HZ_TPB), lds, st, p);
-    } else {
-        HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_shadow<false>),
-                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k_shadow<false>, dim3(grid), dim3(HZ_TPB), lds, st, p);
+    static const bool refill = []() { const char *e = getenv("HZ_SHADOW_REFILL"); return !(e && e[0] == '0'); }();
+    // blocks per wave: as many as leave >= ~48 workgroups per CU over the whole launch (measured on the 3601^2 tile, 144
+    // positions per launch: 2 / 4 / 8 / 16 / 32 / 64 blocks -> 1.64 / 1.49 / 1.42 / 1.36 / 1.29 / 1.51 ms per position; a single
+    // position: 1 / 2 / 4 / 8 / 16 blocks -> 2.49 / 1.77 / 1.67 / 1.65 / 1.79 ms, k_shadow 2.52 ms)
+    p.nb = 1;
+    if (refill) {
+        static const int nb_env = []() { const char *e = getenv("HZ_SHADOW_NB"); return e ? atoi(e) : 0; }();
+        const int tiles_j = (a.dim_in_1 + 15) / 16;
+        const double wgs = (double)tiles_i * tiles_j * (double)a.num_sun;
+        int nb = (int)(wgs / (48.0 * 256.0));
+        nb = std::max(1, std::min(std::min(nb, 32), tiles_j));
+        // a count that cuts the tile row without a ragged last super tile if there is one nearby (224 tiles: 24 blocks per
+        // wave measured 1.41 ms, 32 blocks 1.29 ms per position)
+        for (int c = nb; c >= std::max(1, (nb * 3) / 4); c--)
+            if (tiles_j % c == 0) { nb = c; break; }
+        if (nb_env > 0) nb = std::min(nb_env, tiles_j);
+        p.nb = nb;
+        p.tm = make_tile_map(tiles_i, (tiles_j + nb - 1) / nb);
     }
+    // grid.x is a multiple of 8, so the workgroup -> XCD assignment (flat id % 8) is the same for every grid.y row
+    const dim3 grid((unsigned)(p.tm.per_xcd * 8), (unsigned)a.num_sun);
+#define HZ_LAUNCH_SHADOW(K) do { \
+        HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL(K, grid, dim3(HZ_TPB), lds, st, p); } while (0)
+    if (refill) { if (a.count_work) HZ_LAUNCH_SHADOW(k_shadow_refill<true>); else HZ_LAUNCH_SHADOW(k_shadow_refill<false>); }
+    else { if (a.count_work) HZ_LAUNCH_SHADOW(k_shadow<true>); else HZ_LAUNCH_SHADOW(k_shadow<false>); }
+#undef HZ_LAUNCH_SHADOW
     HZ_HIP(hipGetLastError());
     return HZ_OK;
 }
