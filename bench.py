@@ -109,6 +109,28 @@ def machine_peaks(L, dev_index):
             "cycles_per_wave_inst_measured": (clk.value * 1e9 / best) if best else None, "copy_gbs": g.value}
 
 
+def inst_class_rates(L, dev_index):
+    """Cycles per wave64 VALU instruction per SIMD of the two issue classes of gfx950, measured here (hz_bench.hip:
+    k_inst_rate; selectors 17 / 19 / 11 = v_fma_f32 with sources in different VGPR banks, v_add_f32, v_mul_f32;
+    1 / 3 / 15 / 9 = v_cvt_f32_ubyte0, v_perm_b32, v_min_f32, v_cmp_le_f32).  Two passes, the faster one counts (the first
+    also warms the clocks)."""
+    def rate(op):
+        best = 1e9
+        for _ in range(2):
+            r = C.c_double(0)
+            if L.hz_debug_inst_rate(dev_index, op, C.byref(r)) == 0 and r.value > 0:
+                best = min(best, r.value)
+        return best
+    fast = [rate(op) for op in (17, 19, 11)]
+    slow = [rate(op) for op in (1, 3, 15, 9)]
+    return {"fast_cycles": sum(fast) / len(fast), "slow_cycles": sum(slow) / len(slow),
+            "fast_same_bank_cycles": rate(0), "fast_samples": fast, "slow_samples": slow}
+
+
+SHADOW_SETUP_WINST = (260.0, 900.0)     # wave-level VALU instructions per 64 cells handed out: refraction off / on
+CLASS_MIX_DEFAULT = {"node_step": 0.44, "leaf_step": 0.88, "refill_and_loop_overhead": 0.62}   # fast-class share (ISA count)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -239,6 +261,8 @@ def run_c3(ctx):
         cw = _lib.hz_stats()
         step(n_slabs // 2, cw, count=True)
     peaks = machine_peaks(L, ctx["local_rank"]) if (rank == 0 and not args.no_peaks) else None
+    if peaks is not None:
+        peaks["class_rates"] = inst_class_rates(L, ctx["local_rank"])
 
     # weak scaling: rank r takes steps r K ... r K + K - 1 of the slab sequence (per-GPU work fixed)
     base = rank * steps
@@ -329,10 +353,11 @@ def e2e_numpy_call(g, vec_tilt, args, A):
 
 
 def roofline(args, stats, steps, cw, peaks, A, n, rps):
-    """The bound of k_horizon is VALU issue: achieved = wave-level VALU instructions per
-    second (wave-iteration counters of the COUNT instantiation x the calibrated instructions per iteration),
-    peak = the measured issue rate of independent v_fma_f32 chains on this box.  The HBM pair (algorithmic
-    bytes -- mostly cache-served node re-reads -- and the counter-measured traffic) is reported next to it."""
+    """The bound of k_horizon is the VALU port: achieved = the SIMD cycles its instructions need
+    at the measured issue rates of the two instruction classes (wave-iteration counters of the COUNT instantiation x
+    the calibrated instructions per iteration x the static class mix), peak = the SIMD cycles of the launch.  The HBM
+    pair (algorithmic bytes -- mostly cache-served node re-reads -- and the counter-measured traffic) is reported
+    next to it."""
     k_launch_s = stats.t_kernel_s / max(steps, 1)
     rays_launch = stats.num_rays / max(steps, 1)
     cells_launch = stats.num_cells / max(steps, 1)
@@ -366,12 +391,40 @@ def roofline(args, stats, steps, cw, peaks, A, n, rps):
         r.update({"nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray,
                   "valu_winst_per_launch": winst, "valu_model_constants": model, "lane_utilisation_node_leaf_steps": lanes})
         if peaks and peaks["valu_winst_per_s"]:
-            r.update({"bound": "valu_issue", "achieved": winst / k_launch_s / 1e9, "peak": peaks["valu_winst_per_s"] / 1e9,
-                      "unit": "G wave-instructions/s", "frac": winst / k_launch_s / peaks["valu_winst_per_s"],
-                      "peak_note": "SIMDs x engine clock / 4 cycles per wave64 VALU instruction; measured here with a "
-                                   "3.5 ms burst of independent v_fma_f32 chains: %.1f G/s = %.3f cycles per instruction"
-                                   % (peaks["valu_winst_per_s_measured"] / 1e9, peaks["cycles_per_wave_inst_measured"] or 0.0),
-                      "peak_measured_fma_burst": peaks["valu_winst_per_s_measured"] / 1e9,
+            # The VALU port as the bound.  gfx950 issues wave64 VALU instructions in two classes (class_rates, measured
+            # above): fast (FP32 fma / mul / add, moves, logic, integer add: ~2.4 cycles per SIMD when the VGPR sources
+            # sit in different banks, ~4.1 when they collide) and slow (conversions, v_perm, min / max, compares, ...:
+            # ~4.15).  achieved = the SIMD cycles the launch's instructions need at the conflict-free rates (wave-
+            # iteration counters x calibrated instructions per iteration x static class mix of the section), peak = the
+            # SIMD cycles the launch had.  `frac` is therefore a LOWER bound of the VALU-busy share; with every fast
+            # instruction colliding it is frac_uniform_4_cycle (the round-1/2 model).
+            mix = dict(CLASS_MIX_DEFAULT)
+            mix_note = "default class mix"
+            cpath = os.path.join(ROOT, "profiles", "valu_class_mix.json")
+            if os.path.exists(cpath):
+                try:
+                    cj = json.load(open(cpath))
+                    if cj.get("kernel_source_sha") == sha:
+                        mix = {k: cj[k]["fast_fraction"] for k in mix if k in cj}
+                        mix_note = "profiles/valu_class_mix.json (scripts/isa_class_mix.py, same kernel sources)"
+                except Exception:
+                    pass
+            cr = peaks.get("class_rates") or {"fast_cycles": 2.4, "slow_cycles": 4.15}
+            cyc = lambda f: f * cr["fast_cycles"] + (1.0 - f) * cr["slow_cycles"]
+            cycles_need = scale * (cw.wave_node_iters * model["node_iter"] * cyc(mix["node_step"])
+                                   + cw.wave_leaf_iters * model["leaf_iter"] * cyc(mix["leaf_step"])
+                                   + cw.wave_refills * model["refill_iter"] * cyc(mix["refill_and_loop_overhead"]))
+            cycles_have = peaks["simds"] * peaks["clock_ghz"] * 1e9 * k_launch_s
+            r.update({"bound": "valu_issue", "achieved": cycles_need / k_launch_s / 1e9,
+                      "peak": peaks["simds"] * peaks["clock_ghz"], "unit": "G SIMD-cycles/s (VALU busy)",
+                      "frac": cycles_need / cycles_have,
+                      "frac_uniform_4_cycle": winst / k_launch_s / peaks["valu_winst_per_s"],
+                      "valu_winst_per_s": winst / k_launch_s,
+                      "class_rates_cycles_per_wave_inst": cr, "class_mix_fast_fraction": mix, "class_mix_note": mix_note,
+                      "peak_note": "SIMDs x engine clock; a wave64 VALU instruction occupies its SIMD for ~2.4 (fast class, "
+                                   "bank-conflict free) or ~4.15 cycles (slow class), measured here; a 3.5 ms burst of "
+                                   "v_fma_f32 chains with scalar operands: %.3f cycles per instruction"
+                                   % (peaks["cycles_per_wave_inst_measured"] or 0.0),
                       "clock_ghz": peaks["clock_ghz"], "simds": peaks["simds"]})
     alg = (b_io + b_trav) / k_launch_s / 1e9 if k_launch_s else None
     traffic, tnote = None, "profiles/traffic.json missing"
@@ -633,7 +686,7 @@ def run_c4(ctx):
     V = n * n
     out_b = 1 if shadow else 4
     # SURVEY 8(d) "shadow bytes": 12 V + 33 C once at initialise, 1 C (shadow) / 4 C (sw_dir_cor) per sun position;
-    # B_trav = rays x (node visits x 64 B + triangle tests x 24 B) from the counting pass
+    # B_trav = rays x (node visits x 64 B + triangle tests x 24 B) from the counting pass -- served by the caches
     b_io = S * out_b * cells + (12.0 * V + 33.0 * cells)
     b_trav = (cw["nodes_visited"] * 64.0 + cw["tris_tested"] * 24.0) if cw else 0.0
     alg = (b_io + b_trav) / k_step / 1e9 if k_step else None
@@ -641,6 +694,39 @@ def run_c4(ctx):
     if shadow:
         o = out[S // 2].cpu().numpy()
         codes = [float((o == c).mean()) for c in range(4)]
+    roof = {"kernel": "hz::k_shadow_refill<false> (all sun positions of a step in one launch, lane refill)",
+            "kernel_ms_per_step": 1e3 * k_step, "traffic": None,
+            "hbm": {"peak_gbs": HBM_PEAK_GBS, "alg_bytes_per_step": b_io + b_trav, "io_bytes_per_step": b_io,
+                    "alg_gbs_cache_served": alg,
+                    "note": "algorithmic bytes (SURVEY 8d) are almost all node re-reads served by L1 / L2: the figure may exceed "
+                            "the HBM peak and is not an HBM utilisation; the compulsory bytes are io_bytes_per_step"}}
+    if cw:
+        # VALU port as the bound, as for k_horizon: the traversal is the same hz_trace (147 / 218 wave instructions per node /
+        # leaf step, class mix of those sections); the per-cell set-up (ray, self-shading test, refraction) is priced with
+        # SETUP wave instructions per 64 cells handed out (calibrated on SQ_INSTS_VALU, profiles/r03/pmc_shadow_refill.json)
+        setup = SHADOW_SETUP_WINST[int(bool(args.refrac))]
+        n_it, l_it = cw["wave_node_iters"], cw["wave_leaf_iters"]
+        rounds = S * cells / 64.0
+        winst = VALU_MODEL_DEFAULT["node_iter"] * n_it + VALU_MODEL_DEFAULT["leaf_iter"] * l_it + setup * rounds
+        roof.update({"nodes_per_ray": cw["nodes_visited"] / max(cw["num_rays"], 1), "tris_per_ray": cw["tris_tested"] / max(cw["num_rays"], 1),
+                     "wave_node_iters": n_it, "wave_leaf_iters": l_it,
+                     "lane_utilisation_node_leaf_steps": (cw["nodes_visited"] + cw["tris_tested"] / 2.0) / max(64.0 * (n_it + l_it), 1.0),
+                     "valu_winst_per_step_model": winst})
+        peaks = machine_peaks(_lib.lib(), ctx["local_rank"]) if not args.no_peaks else None
+        if peaks:
+            cr = inst_class_rates(_lib.lib(), ctx["local_rank"])
+            cyc = lambda f: f * cr["fast_cycles"] + (1.0 - f) * cr["slow_cycles"]
+            need = (VALU_MODEL_DEFAULT["node_iter"] * n_it * cyc(CLASS_MIX_DEFAULT["node_step"])
+                    + VALU_MODEL_DEFAULT["leaf_iter"] * l_it * cyc(CLASS_MIX_DEFAULT["leaf_step"]) + setup * rounds * cyc(0.7))
+            have = peaks["simds"] * peaks["clock_ghz"] * 1e9 * k_step
+            roof.update({"bound": "valu_issue", "achieved": need / k_step / 1e9, "peak": peaks["simds"] * peaks["clock_ghz"],
+                         "unit": "G SIMD-cycles/s (VALU busy)", "frac": need / have,
+                         "frac_uniform_4_cycle": 4.0 * winst / have, "class_rates_cycles_per_wave_inst": cr,
+                         "peak_note": "as for k_horizon (c3 line): SIMD cycles the instructions need at the measured issue rates of "
+                                      "the two VALU classes over the SIMD cycles of the launch; a lower bound of the VALU-busy share"})
+    if "bound" not in roof:
+        roof.update({"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s (cache-served, see hbm.note)",
+                     "frac": alg / HBM_PEAK_GBS if alg else None})
     res = {
         "metric": "grid_cells_per_s (Terrain.%s, %d sun positions, 3601^2 SRTM-like tile)" % (args.which, S),
         "value": world * steps * S * cells / elapsed, "unit": "cells/s",
@@ -654,15 +740,7 @@ def run_c4(ctx):
                    "sun_alt_deg_minmax": [float(np.rad2deg(alt.min())), float(np.rad2deg(alt.max()))],
                    "code_fractions_0123_at_noon": codes,
                    "bvh_build_s": scene_stats["t_bvh_s"] if scene_stats else None},
-        "roofline": {"bound": "hbm", "kernel": "hz::k_shadow<false>", "kernel_ms_per_step": 1e3 * k_step,
-                     "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / HBM_PEAK_GBS if alg else None,
-                     "alg_bytes_per_step": b_io + b_trav, "io_bytes_per_step": b_io, "traffic": None,
-                     "nodes_per_ray": cw["nodes_visited"] / max(cw["num_rays"], 1) if cw else None,
-                     "tris_per_ray": cw["tris_tested"] / max(cw["num_rays"], 1) if cw else None,
-                     "lane_utilisation_node_leaf_steps":
-                         (cw["nodes_visited"] + cw["tris_tested"] / 2.0) / max(64.0 * (cw["wave_node_iters"] + cw["wave_leaf_iters"]), 1.0) if cw else None,
-                     "note": "algorithmic bytes are mostly cache-served node re-reads (SURVEY 8d); the kernel is VALU-issue "
-                             "bound like k_horizon (profiles/r02/pmc_shadow_summary.json: 81 % of the issue slots)"},
+        "roofline": roof,
     }
     return res
 

@@ -34,7 +34,9 @@ struct ShadowParams {
 
 // The float libm calls of the reference's refraction branch (acos / tan / pow / cos / sin on float arguments
 // resolve to the float overloads, shadow_comp.cpp:19): self-contained correctly rounded versions shared with
-// the CPU oracle (hz_crmath.h), so shadow codes and sw_dir_cor are bit-identical with refraction too.
+// the CPU oracle (hz_crmath.h): with refraction, shadow codes and sw_dir_cor are bit-identical TO THAT CONTRACT (the
+// correctly rounded float), not to the reference's glibc calls -- tests/test_gpu_parity.py::
+// test_refraction_against_platform_libm measures the distance to the platform libm (a tolerance, not equality).
 __device__ __forceinline__ float f_acos(float x) { return hz_crm_acosf(x); }
 __device__ __forceinline__ float f_tan(float x) { return hz_crm_tanf(x); }
 __device__ __forceinline__ float f_cos(float x) { return hz_crm_cosf(x); }

@@ -116,6 +116,9 @@ def _triple(a, b, c, sym, *, device):
     return o0.reshape(shp), o1.reshape(shp), o2.reshape(shp)
 
 
+# wgs2swiss / swiss2wgs: outside the scope table (SURVEY.md section 8(f)4 cites transform.pyx:60-103, 152-189, 231-261;
+# coordinate transforms are otherwise out of scope, section 2).  Kept from round 2 as a convenience for the swissALTI3D
+# input path of the reference's examples; no parity or coverage claim rests on them.
 def wgs2swiss(lon, lat, h_wgs, *, device=0):
     """Ellipsoidal WGS84 longitude / latitude [degree] (float64) and height above the ellipsoid (float32) to Swiss
     projection coordinates LV95: ``e``, ``n`` [metre] (float64) and ``h_ch`` (float32).  Arguments, checks and

@@ -240,6 +240,9 @@ int hz_slope_vector_meth(const float *x, const float *y, const float *z, int len
 /* _lonlat2ecef_1d, transform.pyx:60-103: lon, lat f64[n] [degree], h f32[n] -> f64[n] x 3      */
 int hz_lonlat2ecef(const double *lon, const double *lat, const float *h, size_t n, int ellps,
                    double *x_ecef, double *y_ecef, double *z_ecef, int device);
+/* -- NOT a row of the scope table (SURVEY.md section 8(f)4 names transform.pyx:60-103, 152-189, 231-261 only; section 2   */
+/*    lists coordinate transforms as out of scope): the two Swiss-grid routines below were added in round 2, are kept   */
+/*    because the reference's swissALTI3D examples feed the path through them, and are not part of any parity claim.    */
 /* _wgs2swiss_1d, transform.pyx:306-345: lon, lat f64[n] [degree], h_wgs f32[n] -> LV95 e, n f64[n] [m], */
 /* h_ch f32[n]; _swiss2wgs_1d, transform.pyx:390-432: the inverse (swisstopo's approximate formulas)  */
 int hz_wgs2swiss(const double *lon, const double *lat, const float *h_wgs, size_t n,

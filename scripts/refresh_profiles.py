@@ -12,6 +12,16 @@ sha = bench.kernel_source_sha()
 newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)       # gpurun_out/ keeps the files of earlier calls
 shutil.copy(newest("gpurun_out/%s_kt/*/*kernel_stats.csv" % pre), "profiles/%s/bench_kernel_stats.csv" % rnd)
 shutil.copy("gpurun_out/%s_kt_bench.json" % pre, "profiles/%s/bench_under_rocprof.json" % rnd)
+try:      # the default command (with the untimed drop-in call: 5 more, shorter launches of the same kernel)
+    shutil.copy(newest("gpurun_out/%s_kte/*/*kernel_stats.csv" % pre), "profiles/%s/bench_kernel_stats_default_command.csv" % rnd)
+    shutil.copy("gpurun_out/%s_kte_bench.json" % pre, "profiles/%s/bench_under_rocprof_default_command.json" % rnd)
+except (ValueError, OSError):
+    pass
+try:      # config 4
+    shutil.copy(newest("gpurun_out/%s_c4kt/*/*kernel_stats.csv" % pre), "profiles/%s/bench_c4_kernel_stats.csv" % rnd)
+    shutil.copy("gpurun_out/%s_c4kt_bench.json" % pre, "profiles/%s/bench_c4_under_rocprof.json" % rnd)
+except (ValueError, OSError):
+    pass
 KERNEL = "k_horizon<2, false, true, false"
 
 
@@ -71,3 +81,28 @@ if kk:
     json.dump(vm, open("profiles/valu_model.json", "w"), indent=1)
     json.dump(vm, open("profiles/%s/valu_model.json" % rnd, "w"), indent=1)
     print(json.dumps(vm))
+
+# ---- config 4: SQ counters of the shadow kernel -------------------------------------------------------------------
+try:
+    agg = {}
+    for d in ("c4sq", "c4grbm"):
+        f = newest("gpurun_out/%s_%s/*/*counter_collection.csv" % (pre, d))
+        for r in csv.DictReader(open(f)):
+            if "k_shadow" in r["Kernel_Name"]:
+                agg.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    m = {k: sum(v) / len(v) for k, v in agg.items()}
+    b4 = json.loads(open("gpurun_out/%s_c4kt_bench.json" % pre).read().strip().splitlines()[-1])
+    cyc = m["GRBM_GUI_ACTIVE"] / 8.0
+    rf = b4["roofline"]
+    out4 = {"kernel": "hz::k_shadow_refill<false>, 144 sun positions per launch", "counters_per_launch": m,
+            "lane_utilisation_valu": m["SQ_THREAD_CYCLES_VALU"] / (64.0 * m["SQ_INSTS_VALU"]),
+            "engine_cycles_per_launch": cyc, "simd_cycles_per_valu_instruction": 1024.0 * cyc / m["SQ_INSTS_VALU"],
+            "note": "1024 SIMDs x engine cycles / SQ_INSTS_VALU: below 4 means the instructions cannot all have taken the 4 cycles "
+                    "of the round-2 model -- the fast class issues every ~2.4 cycles (profiles/%s/inst_rates.json)" % rnd}
+    if rf.get("wave_node_iters"):
+        rest = m["SQ_INSTS_VALU"] - 147.0 * rf["wave_node_iters"] - 218.0 * rf["wave_leaf_iters"]
+        out4["setup_winst_per_64_cells"] = rest / (144 * 3569 * 3569 / 64.0)
+    json.dump(out4, open("profiles/%s/pmc_shadow_refill.json" % rnd, "w"), indent=1)
+    print(json.dumps(out4))
+except (ValueError, OSError, KeyError) as e:
+    print("no config-4 counters:", e)

@@ -481,7 +481,7 @@ def test_shadow_and_sw_dir_cor(hip, orc, refrac):
         rays_g, rays_c = tg.last_stats["num_rays"], tc.rays
         fg = np.full(mask.shape, np.nan, np.float32); fc = fg.copy()
         tg.sw_dir_cor(suns[s], fg); tc.sw_dir_cor(suns[s], fc)
-        # bit-identical with and without refraction: the refraction branch's float libm calls are the shared,
+        # bit-identical with and without refraction -- to the correctly-rounded-libm CONTRACT: the refraction branch's float libm calls are the shared,
         # correctly rounded hz_crmath.h routines on both sides (byte and float output: the bar is equality)
         assert np.array_equal(sg, sc)
         assert rays_g == rays_c
