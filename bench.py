@@ -127,7 +127,8 @@ def inst_class_rates(L, dev_index):
             "fast_same_bank_cycles": rate(0), "fast_samples": fast, "slow_samples": slow}
 
 
-SHADOW_SETUP_WINST = (260.0, 900.0)     # wave-level VALU instructions per 64 cells handed out: refraction off / on
+SHADOW_SETUP_WINST = (485.0, 1100.0)    # wave-level VALU instructions per 64 cells handed out: refraction off (calibrated on
+                                        # SQ_INSTS_VALU, profiles/r03/pmc_shadow_refill.json) / on (estimate)
 CLASS_MIX_DEFAULT = {"node_step": 0.44, "leaf_step": 0.88, "refill_and_loop_overhead": 0.62}   # fast-class share (ISA count)
 
 
