@@ -337,7 +337,8 @@ def run_c3(ctx):
 def e2e_numpy_call(g, vec_tilt, args, A):
     """UNTIMED (not part of `value`): the drop-in call as a user of the reference makes it -- NumPy in, NumPy out
     (horizon.pyx:170-197): vertices and per-cell inputs uploaded, BVH built, horizon traced in chunks that are
-    copied into the caller's 18 GB array behind the next chunk's kernel, SVF fused."""
+    copied into the caller's 18 GB array behind the next chunk's kernel (the array is page-locked chunk by chunk on a
+    helper thread so that those copies are DMA, HostPinner in hz_api.hip), SVF fused."""
     import horayzon_amd as hz
     kw = {k: g[k] for k in ("vert_grid", "dem_dim_0", "dem_dim_1", "vec_norm", "vec_north", "offset_0", "offset_1")}
     t0 = time.perf_counter()

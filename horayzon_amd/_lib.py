@@ -28,7 +28,7 @@ class hz_opts(C.Structure):
                 ("skip_hori", C.c_int32), ("chunk_rows", C.c_int32),
                 ("level_stack", C.c_int32), ("hori_is_slab", C.c_int32),
                 ("no_near_skip", C.c_int32), ("verify_near", C.c_int32),
-                ("inputs_are_slab", C.c_int32), ("reserved_", C.c_int32)]
+                ("inputs_are_slab", C.c_int32), ("no_host_pin", C.c_int32)]
 
 
 class hz_stats(C.Structure):

@@ -11,6 +11,8 @@
 #include <limits>
 #include <mutex>
 #include <utility>
+#include <thread>
+#include <atomic>
 
 namespace hz {
 
@@ -233,6 +235,58 @@ static int persist(const void *src, size_t bytes, hipStream_t st, void **dst, bo
     return HZ_OK;
 }
 
+// Host output of the drop-in call (NumPy memory, pageable): a device-to-host copy into pageable memory is staged by the
+// runtime (copy kernels on the CUs, host-blocking, 16 GB/s into untouched pages -- scripts/d2h_probe.py) and slows the
+// traversal kernel it is meant to hide behind.  HostPinner page-locks the caller's slab region by region (one region per
+// chunk of rows) on a helper thread, ahead of the copies: 45 ms per GB, done while the first chunks are traced; the copies
+// are then plain DMA (57 GB/s, no CU time).  Regions are page aligned and disjoint; the last bytes of chunk k may lie in
+// region k + 1, so a copy waits for that one too.  If page locking fails (memlock limit, memory that is already
+// registered) the copies simply stay pageable.
+struct HostPinner {
+    std::vector<std::pair<char *, size_t>> regions;
+    std::atomic<int> done{0};
+    std::atomic<bool> failed{false};
+    std::thread worker;
+    int device = 0;
+    void start(int dev, char *base, const std::vector<size_t> &chunk_bytes) {
+        device = dev;
+        const uintptr_t page = 4096;
+        uintptr_t lo = reinterpret_cast<uintptr_t>(base) & ~(page - 1);
+        uintptr_t cur = reinterpret_cast<uintptr_t>(base);
+        for (size_t k = 0; k < chunk_bytes.size(); k++) {
+            cur += chunk_bytes[k];
+            const uintptr_t hi = (k + 1 == chunk_bytes.size()) ? ((cur + page - 1) & ~(page - 1)) : (cur & ~(page - 1));
+            regions.emplace_back(reinterpret_cast<char *>(lo), hi > lo ? (size_t)(hi - lo) : 0);
+            lo = std::max(lo, hi);
+        }
+        worker = std::thread([this]() {
+            (void)hipSetDevice(device);
+            for (size_t k = 0; k < regions.size(); k++) {
+                if (!failed.load() && regions[k].second &&
+                    hipHostRegister(regions[k].first, regions[k].second, hipHostRegisterDefault) != hipSuccess) {
+                    (void)hipGetLastError();
+                    regions[k].second = 0;               // not ours to unregister
+                    failed.store(true);
+                } else if (failed.load()) {
+                    regions[k].second = 0;
+                }
+                done.store((int)k + 1, std::memory_order_release);
+            }
+        });
+    }
+    // regions 0 .. k + 1 are locked (or locking has been given up)
+    void wait_for(int k) const {
+        const int need = std::min((int)regions.size(), k + 2);
+        while (done.load(std::memory_order_acquire) < need) std::this_thread::yield();
+    }
+    void finish() {          // after every copy has completed
+        if (worker.joinable()) worker.join();
+        for (auto &r : regions) if (r.second) (void)hipHostUnregister(r.first);
+        regions.clear();
+    }
+    ~HostPinner() { finish(); }
+};
+
 static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_north, int offset_0,
                        int offset_1, float *hori_buffer, int dim_in_0, int dim_in_1, int azim_num,
                        float dist_search, float hori_acc, const char *ray_algorithm,
@@ -403,14 +457,43 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         if (st_copy) { stream_release(sc->device, st_copy); st_copy = nullptr; }
     };
     if (stream_out && (rc = stream_acquire(sc->device, &st_copy))) return rc;
+    if (use_near) {             // the certificate scratch of the largest chunk, allocated before the pinner thread starts
+        const size_t cells = (size_t)std::min(chunk_rows, row_end - row_begin) * dim_in_1;      // (page locking and hipMalloc
+        const size_t need = ((cells * (size_t)azim_num * 2 + 255) & ~(size_t)255) + cells * 4;  //  serialise in the driver)
+        if (sc->near_bytes < need) {
+            if (sc->near_buf) (void)hipFree(sc->near_buf);
+            sc->near_buf = nullptr; sc->near_bytes = 0;
+            if (hipMalloc(&sc->near_buf, need) != hipSuccess) { free_events(); return set_error(HZ_ERR_HIP, "hipMalloc of the near-field certificates failed"); }
+            sc->near_bytes = need;
+        }
+    }
+    HostPinner pinner;          // declared after the events: destroyed (joined, unregistered) before them
+    if (stream_out && !(opts && opts->no_host_pin)) {
+        std::vector<size_t> cb;
+        for (int rb = row_begin; rb < row_end; rb += chunk_rows) cb.push_back((size_t)(std::min(rb + chunk_rows, row_end) - rb) * row_bytes);
+        pinner.start(sc->device, reinterpret_cast<char *>(hori_slab_host), cb);
+    }
     // copy of chunk k (issued after chunk k + 1 was launched, so a host-blocking pageable copy still overlaps)
     auto copy_out = [&](int k) -> int {
         const int rb = row_begin + k * chunk_rows, re = std::min(rb + chunk_rows, row_end);
         const void *src = (k & 1) ? tmp_hori2 : tmp_hori;
         Ev &e = evs[ev_of[(size_t)k]];
+        char *dst = reinterpret_cast<char *>(hori_row0 + (size_t)rb * dim_in_1 * azim_num);
+        const size_t bytes = (size_t)(re - rb) * row_bytes;
+        // a copy must not straddle two separately page-locked regions: the last (< 4096) bytes of chunk k lie in region
+        // k + 1 and go as a copy of their own
+        size_t head = bytes;
+        if (!pinner.regions.empty()) {
+            pinner.wait_for(k);
+            if (!pinner.failed.load() && (size_t)k + 1 < pinner.regions.size()) {
+                char *next = pinner.regions[(size_t)k + 1].first;
+                if (next > dst && next < dst + bytes) head = (size_t)(next - dst);
+            }
+        }
         if (hipStreamWaitEvent(st_copy, e.c, 0) != hipSuccess ||
-            hipMemcpyAsync(hori_row0 + (size_t)rb * dim_in_1 * azim_num, src, (size_t)(re - rb) * row_bytes,
-                           hipMemcpyDeviceToHost, st_copy) != hipSuccess ||
+            hipMemcpyAsync(dst, src, head, hipMemcpyDeviceToHost, st_copy) != hipSuccess ||
+            (head < bytes && hipMemcpyAsync(dst + head, static_cast<const char *>(src) + head, bytes - head,
+                                            hipMemcpyDeviceToHost, st_copy) != hipSuccess) ||
             hipEventRecord(e.d, st_copy) != hipSuccess)
             return set_error(HZ_ERR_HIP, "copy of the horizon chunk failed: %s", hipGetErrorString(hipGetLastError()));
         return HZ_OK;
@@ -524,6 +607,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     if (stream_out) {
         rc = copy_out(n_chunk - 1);
         const hipError_t se = hipStreamSynchronize(st_copy);
+        pinner.finish();
         if (!rc && se != hipSuccess) rc = set_error(HZ_ERR_HIP, "copy of the horizon failed: %s", hipGetErrorString(se));
         if (rc) { free_events(); return rc; }
     }

@@ -293,7 +293,8 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
     p.top_nodes = top;
     // defaults from the sweep on the 3601^2 tile: refill when fewer than 40 lanes
     // are traversing; leaf step when 20 n_leaf > 16 n_node.  opts.regroup = threshold | bias << 8.
-    p.regroup = (a.regroup < 0) ? 40 : std::min(a.regroup & 0xff, 64);
+    // (<= 0: the default -- a zeroed hz_opts must not switch the ray compaction off: 2.9 s instead of 2.15 s per tile)
+    p.regroup = (a.regroup <= 0) ? 40 : std::min(a.regroup & 0xff, 64);
     p.leaf_bias = (a.regroup >= 256) ? (a.regroup >> 8) : 20;
     p.hit_cache = (a.hit_cache != 0) ? 1 : 0;
     p.near_idx = a.near_idx; p.near_r = a.near_r; p.verify_near = a.verify_near;

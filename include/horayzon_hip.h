@@ -46,7 +46,7 @@ typedef struct hz_opts {
                            /*   slab: the call succeeds and computes nothing (a rank without rows)                      */
     int32_t top_nodes;     /* > 0: stage that many top-of-tree BVH nodes in LDS (guess_constant;   */
                            /*   measured 2 % slower than L1 reads, so <= 0 means none)            */
-    int32_t regroup;       /* wave regroup threshold in lanes (-1 auto)        */
+    int32_t regroup;       /* wave regroup threshold in lanes (<= 0: default)  */
     int32_t count_work;    /* 1: also count BVH nodes / triangle tests (slow)  */
     int32_t no_hit_cache;  /* 0 (default): rays expected to be blocked first walk the subtree  */
                            /*   that blocked the cell's previous ray; 1: always start at the root */
@@ -73,7 +73,9 @@ typedef struct hz_opts {
                            /*   layout; only the slab's rows are read or uploaded); 1: they address row_begin, i.e. the */
                            /*   caller holds only its slab [row_end - row_begin][dim_in_1] of each -- the form for a    */
                            /*   rank of a row-sharded job                                                                */
-    int32_t reserved_;
+    int32_t no_host_pin;   /* 0 (default): a HOST hori_buffer is page-locked chunk by chunk on a helper thread while the   */
+                           /*   first chunks are traced (hipHostRegister, released before the call returns), so that the  */
+                           /*   device-to-host copies are DMA instead of staged pageable copies; 1: leave it pageable     */
 } hz_opts;
 
 /* Run-time self report (the quantities the reference prints,                  */
