@@ -391,13 +391,19 @@ __global__ __launch_bounds__(256) void k_topo(const float *__restrict__ azim, co
         }
     };
     fetch(0);
+    __syncthreads();                                    // az_tab is written
+    // A wave's tile is private to it: LDS instructions of one wave execute in program order, so the transposed reads
+    // below see the stores above without a workgroup barrier (the waves of a workgroup drift apart and overlap each
+    // other's load and arithmetic phases); the fences only keep the compiler from reordering across them.
     for (int k0 = 0; k0 < A; k0 += HZ_TOPO_CH) {
         const int n = min(HZ_TOPO_CH, A - k0);
-        __syncthreads();                                // the previous block has been consumed (and az_tab is written)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < 32; r++) tile[(2 * r + half) * (HZ_TOPO_CH + 1) + col] = pre[r];
         if (k0 + HZ_TOPO_CH < A) fetch(k0 + HZ_TOPO_CH);   // the next block's loads fly while this one is reduced
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
         if (!have) continue;
         const float *row = tile + lane * (HZ_TOPO_CH + 1);
         for (int kk = 0; kk < n; kk++) {

@@ -276,6 +276,18 @@ def test_streamed_host_output(hip, chunk):
     assert np.array_equal(part[5:41], full[5:41])
     assert np.isnan(part[:5]).all() and np.isnan(part[41:]).all()
     vec_tilt = np.zeros(full.shape[:2] + (3,), np.float32); vec_tilt[..., 2] = 1.0
+    # the result array is page-locked chunk by chunk behind the scenes (HostPinner); with that switched off the copies
+    # are staged pageable ones: same bytes
+    import ctypes as C
+    from horayzon_amd import _lib
+    sc = hip.Scene.create(kw["vert_grid"], kw["dem_dim_0"], kw["dem_dim_1"])
+    plain = np.full(full.shape, np.nan, np.float32)
+    o = _lib.hz_opts(); o.chunk_rows = chunk; o.no_host_pin = 1
+    m = np.ones(full.shape[:2], np.uint8)
+    _lib.check(_lib.lib().hz_horizon_gridded_scene(sc._h, kw["vec_norm"].ctypes.data, kw["vec_north"].ctypes.data, kw["offset_0"], kw["offset_1"],
+                                                   plain.ctypes.data, full.shape[0], full.shape[1], 12, 1.0, 0.25, b"guess_constant", -60.0,
+                                                   m.ctypes.data, 0.0, 0.01, C.byref(o), None))
+    assert np.array_equal(plain, full)
     h2, _, svf = hip.horizon.horizon_gridded(**kw, **par, svf_vec_tilt=vec_tilt, _chunk_rows=chunk)
     h1, _, svf1 = hip.horizon.horizon_gridded(**kw, **par, svf_vec_tilt=vec_tilt)
     assert np.array_equal(h2, full) and np.array_equal(svf, svf1)
