@@ -406,6 +406,10 @@ __global__ __launch_bounds__(256) void k_topo(const float *__restrict__ azim, co
         __builtin_amdgcn_wave_barrier();
         if (!have) continue;
         const float *row = tile + lane * (HZ_TOPO_CH + 1);
+#ifndef HZ_TOPO_UNROLL
+#define HZ_TOPO_UNROLL 2      // two terms in flight per lane (the float32 accumulation stays sequential): 15.7 -> 14.8 ms; 4: 16.5 (VGPRs)
+#endif
+#pragma unroll HZ_TOPO_UNROLL
         for (int kk = 0; kk < n; kk++) {
             const float hv = row[kk];
             if (KIND == 2) {
