@@ -45,6 +45,38 @@ def classify(lines):
     return fast, slow, slow_names
 
 
+def bank_census(lines):
+    """VGPR bank (register number mod 4) collisions among the sources of the fast-class instructions: a fast
+    instruction whose sources share a bank issues in ~4.1 instead of ~2.4 cycles (profiles/r03/inst_rates.json); hipcc
+    assigns registers without regard to banks."""
+    st = {"fast_instructions": 0, "one_vgpr_source": 0, "all_sources_in_different_banks": 0, "two_sources_share_a_bank": 0,
+          "all_sources_in_one_bank": 0, "same_register_twice": 0}
+    for l in lines:
+        t = l.strip().split(None, 1)
+        if not t or not t[0].startswith("v_"):
+            continue
+        base = re.sub(r"_(e32|e64|sdwa|dpp)$", "", t[0])
+        if base not in FAST:
+            continue
+        ops = [o.strip() for o in t[1].split(",")] if len(t) > 1 else []
+        regs = [int(re.search(r"v(\d+)", o).group(1)) for o in ops[1:] if re.fullmatch(r"-?\|?v\d+\|?", o)]
+        if base in ("v_fmac_f32", "v_mac_f32") and re.fullmatch(r"v\d+", ops[0]):
+            regs.append(int(ops[0][1:]))                     # the destination is the third source
+        st["fast_instructions"] += 1
+        banks = [r % 4 for r in regs]
+        if len(regs) <= 1:
+            st["one_vgpr_source"] += 1
+        elif len(set(regs)) < len(regs):
+            st["same_register_twice"] += 1
+        elif len(set(banks)) == len(banks):
+            st["all_sources_in_different_banks"] += 1
+        elif len(set(banks)) == 1 and len(banks) >= 3:
+            st["all_sources_in_one_bank"] += 1
+        else:
+            st["two_sources_share_a_bank"] += 1
+    return st
+
+
 def main():
     src = os.path.join(ROOT, "horayzon_amd", "csrc", "hz_horizon.hip")
     out_s = "/tmp/hz_horizon_classmix.s"
@@ -87,7 +119,8 @@ def main():
     res = {"kernel_source_sha": bench.kernel_source_sha(), "classes": "fast: " + ", ".join(FAST)}
     for name, lines in sec.items():
         f, s, names = classify(lines)
-        res[name] = {"fast": f, "slow": s, "fast_fraction": f / max(f + s, 1), "slow_breakdown": names}
+        res[name] = {"fast": f, "slow": s, "fast_fraction": f / max(f + s, 1), "slow_breakdown": names,
+                     "vgpr_bank_census_of_fast_instructions": bank_census(lines)}
     with open(os.path.join(ROOT, "profiles", "valu_class_mix.json"), "w") as fh:
         json.dump(res, fh, indent=1)
     print(json.dumps({k_: (v if not isinstance(v, dict) else {q: v[q] for q in ("fast", "slow", "fast_fraction")}) for k_, v in res.items()}, indent=1))

@@ -214,6 +214,35 @@ def test_row_slab(hip, orc):
     assert np.isnan(part[:17]).all() and np.isnan(part[40:]).all()
 
 
+def test_concurrent_calls_on_one_scene(hip):
+    """The C ABI takes `const hz_scene *` and ctypes releases the GIL: two host threads may call on the same scene at
+    once.  The scene-owned certificate scratch and the shared stream are protected by the scene's run mutex (the calls
+    run one after the other); every call must return what it returns alone."""
+    import threading
+    g = cases.rough_terrain(90, 84, seed=41, offset=4, relief=900.0)
+    kw = cases.grid_kwargs(g)
+    sc = hip.Scene.create(kw["vert_grid"], 90, 84)
+    pars = [dict(dist_search=2.0, azim_num=36), dict(dist_search=1.0, azim_num=60, hori_acc=0.5),
+            dict(dist_search=3.0, azim_num=24, ray_algorithm="binary_search"), dict(dist_search=2.0, azim_num=90, rows=(10, 60))]
+    alone = [hip.horizon.horizon_gridded(**kw, **p, scene=sc)[0] for p in pars]
+    got, errs = [None] * len(pars), []
+
+    def work(i):
+        try:
+            for _ in range(3):
+                got[i] = hip.horizon.horizon_gridded(**kw, **pars[i], scene=sc)[0]
+        except Exception as exc:
+            errs.append(exc)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(pars))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errs, errs
+    for a, b in zip(alone, got):
+        assert np.array_equal(a, b, equal_nan=True)
+
+
 def test_row_slab_c_abi_semantics(hip):
     """C ABI (include/horayzon_hip.h): {0, 0} = whole domain, row_end = -1 = dim_in_0, negative / out-of-range /
     reversed slabs are rejected (not clamped), begin == end is an empty slab that succeeds and writes nothing; with
