@@ -68,3 +68,18 @@ def test_config5_single_rank_broadcast_is_free_and_emulated_partition():
         assert len(sl) == 4 and sl[0][0] == 0 and sl[-1][1] == 769 and all(sl[i][1] == sl[i + 1][0] for i in range(3))
         assert len(e[kind]["t_slab_s"]) == 4 and e[kind]["imbalance_measured"] >= 1.0
     assert e["cost"]["imbalance_predicted"] <= e["cells"]["imbalance_predicted"] + 1e-9
+
+
+def test_config4_bench_line():
+    """bench.py --workload c4 (small tile, 8 sun positions): the shadow line with its own roofline."""
+    env = dict(os.environ)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c4", "--tile", "601", "--suns", "8", "--steps", "2"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    cells = 569 * 569
+    assert d["n_gpus"] == 1 and d["steps"] == 2 and d["unit"] == "cells/s" and "Terrain.shadow" in d["metric"]
+    assert abs(d["value"] - 2 * 8 * cells / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "valu_issue" and 0.0 < r["frac"] <= 1.0 and r["kernel_ms_per_step"] > 0
+    assert r["nodes_per_ray"] > 1 and 0.0 < r["lane_utilisation_node_leaf_steps"] <= 1.0

@@ -214,6 +214,29 @@ def test_row_slab(hip, orc):
     assert np.isnan(part[:17]).all() and np.isnan(part[40:]).all()
 
 
+def test_host_output_that_is_already_page_locked(hip):
+    """The library page-locks a host result array while it runs (HostPinner).  An array the caller has pinned already
+    (torch pinned memory) cannot be registered again: the copies must simply go ahead."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    from horayzon_amd import _lib
+    g = cases.rough_terrain(70, 66, seed=13, offset=3)
+    kw = cases.grid_kwargs(g)
+    full, _ = hip.horizon.horizon_gridded(**kw, dist_search=1.0, azim_num=12, elev_ang_low_lim=-60.0)
+    sc = hip.Scene.create(kw["vert_grid"], 70, 66)
+    pinned = torch.empty(full.shape, dtype=torch.float32, pin_memory=True)
+    pinned.fill_(float("nan"))
+    out = pinned.numpy()
+    m = np.ones(full.shape[:2], np.uint8)
+    for chunk in (0, 9):
+        o = _lib.hz_opts(); o.chunk_rows = chunk
+        out[:] = np.nan
+        _lib.check(_lib.lib().hz_horizon_gridded_scene(sc._h, kw["vec_norm"].ctypes.data, kw["vec_north"].ctypes.data, 3, 3, out.ctypes.data,
+                                                       full.shape[0], full.shape[1], 12, 1.0, 0.25, b"guess_constant", -60.0, m.ctypes.data,
+                                                       0.0, 0.01, C.byref(o), None))
+        assert np.array_equal(out, full)
+
+
 def test_concurrent_calls_on_one_scene(hip):
     """The C ABI takes `const hz_scene *` and ctypes releases the GIL: two host threads may call on the same scene at
     once.  The scene-owned certificate scratch and the shared stream are protected by the scene's run mutex (the calls
