@@ -497,7 +497,8 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         size_t head = bytes;
         if (!pinner.regions.empty()) {
             pinner.wait_for(k);
-            if (!pinner.failed.load() && (size_t)k + 1 < pinner.regions.size()) {
+            if ((size_t)k + 1 < pinner.regions.size()) {      // (also when locking was given up half way: the boundary
+                                                              //  may then separate locked from pageable memory)
                 char *next = pinner.regions[(size_t)k + 1].first;
                 if (next > dst && next < dst + bytes) head = (size_t)(next - dst);
             }
