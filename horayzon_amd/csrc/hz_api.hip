@@ -6,6 +6,7 @@
 #include "hz_internal.h"
 #include <cmath>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 #include <limits>
@@ -605,7 +606,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             (void)hipEventRecord(e.c, st);
             if (!rc && stream_out && n_chunk >= 1) rc = copy_out(n_chunk - 1);
             if (rc) return fail(rc);
-            unsigned long long c[16];
+            unsigned long long c[24];
             if (hipMemcpyAsync(c, cnt_dev, sizeof(c), hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess)
                 return fail(set_error(HZ_ERR_HIP, "horizon kernel failed: %s", hipGetErrorString(hipGetLastError())));
@@ -614,6 +615,12 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             (void)hipEventElapsedTime(&m2, e.b, e.c);
             ms += m1; ms_svf += m2;
             for (int k = 0; k < 16; k++) cnt[k] += c[k];
+            if (a.count_work && getenv("HZ_XCD_TRACE")) {      // per-XCD span of this launch (counting instantiation)
+                const unsigned long long t0 = ~c[20];
+                fprintf(stderr, "hz xcd spans [ms] rows %d..%d:", rb, re);
+                for (int x = 0; x < 8; x++) fprintf(stderr, " %.1f", c[12 + x] ? (double)(c[12 + x] - t0) * 1.0e-5 : 0.0);
+                fprintf(stderr, "\n");
+            }
         }
     }
     Timer t_d2h; t_d2h.start();

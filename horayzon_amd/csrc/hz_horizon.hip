@@ -82,6 +82,7 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
     const bool in_dom = has_tile && (i < p.row_end) && (j < p.dim_in_1);
 
     const Tables &t = p.tb;
+    const unsigned long long t_start = COUNT ? (unsigned long long)wall_clock64() : 0ull;
     const size_t cell = in_dom ? ((size_t)i * p.dim_in_1 + j) : 0;
     bool done = !in_dom;
     // launch-local cell number: the only per-cell address state kept across the traversal (the output pointer
@@ -222,6 +223,13 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
         }
     }
     if (COUNT) {
+        // when did the last wave of each XCD finish?  (counters[12 + xcc] = latest end, counters[20] = ~earliest start, on
+        // the 100 MHz real-time counter; HZ_XCD_TRACE=1 prints the spans: the 8 XCDs own fixed regions of the tile)
+        if (lane == 0) {
+            const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;      // HW_REG_XCC_ID, bits 3:0
+            atomicMax(&p.counters[12 + xcc], (unsigned long long)wall_clock64());
+            atomicMax(&p.counters[20], ~t_start);
+        }
         unsigned long long sh = shortened, vi = violations;
         for (int off = 32; off > 0; off >>= 1) { sh += __shfl_xor(sh, off); vi += __shfl_xor(vi, off); }
         if (lane == 0) { if (sh) atomicAdd(&p.counters[9], sh); if (vi) atomicAdd(&p.counters[10], vi); }

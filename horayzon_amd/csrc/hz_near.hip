@@ -25,6 +25,9 @@
 //        tanE[k] = max over window edges crossing H_k of z / r at the crossing point
 //    bounds the elevation of everything in W along azimuth k.  (The six spokes from the cell's own vertex cross H_k
 //    only at the vertex itself, directly below o, and contribute nothing.)
+//  * That bound needs the window's surface to be a graph over the cell's LOCAL horizontal plane (one curve z(r) per
+//    azimuth, starting directly below o): checked per cell (orientation of every window triangle in the local (east,
+//    north) projection); a cell whose frame is tilted against terrain steeper than the tilt allows gets no certificate.
 //  * The mesh is a height field over the world (x, y) plane, so every triangle outside W projects outside W's
 //    boundary polygon, and its 3-D distance from o is at least the horizontal distance from o to that polygon:
 //    near_r = that distance (shrunk).  Outer-domain TIN triangles do not obey this; with a TIN the certificates
@@ -185,17 +188,34 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
     }
     // a window triangle (other than the six at the cell's own vertex) that contains the local vertical axis would be
     // seen at every azimuth, up to the zenith: its edges alone do not bound it -> no certificate for this cell
+    // The same triangles must form a GRAPH over the cell's local horizontal plane: every window triangle projects onto
+    // the local (east, north) plane with the same orientation and is not seen edge-on (|n . norm| > 1e-3 |n|).  The
+    // tangent bound above rests on it -- along an azimuth the surface is then one curve z(r) that starts directly below
+    // the origin.  With a frame tilted against very steep terrain (found by the random sweep of round 3: 1 m x 90 m
+    // cells, 119 m steps, vec_norm 0.4 degrees off the vertical) an ADJACENT triangle can face away from vec_norm; the
+    // origin then lies behind it, rays leaving upwards hit it at once, and its spokes -- which the edge phase skips
+    // because they "cross the half-plane at the vertex below the origin" -- bound nothing.  No certificate then.
     if (valid) {
+        bool pos = false, neg = false;
         for (int t = lane; t < 2 * NDIAG; t += 64) {
             const int qd = t >> 1, r = qd / (NV - 1), c = qd % (NV - 1);
             const int va = r * NV + c, vb = va + 1, vc = va + NV, vd = vc + 1;     // quad corners a, b / c, d
             const int i0 = (t & 1) ? vb : va, i1 = (t & 1) ? vd : vb, i2 = vc;     // (a, b, c) and (b, d, c)
-            if (i0 == CENTRE || i1 == CENTRE || i2 == CENTRE) continue;
             const float x0 = q[5 * i0], y0 = q[5 * i0 + 1], x1 = q[5 * i1], y1 = q[5 * i1 + 1], x2 = q[5 * i2], y2 = q[5 * i2 + 1];
+            {
+                const float ux = x1 - x0, uy = y1 - y0, uz = q[5 * i1 + 2] - q[5 * i0 + 2];
+                const float vx = x2 - x0, vy = y2 - y0, vz = q[5 * i2 + 2] - q[5 * i0 + 2];
+                const float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;   // nz: local projected area
+                if (!(nz * nz > 1.0e-6f * ((nx * nx + ny * ny) + nz * nz))) flags[0] = 1;
+                else if (nz > 0.0f) pos = true;
+                else neg = true;
+            }
+            if (i0 == CENTRE || i1 == CENTRE || i2 == CENTRE) continue;
             const float c0 = x0 * y1 - x1 * y0, c1 = x1 * y2 - x2 * y1, c2 = x2 * y0 - x0 * y2;   // origin vs the three edges
             const float tol = 1.0e-3f * (__builtin_fabsf(c0) + __builtin_fabsf(c1) + __builtin_fabsf(c2));
             if ((c0 >= -tol && c1 >= -tol && c2 >= -tol) || (c0 <= tol && c1 <= tol && c2 <= tol)) flags[0] = 1;
         }
+        if (__ballot(pos) != 0ull && __ballot(neg) != 0ull && lane == 0) flags[0] = 1;
     }
     __syncthreads();
     // ---- distance to everything outside the window: the boundary polygon in the world (x, y) plane -----------------

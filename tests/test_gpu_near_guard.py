@@ -90,3 +90,23 @@ def test_scene_reports_height_field(hip):
     assert sc2.vertices()[3] in (False, True)             # consistent orientation may still hold ...
     kw = _rotated_hill(80.0)
     assert hip.Scene.create(kw["vert_grid"], 200, 200).vertices()[3] is False
+
+
+def test_tilted_frame_against_very_steep_terrain(hip, orc):
+    """Configuration 370 of HZ_FUZZ_SEED=31001 (found by the wide random sweep of round 3): 1 m x 90 m cells with
+    100 m steps and vec_norm 0.4 degrees off the vertical.  Adjacent triangles face away from vec_norm, the ray origin
+    lies behind them, and the certificates -- which skip the spokes at the cell's own vertex -- shortened rays that hit
+    at once: 14 violations in one cell, visible only in the guard count (the horizon came out the same).  The window
+    must be a graph over the cell's LOCAL horizontal plane (hz_near.hip); such cells get no certificate now."""
+    rng = np.random.default_rng(31001)
+    for it in range(371):
+        kw, par, extra, tilt = cases.fuzz_case(rng)
+        if it % 4 == 1:
+            rng.integers(4, 15)
+    assert (kw["dem_dim_0"], kw["dem_dim_1"], par["hori_acc"], par["azim_num"]) == (15, 78, 3.0, 45)
+    out = hip.horizon.horizon_gridded(**kw, **par, rows=extra["rows"], count_work=True, _verify_near=True)
+    st = dict(hip.horizon.last_stats)
+    ref, _, so = orc.horizon_gridded(**kw, **par, rows=extra["rows"], return_stats=True)
+    assert st["near_used"] == 1 and st["near_violations"] == 0
+    assert np.array_equal(out[0], ref, equal_nan=True)
+    assert st["num_rays"] == so["rays"] and st["guard_events"] == so["guards"] == 539
