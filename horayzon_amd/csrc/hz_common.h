@@ -80,27 +80,33 @@ struct __attribute__((aligned(16))) Prim {
 };
 static_assert(sizeof(Prim) == 48, "Prim must be 48 bytes");
 
-// XCD-aware block -> tile mapping (device + host).  Workgroup b runs on XCD b % 8 (observed
-// dispatch order; used for L2 affinity only).  The tile grid is cut into sr x sc = 8 compact
-// regions, one per XCD; inside a region tiles are walked in column groups of `gw` tiles so that
-// the workgroups resident at the same time on one XCD cover a compact patch of the DEM (their
-// rays share BVH nodes in that XCD's L2).
+// XCD-aware block -> tile mapping (device + host).  Workgroup b runs on XCD b % 8 (observed dispatch order; used for
+// L2 affinity only), and the workgroups of one XCD are dispatched in the order of their number.  The tile grid is cut
+// into 8 columns x `pi` rows of compact PATCHES; XCD x owns one patch of every patch row (in row k the patch of column
+// (x + 5 k) % 8, so its patches are spread over the grid) and walks them one after the other, each in column groups of
+// `gw` tiles, so that the workgroups resident at the same time on one XCD cover a compact piece of the DEM (their rays
+// share BVH nodes in that XCD's L2).  Rounds 1-2 gave every XCD ONE region (an eighth of the grid): the XCDs then finish
+// when their own region is done, and on the 3601^2 tile the slowest one needed 5.9 % longer than the mean
+// (HZ_XCD_TRACE, 2091 ... 2326 ms) -- the launch waits for it.  Several patches per XCD average the terrain out.
 struct TileMap {
     int tiles_i, tiles_j;   // tile grid
-    int sr, sc;             // regions: sr rows x sc columns (sr * sc == 8)
-    int ri, rj;             // tiles per region (rows, columns; last regions may be cut)
-    int gw;                 // column-group width inside a region
-    int per_xcd;            // ri * rj: workgroups launched per XCD
+    int pi;                 // patch rows (8 patch columns): every XCD owns pi patches
+    int ri, rj;             // tiles per patch (rows, columns; the last patches of a row / column may be cut)
+    int gw;                 // column-group width inside a patch
+    int per_xcd;            // pi * ri * rj: workgroups launched per XCD
 };
 
 #ifdef __HIPCC__
 __device__ __forceinline__ bool hz_tile_of_block(const TileMap &m, int b, int *ti, int *tj) {
     const int x = b & 7, t = b >> 3;
-    const int i0 = (x / m.sc) * m.ri, j0 = (x % m.sc) * m.rj;
+    const int per_patch = m.ri * m.rj;
+    const int k = t / per_patch, r0 = t - k * per_patch;
+    if (k >= m.pi) return false;
+    const int i0 = k * m.ri, j0 = ((x + 5 * k) & 7) * m.rj;
     const int rows = min(m.ri, m.tiles_i - i0), cols = min(m.rj, m.tiles_j - j0);
-    if (rows <= 0 || cols <= 0 || t >= rows * cols) return false;
+    if (rows <= 0 || cols <= 0 || r0 >= rows * cols) return false;
     const int per_group = m.gw * rows;
-    const int g = t / per_group, r = t - g * per_group;
+    const int g = r0 / per_group, r = r0 - g * per_group;
     const int w = min(m.gw, cols - g * m.gw);          // width of this (possibly last, narrower) group
     *ti = i0 + r / w;
     *tj = j0 + g * m.gw + (r - (r / w) * w);
