@@ -86,6 +86,8 @@ inline SceneView scene_view(const Scene *sc) {
 
 inline TileMap make_tile_map(int tiles_i, int tiles_j, int gw = 8) {
     TileMap m;
+    static const int gw_env = []() { const char *e = getenv("HZ_TILE_GW"); return e ? atoi(e) : 0; }();
+    if (gw_env > 0) gw = gw_env;
     m.tiles_i = tiles_i; m.tiles_j = tiles_j; m.gw = gw;
     m.rj = std::max(1, (tiles_j + 7) / 8);
     // patch rows: near-square patches, but at least 16 rows when the grid is high enough and at most 64.  Measured on

@@ -148,7 +148,10 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
         carry += __shfl(inc, 63);
     }
     if (lane == 0) pre[NEDGE] = carry;
-    __syncthreads();
+    // (everything below the azimuth table is private to the wave: its LDS instructions execute in program order, so a
+    //  fence against compiler reordering is enough and the four cells of a workgroup need not wait for each other)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     // ---- edges, phase 2: one task = one edge x <= CH azimuths; where does the edge cross those vertical planes? ------
     if (valid) {
         const int n_task = pre[NEDGE];
@@ -217,7 +220,8 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
         }
         if (__ballot(pos) != 0ull && __ballot(neg) != 0ull && lane == 0) flags[0] = 1;
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     // ---- distance to everything outside the window: the boundary polygon in the world (x, y) plane -----------------
     float rin = __builtin_inff();
     if (valid && lane < NSEG) {
