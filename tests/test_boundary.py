@@ -300,8 +300,10 @@ def test_pad_buffer_mirrors_the_reference():
 
 
 def test_bench_roofline_arithmetic():
-    """bench.py's roofline object from known counters: achieved = wave-level VALU instructions / kernel time, peak as
-    handed in, frac = achieved / peak; HBM pair from the stamped traffic file only when it matches the run."""
+    """bench.py's roofline object from known counters: achieved = the SIMD cycles the launch's VALU instructions need at
+    the issue rates of the two instruction classes (wave iterations x instructions per iteration x class mix) per
+    second, peak = SIMDs x clock, frac = achieved / peak; frac_uniform_4_cycle = the round-1/2 model; HBM pair from the
+    stamped traffic file only when it matches the run."""
     import types
     import bench
     from horayzon_amd import _lib
@@ -310,14 +312,19 @@ def test_bench_roofline_arithmetic():
     cw = _lib.hz_stats(); cw.num_rays = 10 ** 10; cw.nodes_visited = 22 * 10 ** 10; cw.tris_tested = 6 * 10 ** 10
     cw.wave_node_iters = 5 * 10 ** 9; cw.wave_leaf_iters = 10 ** 9; cw.wave_refills = 5 * 10 ** 8
     peaks = {"valu_winst_per_s": 6.144e11, "valu_winst_per_s_measured": 6.0e11, "simds": 1024, "clock_ghz": 2.4,
-             "cycles_per_wave_inst_measured": 4.096, "copy_gbs": 4600.0}
+             "cycles_per_wave_inst_measured": 4.096, "copy_gbs": 4600.0,
+             "class_rates": {"fast_cycles": 2.5, "slow_cycles": 4.0}}
     r = bench.roofline(args, st, 2, cw, peaks, 360, 3601, 3569)
-    m = r["valu_model_constants"]
+    m, mix = r["valu_model_constants"], r["class_mix_fast_fraction"]
     winst = 5e9 * m["node_iter"] + 1e9 * m["leaf_iter"] + 5e8 * m["refill_iter"]      # per launch: rays per launch = cw rays
-    assert r["bound"] == "valu_issue" and r["unit"] == "G wave-instructions/s"
+    cyc = lambda f: 2.5 * f + 4.0 * (1.0 - f)
+    need = (5e9 * m["node_iter"] * cyc(mix["node_step"]) + 1e9 * m["leaf_iter"] * cyc(mix["leaf_step"])
+            + 5e8 * m["refill_iter"] * cyc(mix["refill_and_loop_overhead"]))
+    assert r["bound"] == "valu_issue" and r["unit"].startswith("G SIMD-cycles/s")
     assert abs(r["valu_winst_per_launch"] - winst) <= 1e-6 * winst
-    assert abs(r["achieved"] - winst / 2.0 / 1e9) <= 1e-6 * r["achieved"] and r["peak"] == 614.4
+    assert abs(r["achieved"] - need / 2.0 / 1e9) <= 1e-6 * r["achieved"] and abs(r["peak"] - 1024 * 2.4) < 1e-9
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel_ms_per_launch"] == 2000.0
+    assert abs(r["frac_uniform_4_cycle"] - winst / 2.0 / 6.144e11) < 1e-12 and r["frac"] < r["frac_uniform_4_cycle"]
     assert r["nodes_per_ray"] == 22.0 and r["tris_per_ray"] == 6.0
     if r["traffic"] is not None:          # stamped for these kernel sources and this launch shape
         assert abs(r["hbm"]["hbm_frac"] - r["traffic"] / 2.0 / 1e9 / 8000.0) < 1e-12
