@@ -397,7 +397,14 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         for (;;) {
             chunk_rows = row_end - row_begin;
             if (fixed) chunk_rows = std::min(chunk_rows, opts->chunk_rows);
-            else chunk_rows = (int)std::max<size_t>(16, std::min<size_t>((size_t)chunk_rows, target / row_bytes));
+            else {
+                chunk_rows = (int)std::max<size_t>(16, std::min<size_t>((size_t)chunk_rows, target / row_bytes));
+                // equal chunks (whole 16-row tile rows) instead of full ones and a small rest: a slab of 1800 rows is
+                // 3 x 608 rows, not 830 + 830 + 140 -- every launch ends with a tail, and a short launch is mostly tail
+                const int rows_all = row_end - row_begin;
+                const int n_ch = (rows_all + chunk_rows - 1) / chunk_rows;
+                chunk_rows = std::min(chunk_rows, std::max(16, ((rows_all + n_ch - 1) / n_ch + 15) / 16 * 16));
+            }
             chunk_rows = std::min(chunk_rows, row_end - row_begin);
             if (hipMalloc(&tmp_hori, (size_t)chunk_rows * row_bytes) == hipSuccess) break;
             (void)hipGetLastError();
