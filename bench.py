@@ -69,7 +69,7 @@ def parse():
     ap.add_argument("--which", choices=("shadow", "sw_dir_cor"), default="shadow", help="c4: output kind")
     ap.add_argument("--balance", choices=("cost", "cells"), default="cells",
                     help="c5: row slabs balanced by cell count (default) or by the sampled cost pre-pass (measured on the "
-                         "synthetic mosaic, 8 emulated ranks: 1.054 against 1.061 max/mean, less than the pre-pass costs)")
+                         "synthetic mosaic, 8 emulated ranks: 1.028 against 1.033 max/mean, less than the pre-pass costs)")
     ap.add_argument("--cost-samples", type=int, default=0, help="c5: probe rows of the cost pre-pass (0: max(16, 4 x ranks))")
     ap.add_argument("--emulate-ranks", type=int, default=0, help="c5, one GPU: time the slabs of an R-rank partition one by one")
     ap.add_argument("--dump-svf-rows", default="", help="c5: comma separated inner-domain rows of the gathered SVF to save")
