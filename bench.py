@@ -474,6 +474,7 @@ def run_c5(ctx):
     import torch
     import torch.distributed as dist
     from horayzon_amd import _lib, synth
+    from horayzon_amd import dist as _dist_mod
     from horayzon_amd.dist import (sharded_rows, row_slabs, estimate_row_cost, predicted_imbalance,
                                    device_bytes_tensor)
     args, rank, world, dev = ctx["args"], ctx["rank"], ctx["world"], ctx["dev"]
@@ -488,7 +489,7 @@ def run_c5(ctx):
     del g
     blob_ptr, blob_bytes = scene.blob()
     vptr, d0, d1, height_field = scene.vertices()
-    verts = device_bytes_tensor(vptr, d0 * d1 * 12, ctx["local_rank"], owner=scene).view(torch.float32).view(d0, d1, 3)
+    verts = _dist_mod.device_bytes_or_copy(vptr, d0 * d1 * 12, ctx["local_rank"], owner=scene)[0].view(torch.float32).view(d0, d1, 3)
     stats = _lib.hz_stats()
 
     def slab_inputs(b, e):
@@ -591,7 +592,7 @@ def run_c5(ctx):
                    "cost_prepass_s": t_cost, "cost_prepass_probe_rows": n_samples if cost is not None else 0,
                    "cost_prepass_probe_azimuths": a_probe,
                    "bvh_build_s": scene_stats["t_bvh_s"] if scene_stats else None, "scene_bytes": int(blob_bytes),
-                   "scene_bcast_s": t_bcast, "scene_bcast_zero_copy": True, "scene_create_wall_s": t_build,
+                   "scene_bcast_s": t_bcast, "scene_bcast_zero_copy": _dist_mod.last_broadcast_zero_copy, "scene_create_wall_s": t_build,
                    "kernel_s_rank0": stats.t_kernel_s,
                    "svf_kernel_s_rank0": stats.t_svf_s, "near_prepass_s_rank0": stats.t_near_s,
                    "stack_fallbacks_rank0": int(stats.stack_fallbacks), "stack_redo_blocks_rank0": int(stats.stack_redo_blocks),

@@ -142,11 +142,33 @@ def device_bytes_tensor(ptr, nbytes, device, owner=None):
     return t
 
 
+def device_bytes_or_copy(ptr, nbytes, device, owner=None):
+    """(uint8 tensor over the range, True) -- or, if torch cannot wrap it, (a torch-owned copy of the range, False)."""
+    try:
+        return device_bytes_tensor(ptr, nbytes, device, owner=owner), True
+    except Exception:
+        import ctypes as C
+        import torch
+        from . import _lib
+        buf = torch.empty(int(nbytes), dtype=torch.uint8, device="cuda:%d" % device)
+        path = next((l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l), "libamdhip64.so")
+        rc = C.CDLL(path).hipMemcpy(C.c_void_p(buf.data_ptr()), C.c_void_p(int(ptr)), C.c_size_t(int(nbytes)), 3)
+        if rc != 0:
+            raise _lib.HorayzonHipError("hipMemcpy of a device range failed (%d)" % rc)
+        return buf, False
+
+
+last_broadcast_zero_copy = None      # True / False after a broadcast on the source rank (bench.py reports it)
+
+
 def _hip_blob_tensor(scene, device):
     """The scene's blob AS a torch uint8 CUDA tensor: the send buffer of the broadcast is the blob allocation itself
-    (no second copy of a 17.7 GB blob on the source rank)."""
+    (no second copy of a 17.7 GB blob on the source rank).  If torch cannot wrap the range (an unexpected build of
+    torch), the blob is copied into a torch tensor as in round 2 -- slower, same result."""
+    global last_broadcast_zero_copy
     p, n = scene.blob()
-    return device_bytes_tensor(p, n, device, owner=scene), n
+    t, last_broadcast_zero_copy = device_bytes_or_copy(p, n, device, owner=scene)
+    return t, n
 
 
 def broadcast_scene(scene, device, src=0, group=None, *, to_tensor=None, adopt=None, torch_device=None):
