@@ -178,12 +178,36 @@ __global__ __launch_bounds__(256) void k_inst_rate(unsigned *__restrict__ out, i
                              "v_fma_f32 v100, v100, v104, v108\n\tv_fma_f32 v112, v112, v104, v108\n\tv_fma_f32 v116, v116, v104, v108\n\tv_fma_f32 v120, v120, v104, v108\n\t"
                              "v_fma_f32 v124, v124, v104, v108\n\tv_fma_f32 v128, v128, v104, v108\n\tv_fma_f32 v132, v132, v104, v108\n\tv_fma_f32 v136, v136, v104, v108"
                              : : : "v100", "v104", "v108", "v112", "v116", "v120", "v124", "v128", "v132", "v136");
-            } else {                 // 34: the same with the sources in three different banks
+            } else if (OP == 34) {   // the same with the sources in three different banks
                 asm volatile("v_fma_f32 v100, v100, v105, v110\n\tv_fma_f32 v112, v112, v105, v110\n\tv_fma_f32 v116, v116, v105, v110\n\tv_fma_f32 v120, v120, v105, v110\n\t"
                              "v_fma_f32 v124, v124, v105, v110\n\tv_fma_f32 v128, v128, v105, v110\n\tv_fma_f32 v132, v132, v105, v110\n\tv_fma_f32 v136, v136, v105, v110\n\t"
                              "v_fma_f32 v100, v100, v105, v110\n\tv_fma_f32 v112, v112, v105, v110\n\tv_fma_f32 v116, v116, v105, v110\n\tv_fma_f32 v120, v120, v105, v110\n\t"
                              "v_fma_f32 v124, v124, v105, v110\n\tv_fma_f32 v128, v128, v105, v110\n\tv_fma_f32 v132, v132, v105, v110\n\tv_fma_f32 v136, v136, v105, v110"
                              : : : "v100", "v105", "v110", "v112", "v116", "v120", "v124", "v128", "v132", "v136");
+            } else {
+                // 35 .. 42: do VGPR bank collisions (register number mod 4) also slow the slow-class instructions of the
+                // node step down?  odd selector: every source in bank 0 (v100 / v104 / v108); even: three banks (v100 / v105 / v110)
+#define HZ_B8(INS, A, B, TAIL) INS " v100, v100, " A ", " B TAIL "\n\t" INS " v112, v112, " A ", " B TAIL "\n\t" INS " v116, v116, " A ", " B TAIL "\n\t" \
+                INS " v120, v120, " A ", " B TAIL "\n\t" INS " v124, v124, " A ", " B TAIL "\n\t" INS " v128, v128, " A ", " B TAIL "\n\t" \
+                INS " v132, v132, " A ", " B TAIL "\n\t" INS " v136, v136, " A ", " B TAIL
+#define HZ_B16(INS, A, B, TAIL) asm volatile(HZ_B8(INS, A, B, TAIL) "\n\t" HZ_B8(INS, A, B, TAIL) : : : "v100", "v104", "v105", "v108", "v110", \
+                "v112", "v116", "v120", "v124", "v128", "v132", "v136")
+                if (OP == 35) HZ_B16("v_fma_mix_f32", "v104", "v108", " op_sel:[1,0,0] op_sel_hi:[1,0,0]");
+                else if (OP == 36) HZ_B16("v_fma_mix_f32", "v105", "v110", " op_sel:[1,0,0] op_sel_hi:[1,0,0]");
+                else if (OP == 37) HZ_B16("v_perm_b32", "v104", "v108", "");
+                else if (OP == 38) HZ_B16("v_perm_b32", "v105", "v110", "");
+                else if (OP == 39) HZ_B16("v_max3_f32", "v104", "v108", "");
+                else if (OP == 40) HZ_B16("v_max3_f32", "v105", "v110", "");
+                else if (OP == 41) asm volatile("v_max_f32_e32 v100, v100, v104\n\tv_max_f32_e32 v112, v112, v104\n\tv_max_f32_e32 v116, v116, v104\n\tv_max_f32_e32 v120, v120, v104\n\t"
+                                                "v_max_f32_e32 v124, v124, v104\n\tv_max_f32_e32 v128, v128, v104\n\tv_max_f32_e32 v132, v132, v104\n\tv_max_f32_e32 v136, v136, v104\n\t"
+                                                "v_max_f32_e32 v100, v100, v104\n\tv_max_f32_e32 v112, v112, v104\n\tv_max_f32_e32 v116, v116, v104\n\tv_max_f32_e32 v120, v120, v104\n\t"
+                                                "v_max_f32_e32 v124, v124, v104\n\tv_max_f32_e32 v128, v128, v104\n\tv_max_f32_e32 v132, v132, v104\n\tv_max_f32_e32 v136, v136, v104"
+                                                : : : "v100", "v104", "v112", "v116", "v120", "v124", "v128", "v132", "v136");
+                else asm volatile("v_max_f32_e32 v100, v100, v105\n\tv_max_f32_e32 v112, v112, v105\n\tv_max_f32_e32 v116, v116, v105\n\tv_max_f32_e32 v120, v120, v105\n\t"
+                                  "v_max_f32_e32 v124, v124, v105\n\tv_max_f32_e32 v128, v128, v105\n\tv_max_f32_e32 v132, v132, v105\n\tv_max_f32_e32 v136, v136, v105\n\t"
+                                  "v_max_f32_e32 v100, v100, v105\n\tv_max_f32_e32 v112, v112, v105\n\tv_max_f32_e32 v116, v116, v105\n\tv_max_f32_e32 v120, v120, v105\n\t"
+                                  "v_max_f32_e32 v124, v124, v105\n\tv_max_f32_e32 v128, v128, v105\n\tv_max_f32_e32 v132, v132, v105\n\tv_max_f32_e32 v136, v136, v105"
+                                  : : : "v100", "v105", "v112", "v116", "v120", "v124", "v128", "v132", "v136");
             }
         }
     }
@@ -258,6 +282,14 @@ int bench_inst_rate(int op, double *cycles_per_inst) {
         case 32: ms = inst_rate_ms<32>(grid, out, trips); break;
         case 33: ms = inst_rate_ms<33>(grid, out, trips); break;
         case 34: ms = inst_rate_ms<34>(grid, out, trips); break;
+        case 35: ms = inst_rate_ms<35>(grid, out, trips); break;
+        case 36: ms = inst_rate_ms<36>(grid, out, trips); break;
+        case 37: ms = inst_rate_ms<37>(grid, out, trips); break;
+        case 38: ms = inst_rate_ms<38>(grid, out, trips); break;
+        case 39: ms = inst_rate_ms<39>(grid, out, trips); break;
+        case 40: ms = inst_rate_ms<40>(grid, out, trips); break;
+        case 41: ms = inst_rate_ms<41>(grid, out, trips); break;
+        case 42: ms = inst_rate_ms<42>(grid, out, trips); break;
         default: (void)hipFree(out); return set_error(HZ_ERR_ARG, "unknown instruction selector %d", op);
     }
     (void)hipFree(out);

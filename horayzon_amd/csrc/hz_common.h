@@ -7,7 +7,7 @@
 // vertices : the caller's vert_grid, untouched (ray origins read them;
 //            reference: shared vertex buffer, horizon_comp.cpp:126-127).
 // nodes    : flat LBVH collapsed to 4-wide nodes along the 2-bit digits of the Morton key (= a quadtree over the
-//            (x, y) centroids).  One node is 64 B and holds the conservatively quantised AABBs (8 bit x/y, 16 bit z,
+//            (x, y) centroids).  One node is 64 B and holds the conservatively quantised AABBs (8 bit x/y, 11 bit z as half floats,
 //            relative to the node's own box) of up to 4 children, stored tallest (largest z-max) first.  ALL nodes
 //            are numbered breadth first and the children of a node are CONTIGUOUS: one index (`first`) addresses
 //            the block of 4 child slots -- 4 consecutive nodes, or 4 consecutive leaf records (a node whose children
@@ -29,7 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #define HZ_BLOB_MAGIC 0x485a4c42u /* "HZLB" */
-#define HZ_BLOB_VERSION 6u
+#define HZ_BLOB_VERSION 7u
 #define HZ_WAVE 64
 
 struct BlobHeader {
@@ -65,11 +65,12 @@ static_assert(sizeof(BlobHeader) == 256, "BlobHeader must be 256 bytes");
 #define HZ_LEAF_BIT 0x80000000u
 #define HZ_LEAF_ID(link) ((int)((unsigned)(link) & 0x7fffffffu))
 struct __attribute__((aligned(64))) Node {
-    float org[3];        // lower corner of the node's box (centred frame)
+    float org[3];        // lower corner of the node's box (centred frame); x and y shifted by -1024 quantisation steps
+                         // (a child's x bound is org[0] + (1024 + q) * step[0]: the form hz_qbox_hit decodes)
     int32_t first;       // link of child slot 0; slots 1..3 are first + 1 .. first + 3: 4 consecutive nodes or 4
                          // consecutive leaf records (blocks are 4-aligned; slot k exists iff bit k of `valid`)
     uint32_t qxy[4];     // per child slot: xlo | xhi<<8 | ylo<<16 | yhi<<24   (8 bit, 0..255)
-    uint32_t qz[4];      // per child slot: zlo | zhi<<16                      (16 bit)
+    uint32_t qz[4];      // per child slot: zlo | zhi<<16     (two half floats holding integers 0..2047: org[2] + q * step[2])
     float step[3];       // quantisation steps of x, y, z (powers of two)
     uint32_t valid;
 };
@@ -251,8 +252,8 @@ __device__ __forceinline__ bool hz_tri_hit_t(float ox, float oy, float oz, float
 struct RayBox {
     float rdx, rdy, rdz;     // 1 / d (clamped away from inf)
     float ordx, ordy, ordz;  // (o - center) * rd
-    uint32_t sel_xy, sel_z;  // v_perm selectors that put the NEAR bound first: (x_near, x_far, y_near, y_far)
-                             // and (z_near, z_far); near = lo when 1/d > 0, hi otherwise
+    uint32_t sel_x, sel_y, sel_z;   // v_perm selectors that put the NEAR bound into the low half word and the FAR bound
+                                    // into the high one (near = lo when 1/d > 0, hi otherwise); see hz_qbox_hit
 };
 
 __device__ __forceinline__ float hz_safe_rcp(float d) {
@@ -265,8 +266,10 @@ __device__ __forceinline__ RayBox hz_raybox(float ocx, float ocy, float ocz,
     RayBox r;
     r.rdx = hz_safe_rcp(dx); r.rdy = hz_safe_rcp(dy); r.rdz = hz_safe_rcp(dz);
     r.ordx = ocx * r.rdx; r.ordy = ocy * r.rdy; r.ordz = ocz * r.rdz;
-    // selector bytes 0..3 pick bytes 0..3 of the second v_perm operand
-    r.sel_xy = ((r.rdy < 0.0f) ? 0x02030000u : 0x03020000u) | ((r.rdx < 0.0f) ? 0x00000001u : 0x00000100u);
+    // selector bytes 0..3 pick bytes 0..3 of the second v_perm operand (the packed bounds), 4 picks byte 0 of the
+    // first one (HZ_HALF_MAGIC): x and y bounds are single bytes that become the mantissa of a half float
+    r.sel_x = (r.rdx < 0.0f) ? 0x04000401u : 0x04010400u;
+    r.sel_y = (r.rdy < 0.0f) ? 0x04020403u : 0x04030402u;
     r.sel_z = (r.rdz < 0.0f) ? 0x01000302u : 0x03020100u;
     return r;
 }
@@ -282,18 +285,36 @@ __device__ __forceinline__ NodeRay hz_node_ray(const RayBox &r, float ox, float 
     return n;
 }
 
+// Child bounds are decoded WITHOUT integer -> float conversions (24 v_cvt + 24 v_fma per node step in rounds 1-3: the
+// conversions are slow-class VALU instructions and the three-source FMAs collided in the VGPR banks):
+//   x, y : 8-bit integers q.  One v_perm_b32 per axis builds the two half floats 0x64qq = 1024 + q (near bound in the low
+//          half word, far bound in the high one; the byte 0x64 comes from the constant operand), and v_fma_mix_f32 reads a
+//          half-float source directly: t = (1024 + q) * a + b.  The node stores its x / y origin shifted by -1024 steps
+//          (Node::org), so a and b are formed exactly as before.
+//   z    : stored as half floats (integers 0 .. 2047, exact in binary16); one v_perm_b32 orders (near, far).
+// 3 v_perm + 6 v_fma_mix per child instead of 2 v_perm + 6 v_cvt + 6 v_fma.
+#define HZ_HALF_MAGIC 0x64646464u
+typedef _Float16 hz_half2 __attribute__((ext_vector_type(2)));
+
+// (float)half * a + b as ONE v_fma_mix_f32 (the compiler folds the conversion into the FMA's operand modifier; written in
+// C++ rather than inline asm so that it knows the results are arithmetic values: no canonicalising v_max_f32 before min / max)
+__device__ __forceinline__ float hz_fma_mix_lo(uint32_t h2, float a, float b) {
+    return __builtin_fmaf((float)__builtin_bit_cast(hz_half2, h2).x, a, b);
+}
+__device__ __forceinline__ float hz_fma_mix_hi(uint32_t h2, float a, float b) {
+    return __builtin_fmaf((float)__builtin_bit_cast(hz_half2, h2).y, a, b);
+}
+
 // does [0, tfar] overlap the quantised child box (qxy, qz)?  The ray's direction signs say which
 // bound of each slab is entered first, so the bounds are byte-permuted once (v_perm_b32) instead
 // of being sorted with min / max per axis.
 __device__ __forceinline__ bool hz_qbox_hit(const NodeRay &n, const RayBox &r, float tfar, uint32_t qxy, uint32_t qz) {
-    const uint32_t pxy = __builtin_amdgcn_perm(0u, qxy, r.sel_xy);
+    const uint32_t px = __builtin_amdgcn_perm(HZ_HALF_MAGIC, qxy, r.sel_x);
+    const uint32_t py = __builtin_amdgcn_perm(HZ_HALF_MAGIC, qxy, r.sel_y);
     const uint32_t pz = __builtin_amdgcn_perm(0u, qz, r.sel_z);
-    const float xn = (float)(pxy & 0xffu), xf = (float)((pxy >> 8) & 0xffu);
-    const float yn = (float)((pxy >> 16) & 0xffu), yf = (float)(pxy >> 24);
-    const float zn = (float)(pz & 0xffffu), zf = (float)(pz >> 16);
-    const float tnx = __builtin_fmaf(xn, n.ax, n.bx), tfx = __builtin_fmaf(xf, n.ax, n.bx);
-    const float tny = __builtin_fmaf(yn, n.ay, n.by), tfy = __builtin_fmaf(yf, n.ay, n.by);
-    const float tnz = __builtin_fmaf(zn, n.az, n.bz), tfz = __builtin_fmaf(zf, n.az, n.bz);
+    const float tnx = hz_fma_mix_lo(px, n.ax, n.bx), tfx = hz_fma_mix_hi(px, n.ax, n.bx);
+    const float tny = hz_fma_mix_lo(py, n.ay, n.by), tfy = hz_fma_mix_hi(py, n.ay, n.by);
+    const float tnz = hz_fma_mix_lo(pz, n.az, n.bz), tfz = hz_fma_mix_hi(pz, n.az, n.bz);
     const float tmin = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));
     const float tmax = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tfar));
 #ifdef HZ_PROBE_NO_SLACK      // measurement probe: how much does the relative slack cost?

@@ -12,7 +12,7 @@
 //   5. k_leaf_boxes / k_refit_pass  leaf AABBs; bottom-up union, level synchronous with work lists
 //   6. k_roots/scan  collapse along the 2-bit Morton digits: a binary node starts a 4-wide
 //                    node when its common-prefix length enters a new digit (quadtree level)
-//   7. k_emit4       temp 4-wide nodes with conservatively quantised child AABBs (8 bit x/y, 16 bit z),
+//   7. k_emit4       temp 4-wide nodes with conservatively quantised child AABBs (8 bit x/y, 11 bit z as half floats),
 //                    children sorted tallest first
 //   8. k_bfs_*       breadth-first numbering of ALL nodes, level by level, with the children of every node in one
 //                    contiguous block of 4 slots (nodes or 48 B leaf records); emits the final nodes and leaves
@@ -314,6 +314,51 @@ __device__ __forceinline__ uint32_t step_exponent(float extent, float qmax) {
     return (uint32_t)biased;
 }
 
+// x / y bounds (hz_common.h: hz_qbox_hit).  The traversal decodes code q in [0, 255] as the half float 1024 + q and
+// evaluates t = (1024 + q) * (s rd) + (o' rd - oc rd) with the STORED origin o' ~ lo_node - 1024 s.  In exact
+// arithmetic that is the plane X(q) = o' + (1024 + q) s; the build guarantees X(q_lo) <= lo - m and X(q_hi) >= hi + m,
+// checked in float64 (exact for these operands).  m = s 2^-12 pays for what the 1024 s offset adds to the rounding
+// of the two ray constants (b = fma(o', rd, -oc rd): |o'| grows by <= 1024 s, so its rounding by <= 1024 s 2^-24 =
+// s 2^-14 in space units; the origin's own rounding is below that) -- everything else is the error
+// structure the leaf padding has covered since round 1.
+struct AxisQ { uint32_t e; float s, o, m; };
+__device__ __forceinline__ double axis_plane(const AxisQ &a, float q) { return (double)a.o + (double)(1024.0f + q) * (double)a.s; }
+__device__ __forceinline__ AxisQ axis_setup(float nl, float nh) {
+    AxisQ a;
+    a.e = step_exponent(nh - nl, 253.0f);
+    for (;;) {
+        a.s = __uint_as_float(a.e << 23);
+        a.m = a.s * (1.0f / 4096.0f);
+        a.o = nl - 1024.0f * a.s;
+        for (int g = 0; g < 16 && axis_plane(a, 0.0f) > (double)nl - (double)a.m; g++) a.o = nextafterf(a.o, -INFINITY);
+        if (axis_plane(a, 255.0f) >= (double)nh + (double)a.m || a.e >= 254u) break;
+        a.e++;
+    }
+    return a;
+}
+__device__ __forceinline__ uint32_t axis_lo(const AxisQ &a, float lo) {
+    const double want = (double)lo - (double)a.m;
+    float q = fminf(fmaxf(floorf((float)((want - (double)a.o) / (double)a.s) - 1024.0f), 0.0f), 255.0f);
+    while (q > 0.0f && axis_plane(a, q) > want) q -= 1.0f;
+    while (q < 255.0f && axis_plane(a, q + 1.0f) <= want) q += 1.0f;
+    return (uint32_t)q;
+}
+__device__ __forceinline__ uint32_t axis_hi(const AxisQ &a, float hi) {
+    const double want = (double)hi + (double)a.m;
+    float q = fminf(fmaxf(ceilf((float)((want - (double)a.o) / (double)a.s) - 1024.0f), 0.0f), 255.0f);
+    while (q < 255.0f && axis_plane(a, q) < want) q += 1.0f;
+    while (q > 0.0f && axis_plane(a, q - 1.0f) >= want) q -= 1.0f;
+    return (uint32_t)q;
+}
+// z bounds: integers 0 .. 2047 stored as half floats (exact), decoded as o + q s with the node's own lower corner
+#define HZ_QZ_MAX 2047.0f
+__device__ __forceinline__ uint32_t half_bits(uint32_t q) {
+    const _Float16 h = (_Float16)(float)q;
+    return (uint32_t)__builtin_bit_cast(unsigned short, h);
+}
+#define HZ_QXY_EMPTY 0x00ff00ffu      // lo > hi on every axis: never hit
+#define HZ_QZ_EMPTY 0x000067ffu       // half(2047) | half(0) << 16
+
 __global__ __launch_bounds__(256) void k_emit4(Emit4 e, NodeTmp *__restrict__ nodes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= e.n_nodes || !e.flag[i]) return;
@@ -370,21 +415,21 @@ __global__ __launch_bounds__(256) void k_emit4(Emit4 e, NodeTmp *__restrict__ no
     const float4 nl = e.node_lo[i], nh = e.node_hi[i];
     const float org[3] = {nl.x, nl.y, nl.z};
     const float ext[3] = {nh.x - nl.x, nh.y - nl.y, nh.z - nl.z};
-    const uint32_t ex = step_exponent(ext[0], 255.0f), ey = step_exponent(ext[1], 255.0f);
-    const uint32_t ez = step_exponent(ext[2], 65535.0f);
-    const float sx = __uint_as_float(ex << 23), sy = __uint_as_float(ey << 23), sz = __uint_as_float(ez << 23);
+    const AxisQ ax = axis_setup(nl.x, nh.x), ay = axis_setup(nl.y, nh.y);
+    const uint32_t ez = step_exponent(ext[2], HZ_QZ_MAX);
+    const float sz = __uint_as_float(ez << 23);
     NodeTmp n;
-    n.org[0] = org[0]; n.org[1] = org[1]; n.org[2] = org[2];
-    n.scale = ex | (ey << 8) | (ez << 16);
+    n.org[0] = ax.o; n.org[1] = ay.o; n.org[2] = org[2];
+    n.scale = ax.e | (ay.e << 8) | (ez << 16);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         n.link[k] = link[k];
-        if (link[k] == HZ_TMP_EMPTY) { n.qxy[k] = 0x00ff00ffu; n.qz[k] = 0x0000ffffu; continue; }   // lo > hi: never hit
-        const uint32_t xl = quant_lo(lo[k][0], org[0], sx, 255.0f), xh = quant_hi(hi[k][0], org[0], sx, 255.0f);
-        const uint32_t yl = quant_lo(lo[k][1], org[1], sy, 255.0f), yh = quant_hi(hi[k][1], org[1], sy, 255.0f);
-        const uint32_t zl = quant_lo(lo[k][2], org[2], sz, 65535.0f), zh = quant_hi(hi[k][2], org[2], sz, 65535.0f);
+        if (link[k] == HZ_TMP_EMPTY) { n.qxy[k] = HZ_QXY_EMPTY; n.qz[k] = HZ_QZ_EMPTY; continue; }   // lo > hi: never hit
+        const uint32_t xl = axis_lo(ax, lo[k][0]), xh = axis_hi(ax, hi[k][0]);
+        const uint32_t yl = axis_lo(ay, lo[k][1]), yh = axis_hi(ay, hi[k][1]);
+        const uint32_t zl = quant_lo(lo[k][2], org[2], sz, HZ_QZ_MAX), zh = quant_hi(hi[k][2], org[2], sz, HZ_QZ_MAX);
         n.qxy[k] = xl | (xh << 8) | (yl << 16) | (yh << 24);
-        n.qz[k] = zl | (zh << 16);
+        n.qz[k] = half_bits(zl) | (half_bits(zh) << 16);
     }
     nodes[e.idx[i]] = n;
 }
@@ -494,7 +539,7 @@ __global__ __launch_bounds__(256) void k_bfs_emit(BfsEmit e, BuildParams b) {
                 w.org[0] = n.org[0]; w.org[1] = n.org[1]; w.org[2] = n.org[2];
                 w.step[0] = n.step[0]; w.step[1] = n.step[1]; w.step[2] = n.step[2];
                 w.first = 0; w.valid = 1u;
-                for (int q = 0; q < 4; q++) { w.qxy[q] = 0x00ff00ffu; w.qz[q] = 0x0000ffffu; }
+                for (int q = 0; q < 4; q++) { w.qxy[q] = HZ_QXY_EMPTY; w.qz[q] = HZ_QZ_EMPTY; }
                 w.qxy[0] = t.qxy[k]; w.qz[0] = t.qz[k];
                 e.nodes[first + k] = w;
             }
@@ -522,16 +567,16 @@ __global__ __launch_bounds__(256) void k_anc_bfs(int n_leaf_blocks, int levels, 
 // single primitive: a temp root whose slot 0 is the leaf, quantised against its own box
 __global__ void k_single_tmp(const float4 *leaf_lo, const float4 *leaf_hi, NodeTmp *nodes) {
     const float4 l = leaf_lo[0], h = leaf_hi[0];
-    const uint32_t ex = step_exponent(h.x - l.x, 255.0f), ey = step_exponent(h.y - l.y, 255.0f);
-    const uint32_t ez = step_exponent(h.z - l.z, 65535.0f);
+    const AxisQ ax = axis_setup(l.x, h.x), ay = axis_setup(l.y, h.y);
+    const uint32_t ez = step_exponent(h.z - l.z, HZ_QZ_MAX);
+    const float sz = __uint_as_float(ez << 23);
     NodeTmp n;
-    n.org[0] = l.x; n.org[1] = l.y; n.org[2] = l.z;
-    n.scale = ex | (ey << 8) | (ez << 16);
-    for (int k = 0; k < 4; k++) { n.link[k] = HZ_TMP_EMPTY; n.qxy[k] = 0x00ff00ffu; n.qz[k] = 0x0000ffffu; }
+    n.org[0] = ax.o; n.org[1] = ay.o; n.org[2] = l.z;
+    n.scale = ax.e | (ay.e << 8) | (ez << 16);
+    for (int k = 0; k < 4; k++) { n.link[k] = HZ_TMP_EMPTY; n.qxy[k] = HZ_QXY_EMPTY; n.qz[k] = HZ_QZ_EMPTY; }
     n.link[0] = ~0;
-    n.qxy[0] = 0u | (quant_hi(h.x, l.x, __uint_as_float(ex << 23), 255.0f) << 8)
-             | (quant_hi(h.y, l.y, __uint_as_float(ey << 23), 255.0f) << 24);
-    n.qz[0] = quant_hi(h.z, l.z, __uint_as_float(ez << 23), 65535.0f) << 16;
+    n.qxy[0] = axis_lo(ax, l.x) | (axis_hi(ax, h.x) << 8) | (axis_lo(ay, l.y) << 16) | (axis_hi(ay, h.y) << 24);
+    n.qz[0] = half_bits(quant_lo(l.z, l.z, sz, HZ_QZ_MAX)) | (half_bits(quant_hi(h.z, l.z, sz, HZ_QZ_MAX)) << 16);
     nodes[0] = n;
 }
 

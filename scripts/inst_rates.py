@@ -9,7 +9,10 @@ NAMES = ["v_fma_f32", "v_cvt_f32_ubyte0", "v_cvt_f32_u32_sdwa_word1", "v_perm_b3
          "v_add_f32", "v_sub_f32", "v_max_f32", "v_and_b32", "v_add_u32", "v_mov_b32", "v_cndmask_b32 (vcc never written)",
          "v_fmac_f32", "v_fma_mix_f32 (f16 hi-half source)", "v_min3_f32 three different sources", "v_pk_fma_f32 (2 FMAs)",
          "v_cvt_f32_f16", "v_cndmask + 3 fast-class instructions (per instruction)", "v_cndmask_b32_e64 (mask in s[10:11])",
-         "v_fma_f32 all sources in one VGPR bank (3 waves/SIMD: 144 VGPRs)", "v_fma_f32 sources in three banks (3 waves/SIMD)"]
+         "v_fma_f32 all sources in one VGPR bank (3 waves/SIMD: 144 VGPRs)", "v_fma_f32 sources in three banks (3 waves/SIMD)",
+         "v_fma_mix_f32 sources in one bank", "v_fma_mix_f32 sources in three banks", "v_perm_b32 sources in one bank",
+         "v_perm_b32 sources in three banks", "v_max3_f32 sources in one bank", "v_max3_f32 sources in three banks",
+         "v_max_f32 sources in one bank", "v_max_f32 sources in two banks"]
 import sys as _s
 REPS = 3
 L = _lib.lib()
