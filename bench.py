@@ -13,10 +13,14 @@ workgroups run on a draining GPU (a lane owns one cell for all 360 azimuths, ~50
 7 times (5.63 M cells/s against 6.06 M for the whole tile, same kernel, same box).  Inputs (scene blob, per-cell
 frames, mask, tilt) are resident in HBM before the timed region and outputs stay in HBM; the library is called
 through its C ABI with device pointers (slab-local output buffers, opts.hori_is_slab).
-N > 1 (torch.distributed.run, one rank per GPU, RCCL): weak scaling -- rank 0 builds the scene and
-broadcasts the blob over xGMI once (set-up, untimed, like the BVH build); rank r then takes steps
-r K ... r K + K - 1 of the same step sequence (with whole-tile steps: the same tile on every rank; no data-path
-collective); the SVF rows of every rank's last step are gathered on rank 0 inside the timed region.
+N > 1 (one rank per GPU over RCCL; `python bench.py --gpus N` starts the N ranks itself when it is not already running
+under torch.distributed.run, and fails loudly when the node has fewer than N GPUs): STRONG scaling of the same tile --
+rank 0 builds the scene and broadcasts it over xGMI once (set-up, untimed like the BVH build; `--bcast blob` sends the
+finished blob, `--bcast verts` the 12 V bytes of vertices and every rank rebuilds the LBVH), the inner rows are split
+into one contiguous slab per rank (dist.row_slabs through dist.sharded_rows: the grid-cell shard SURVEY 8e names), every
+rank traces its slab into its own resident horizon + SVF buffers (no data-path collective) and the SVF slabs are
+gathered on rank 0 inside the timed region.  N = 1 is the plain one-launch line above, so the N = 1, 2, 4, 8 values form
+one strong-scaling curve.  (`--scaling weak`: the old replica mode -- every rank computes the whole tile.)
 
 --workload c5 (BASELINE.json config 5, strong scaling): the 4 x 4 mosaic (14401 x 14401, 206 M cells),
 SVF-fused (the 298 GB horizon is never materialised), inner rows split by dist.row_slabs over WORLD_SIZE
@@ -63,7 +67,15 @@ def parse():
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--workload", choices=("c3", "c4", "c5"), default="c3")
+    ap.add_argument("--scaling", choices=("auto", "strong", "weak"), default="auto",
+                    help="c3 with several ranks: strong (default) = one row slab of the tile per rank; weak = every rank "
+                         "computes the whole tile (replicas)")
+    ap.add_argument("--bcast", choices=("blob", "verts"), default="blob",
+                    help="several ranks: broadcast the finished scene blob (vertices + LBVH), or only the 12 V bytes of "
+                         "vertices and rebuild the LBVH on every rank")
     ap.add_argument("--no-e2e", action="store_true", help="c3: skip the untimed NumPy-in / NumPy-out call of horizon_gridded")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="c3, one rank: skip the untimed extras (whole-tile binary_search / discrete_sampling, the curved tile, c4)")
     ap.add_argument("--suns", type=int, default=144, help="c4: sun positions per step")
     ap.add_argument("--refrac", type=int, default=0, help="c4: atmospheric refraction on (1) / off (0)")
     ap.add_argument("--which", choices=("shadow", "sw_dir_cor"), default="shadow", help="c4: output kind")
@@ -72,8 +84,8 @@ def parse():
                          "synthetic mosaic, 8 emulated ranks: 1.028 against 1.033 max/mean, less than the pre-pass costs)")
     ap.add_argument("--cost-samples", type=int, default=0, help="c5: probe rows of the cost pre-pass (0: max(16, 4 x ranks))")
     ap.add_argument("--emulate-ranks", type=int, default=0, help="c5, one GPU: time the slabs of an R-rank partition one by one")
-    ap.add_argument("--dump-svf-rows", default="", help="c5: comma separated inner-domain rows of the gathered SVF to save")
-    ap.add_argument("--dump-path", default="", help="c5: .npy file for --dump-svf-rows")
+    ap.add_argument("--dump-svf-rows", default="", help="sharded runs: comma separated inner-domain rows of the gathered SVF to save ('all': every row)")
+    ap.add_argument("--dump-path", default="", help="sharded runs: .npy file for --dump-svf-rows")
     ap.add_argument("--rows-per-step", type=int, default=0, help="inner-domain rows per step (0: the whole tile in one launch)")
     ap.add_argument("--tile", type=int, default=None, help="DEM size (3601 for c3, 14401 for c5)")
     ap.add_argument("--azim", type=int, default=360)
@@ -132,8 +144,35 @@ SHADOW_SETUP_WINST = (485.0, 1100.0)    # wave-level VALU instructions per 64 ce
 CLASS_MIX_DEFAULT = {"node_step": 0.44, "leaf_step": 0.88, "refill_and_loop_overhead": 0.62}   # fast-class share (ISA count)
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks (one per GPU) and pass their output
+    through; rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    import torch
+    backend = os.environ.get("HZ_DIST_BACKEND", "nccl")
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < 1:
+        raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
+    if have < args.gpus and backend != "gloo":
+        raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible on this node (RCCL needs one GPU per rank; "
+                         "HZ_DIST_BACKEND=gloo lets several ranks share a GPU for testing)" % (args.gpus, have))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -141,8 +180,11 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no HIP device visible)")
+    backend = os.environ.get("HZ_DIST_BACKEND", "nccl")
     # (several ranks may share a GPU when the multi-rank code path is exercised on a box with fewer GPUs than ranks:
     #  HZ_DIST_BACKEND=gloo, since RCCL refuses two ranks on one device)
+    if world > torch.cuda.device_count() and backend != "gloo":
+        raise SystemExit("bench.py: %d ranks but %d GPU(s) visible (one GPU per rank over RCCL)" % (world, torch.cuda.device_count()))
     local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     # HZ_FORCE_DIST=1 runs the multi-rank code path (RCCL broadcast of the scene, gather, all-reduce)
@@ -153,14 +195,17 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
-        backend = os.environ.get("HZ_DIST_BACKEND", "nccl")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda:%d" % local_rank))
         else:
             dist.init_process_group(backend)
+        world = dist.get_world_size()          # n_gpus of the line = the ranks the process group actually formed
     ctx = dict(args=args, world=world, rank=rank, local_rank=local_rank, use_dist=use_dist,
                dev="cuda:%d" % local_rank)
-    out = {"c3": run_c3, "c4": run_c4, "c5": run_c5}[args.workload](ctx)
+    strong_c3 = args.workload == "c3" and use_dist and args.scaling != "weak"
+    fn = {"c3": (lambda c: run_sharded(c, "c3")) if strong_c3 else run_c3, "c4": run_c4,
+          "c5": lambda c: run_sharded(c, "c5")}[args.workload]
+    out = fn(ctx)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -171,26 +216,52 @@ def main():
         except Exception:
             pass
         sys.stdout.flush()
+        if args.gpus != world:
+            out["config"]["gpus_flag"] = args.gpus        # the flag and the launcher disagreed: n_gpus is what ran
         print(json.dumps(out), flush=True)
 
 
 def make_scene(ctx, g, n):
-    """Rank 0 builds the scene; with several ranks the blob is broadcast once (RCCL over xGMI)."""
+    """Rank 0 builds the scene; with several ranks it is broadcast once (RCCL over xGMI): the finished blob straight out of
+    its allocation (`--bcast blob`), or the vertex array alone, after which every rank builds its own LBVH (`--bcast verts`:
+    12 V bytes instead of ~85 V on the links, one 0.02 - 0.2 s build per rank).  Returns (scene, stats of the build on rank 0,
+    wall seconds of the build on rank 0, wall seconds of broadcast [+ per-rank rebuild], bytes broadcast)."""
     import torch
     import torch.distributed as dist
     import horayzon_amd as hz
-    from horayzon_amd.dist import broadcast_scene
+    from horayzon_amd.dist import broadcast_scene, broadcast_blob
+    args = ctx["args"]
+    verts_mode = ctx["use_dist"] and args.bcast == "verts"
     t0 = time.time()
-    scene = hz.Scene.create(g["vert_grid"], n, n, device=ctx["local_rank"]) if ctx["rank"] == 0 else None   # g: rank 0 only
+    scene = None
+    if ctx["rank"] == 0 and not verts_mode:                                  # g: rank 0 only
+        scene = hz.Scene.create(g["vert_grid"], n, n, device=ctx["local_rank"])
     t_build = time.time() - t0
     scene_stats = scene.stats if scene is not None else None
-    t_bcast = 0.0
+    t_bcast, n_bytes = 0.0, 0
     if ctx["use_dist"]:
         torch.cuda.synchronize(); dist.barrier()
         t0 = time.time()
-        scene = broadcast_scene(scene, ctx["local_rank"], src=0)
+        if verts_mode:
+            gloo = dist.get_backend() == "gloo"
+            buf = None
+            if ctx["rank"] == 0:
+                buf = torch.from_numpy(g["vert_grid"]).view(torch.uint8)
+                buf = buf if gloo else buf.to(ctx["dev"])
+            buf = broadcast_blob(buf, buf.numel() if buf is not None else 0, "cpu" if gloo else ctx["dev"], src=0)
+            n_bytes = int(buf.numel())
+            tb = time.time()
+            scene = hz.Scene.create(buf, n, n, device=ctx["local_rank"])   # host (gloo) or device pointer: used in place
+            torch.cuda.synchronize()
+            if ctx["rank"] == 0:
+                scene_stats, t_build = scene.stats, time.time() - tb
+            del buf
+        else:
+            scene = broadcast_scene(scene, ctx["local_rank"], src=0)
+            n_bytes = int(scene.blob()[1])
         torch.cuda.synchronize(); dist.barrier()
         t_bcast = time.time() - t0
+    ctx["bcast_bytes"] = n_bytes
     return scene, scene_stats, t_build, t_bcast
 
 
@@ -304,7 +375,7 @@ def run_c3(ctx):
         "mray_per_s": rays_total / elapsed / 1e6,
         "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": 1e3 * elapsed / max(steps, 1),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": "weak" if (world > 1 or args.scaling == "weak") else "strong", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "c3: horizon_gridded guess_constant + fused SVF, %dx%d synthetic SRTM-like tile, "
                                "%d azimuths, dist_search %g km, %s"
@@ -312,7 +383,10 @@ def run_c3(ctx):
                                   "the whole inner domain (%d rows) per step, one launch" % in0 if n_slabs == 1 else
                                   "slabs of <= %d rows per step (%d slabs cover the tile)" % (rps, n_slabs)),
                    "rows_per_step": rps, "cells_per_step": cells_launch, "rays_per_cell_azimuth": rays_launch / max(cells_launch * A, 1),
-                   "parallelism": "weak scaling x%d: same step sequence, rank r starts at step r K; scene broadcast once" % world,
+                   "parallelism": ("one rank: the N = 1 point of the strong-scaling curve (N > 1: one row slab of this tile per rank)"
+                                   if world == 1 and args.scaling != "weak" else
+                                   "weak scaling x%d (--scaling weak, replicas): same step sequence, rank r starts at step r K; "
+                                   "scene broadcast once" % world),
                    "bvh_build_s": scene_stats["t_bvh_s"] if scene_stats else None,
                    "scene_bytes": int(blob_bytes), "scene_bcast_s": t_bcast, "scene_create_wall_s": t_build,
                    "load_imbalance_max_over_mean": imbalance, "near_prepass_ms_per_step": 1e3 * stats.t_near_s / max(steps, 1),
@@ -324,6 +398,12 @@ def run_c3(ctx):
                    "height_field": int(stats.height_field), "near_certificates_used": int(stats.near_used)},
         "roofline": roofline(args, stats, steps, cw, peaks, A, n, rps),
     }
+    if args.dump_path and args.dump_svf_rows == "all" and n_slabs == 1:
+        np.save(args.dump_path, d_svf.cpu().numpy())
+    if world == 1 and not args.no_extras and n_slabs == 1:
+        out["extras"] = c3_extras(ctx, L, scene, step_args=dict(d_norm=d_norm, d_north=d_north, d_mask=d_mask, d_tilt=d_tilt,
+                                                                 d_hori=d_hori, d_svf=d_svf, in0=in0, in1=in1, off=off, A=A, n=n),
+                                  peaks=peaks, g=g)
     if world == 1 and not args.no_e2e:
         # free the resident buffers of the timed region first: the drop-in call allocates its own
         del d_hori, d_svf, d_tilt, d_norm, d_north, d_mask
@@ -332,6 +412,129 @@ def run_c3(ctx):
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(g, args, A)
     return out
+
+
+def curved_tile_device(L, torch, n, off, dev_index, seed_elev):
+    """The CURVED variant of config 3 (examples/horizon/gridded_curved_DEM.py: lon / lat / elevation on the WGS84 ellipsoid
+    -> ECEF -> ENU; per-cell normal and north vectors are NOT axis aligned), prepared entirely on the device through the
+    library's input-side entry points (hz_lonlat2ecef ... hz_slope_plane_meth)."""
+    import horayzon_amd as hz
+    from horayzon_amd import _lib
+    dev = "cuda:%d" % dev_index
+    lon = 8.0 + np.arange(n) / 3600.0
+    lat = 47.0 - np.arange(n) / 3600.0
+    elev = torch.from_numpy(seed_elev).to(dev)
+    lon2 = torch.from_numpy(lon).to(dev)[None, :].expand(n, n).contiguous()
+    lat2 = torch.from_numpy(lat).to(dev)[:, None].expand(n, n).contiguous()
+    nn = n * n
+    f64 = lambda: torch.empty(nn, dtype=torch.float64, device=dev)
+    f32 = lambda *sh: torch.empty(sh, dtype=torch.float32, device=dev)
+    X, Y, Z = f64(), f64(), f64()
+    _lib.check(L.hz_lonlat2ecef(lon2.data_ptr(), lat2.data_ptr(), elev.data_ptr(), nn, 2, X.data_ptr(), Y.data_ptr(), Z.data_ptr(), dev_index))
+    lon_or, lat_or = float(lon.mean()), float(lat.mean())
+    xe, ye, ze = f32(n, n), f32(n, n), f32(n, n)
+    _lib.check(L.hz_ecef2enu(X.data_ptr(), Y.data_ptr(), Z.data_ptr(), nn, lon_or, lat_or, 2, xe.data_ptr(), ye.data_ptr(), ze.data_ptr(), dev_index))
+    vert_grid = hz.auxiliary.rearrange_pad_buffer(xe, ye, ze)
+    sl = (slice(off, n - off), slice(off, n - off))
+    in0 = n - 2 * off
+    lon_i, lat_i = lon2[sl].contiguous(), lat2[sl].contiguous()
+    Xi, Yi, Zi = (a.view(n, n)[sl].contiguous() for a in (X, Y, Z))
+    vn_e, vno_e, vec_norm, vec_north = f32(in0, in0, 3), f32(in0, in0, 3), f32(in0, in0, 3), f32(in0, in0, 3)
+    m = in0 * in0
+    _lib.check(L.hz_surf_norm(lon_i.data_ptr(), lat_i.data_ptr(), m, vn_e.data_ptr(), dev_index))
+    _lib.check(L.hz_north_dir(Xi.data_ptr(), Yi.data_ptr(), Zi.data_ptr(), vn_e.data_ptr(), m, 2, vno_e.data_ptr(), dev_index))
+    _lib.check(L.hz_ecef2enu_vector(vn_e.data_ptr(), m, lon_or, lat_or, 2, vec_norm.data_ptr(), dev_index))
+    _lib.check(L.hz_ecef2enu_vector(vno_e.data_ptr(), m, lon_or, lat_or, 2, vec_north.data_ptr(), dev_index))
+    tilt_full = f32(n, n, 3)
+    _lib.check(L.hz_slope_plane_meth(xe.data_ptr(), ye.data_ptr(), ze.data_ptr(), n, n, None, 0, tilt_full.data_ptr(), dev_index))
+    vec_tilt = tilt_full[sl].contiguous()
+    return vert_grid, vec_norm, vec_north, vec_tilt
+
+
+def c3_extras(ctx, L, scene, step_args, peaks, g):
+    """UNTIMED additions to the one driver-run line (none of this is part of `value`): the other two
+    search algorithms over the WHOLE tile (horizon_comp.cpp:302-381), the curved variant of the tile with device-prepared
+    frames (SURVEY 8d names both variants) and the config-4 step (shadow masks of 144 sun positions, with and without
+    atmospheric refraction).  Each with its own counter pass on a slab where a VALU figure is given."""
+    import torch
+    import horayzon_amd as hz
+    from horayzon_amd import _lib, synth
+    args, dev = ctx["args"], ctx["dev"]
+    a = step_args
+    in0, in1, off, A, n = a["in0"], a["in1"], a["off"], a["A"], a["n"]
+    res = {"note": "untimed extras, outside `value`; same scene, same resident buffers, one launch over the whole inner domain each"}
+
+    def whole_tile(sc, norm, north, tilt, alg, rows=None, count=False):
+        opts = _lib.hz_opts()
+        opts.device = ctx["local_rank"]; opts.top_nodes = -1; opts.regroup = -1
+        opts.vec_tilt = tilt.data_ptr(); opts.hori_is_slab = 1
+        rb, re = rows if rows else (0, in0)
+        opts.row_begin, opts.row_end = rb, re
+        opts.count_work = int(count)
+        opts.svf = a["d_svf"].data_ptr() + 4 * rb * in1
+        st = _lib.hz_stats()
+        _lib.check(L.hz_horizon_gridded_scene(sc._h, norm.data_ptr(), north.data_ptr(), off, off, a["d_hori"].data_ptr(), in0, in1, A,
+                                              args.dist_search, 0.25, alg.encode(), -15.0, a["d_mask"].data_ptr(), 0.0, 0.01,
+                                              C.byref(opts), C.byref(st)))
+        return st
+
+    def line(st, cw):
+        d = {"cells_per_s": st.num_cells / st.t_kernel_s, "kernel_ms": 1e3 * st.t_kernel_s,
+             "cells_per_s_with_prepass_and_svf": st.num_cells / (st.t_kernel_s + st.t_near_s + st.t_svf_s),
+             "rays_per_cell_azimuth": st.num_rays / max(st.num_cells * A, 1), "mray_per_s": st.num_rays / st.t_kernel_s / 1e6,
+             "guard_events": int(st.guard_events), "near_certificates_used": int(st.near_used),
+             "stack_redo_blocks": int(st.stack_redo_blocks)}
+        if cw is not None:
+            r = roofline(args, st, 1, cw, peaks, A, n, in0)
+            d.update({k: r.get(k) for k in ("frac", "frac_uniform_4_cycle", "nodes_per_ray", "tris_per_ray",
+                                            "lane_utilisation_node_leaf_steps", "frac_8d_hbm_model")})
+            d["frac_note"] = ("VALU-busy share as for the headline kernel; wave-iteration counts from a counting launch over the "
+                              "middle 256 rows, per-iteration instruction constants of the guess_constant calibration")
+        return d
+
+    mid = (in0 // 2 - 128, in0 // 2 + 128) if in0 > 512 else None
+    for alg in ("binary_search", "discrete_sampling"):           # horizon_comp.cpp:302-381
+        cw = whole_tile(scene, a["d_norm"], a["d_north"], a["d_tilt"], alg, rows=mid, count=True) if not args.no_count else None
+        st = whole_tile(scene, a["d_norm"], a["d_north"], a["d_tilt"], alg)
+        res[alg] = line(st, cw)
+    # ---- curved variant: frames that are not axis aligned, everything prepared on the device --------------------------
+    t0 = time.perf_counter()
+    vert_grid, c_norm, c_north, c_tilt = curved_tile_device(L, torch, n, off, ctx["local_rank"], np.ascontiguousarray(g["z"], np.float32))
+    torch.cuda.synchronize()
+    t_prep = time.perf_counter() - t0
+    sc_c = hz.Scene.create(vert_grid, n, n, device=ctx["local_rank"])
+    cw = whole_tile(sc_c, c_norm, c_north, c_tilt, "guess_constant", rows=mid, count=True) if not args.no_count else None
+    whole_tile(sc_c, c_norm, c_north, c_tilt, "guess_constant")
+    st = whole_tile(sc_c, c_norm, c_north, c_tilt, "guess_constant")
+    res["curved_c3_guess_constant"] = dict(line(st, cw), input_prep_on_device_s=t_prep, bvh_build_s=sc_c.stats["t_bvh_s"],
+                                           height_field=int(st.height_field),
+                                           note="3601^2 one-arc-second tile on the WGS84 ellipsoid (lon 8..9 E, lat 46..47 N, the "
+                                                "same synthetic elevations), ENU frame at the tile centre; vec_norm / vec_north / "
+                                                "vec_tilt from hz_surf_norm / hz_north_dir / hz_slope_plane_meth on the device")
+    del sc_c, vert_grid, c_norm, c_north, c_tilt
+    # ---- config 4 on the same scene -------------------------------------------------------------------------------------
+    S = args.suns
+    vec_tilt_h, enl = synth.tilt_from_planar_dem(g["x"], g["y"], g["z"], off)
+    elev = np.ascontiguousarray(g["z"][off:off + in0, off:off + in1])
+    suns, _, _ = synth.sun_positions(num=S)
+    c4 = {}
+    for refrac in (False, True):
+        terrain = hz.shadow.Terrain(device=ctx["local_rank"])
+        terrain.initialise(g["vert_grid"], n, n, off, off, vec_tilt_h, g["vec_norm"], enl, elev, np.ones((in0, in1), np.uint8),
+                           refrac_cor=refrac, scene=scene)
+        for which, fn, dt in (("shadow", terrain.shadow_batch, torch.uint8), ("sw_dir_cor", terrain.sw_dir_cor_batch, torch.float32)):
+            o = torch.empty((S, in0, in1), dtype=dt, device=dev)
+            fn(suns, o)
+            fn(suns, o)
+            ks = terrain.last_stats["t_kernel_s"]
+            c4["%s_refrac_%d" % (which, int(refrac))] = {"ms_per_sun_position": 1e3 * ks / S, "kernel_ms_per_step": 1e3 * ks,
+                                                        "cells_per_s": S * in0 * in1 / ks,
+                                                        "mray_per_s": terrain.last_stats["num_rays"] / ks / 1e6}
+            del o
+        del terrain
+    c4["note"] = "Terrain.shadow_batch / sw_dir_cor_batch over %d diurnal sun positions in one launch, outputs resident in HBM" % S
+    res["c4"] = c4
+    return res
 
 
 def e2e_numpy_call(g, vec_tilt, args, A):
@@ -446,6 +649,13 @@ def roofline(args, stats, steps, cw, peaks, A, n, rps):
                       "alg_frac_of_peak_cache_served": alg / HBM_PEAK_GBS if alg else None,
                       "hbm_counter_gbs": traffic / k_launch_s / 1e9 if traffic else None,
                       "hbm_frac": traffic / k_launch_s / 1e9 / HBM_PEAK_GBS if traffic else None}})
+    # SURVEY 8(d)'s formula (algorithmic bytes / kernel time / HBM peak) as a field of its own: ~99.9 % of those bytes are
+    # node re-reads served by L1 / L2, so the figure can exceed 1 and is NOT a bound; `frac` (VALU-busy share) is the bound
+    r["frac_8d_hbm_model"] = alg / HBM_PEAK_GBS if alg else None
+    r["frac_8d_hbm_model_not_a_bound"] = True
+    r["frac_is"] = ("lower bound of the VALU-busy share of the launch (SIMD cycles its instructions need at conflict-free "
+                    "issue rates / SIMD cycles of the launch); frac_8d_hbm_model answers SURVEY 8(d)'s byte formula, "
+                    "hbm.hbm_frac is the counter-measured HBM utilisation")
     if "bound" not in r:      # no counter pass / no calibration kernels: only the HBM view is available
         r.update({"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                   "frac": alg / HBM_PEAK_GBS if alg else None})
@@ -453,7 +663,7 @@ def roofline(args, stats, steps, cw, peaks, A, n, rps):
 
 
 # ------------------------------------------------------------------------------------------------
-# config 5: the 14401^2 mosaic, SVF-fused, row-sharded over the ranks
+# row-sharded jobs: config 3 on N > 1 ranks (strong scaling of the headline tile) and config 5 (the 14401^2 mosaic)
 # ------------------------------------------------------------------------------------------------
 def _tilt_rows_device(verts, off, in1, b, e):
     """vec_tilt of inner-domain rows [b, e) from the vertex array inside the blob, on the device: the same centred
@@ -470,20 +680,24 @@ def _tilt_rows_device(verts, off, in1, b, e):
     return t.contiguous()
 
 
-def run_c5(ctx):
+def run_sharded(ctx, kind):
+    """Row-sharded job over the ranks: `kind` "c5" = the 14401^2 mosaic, SVF-fused, horizon never
+    materialised; "c3" = the 3601^2 headline tile with the horizon array AND the SVF written to HBM (each rank into its own
+    resident slab buffers) -- the N > 1 points of the c3 strong-scaling curve.  One step = one pass over the whole inner
+    domain: dist.sharded_rows (slabs -> compute -> timing exchange -> gather of the SVF on rank 0)."""
     import torch
     import torch.distributed as dist
     from horayzon_amd import _lib, synth
     from horayzon_amd import dist as _dist_mod
-    from horayzon_amd.dist import (sharded_rows, row_slabs, estimate_row_cost, predicted_imbalance,
-                                   device_bytes_tensor)
+    from horayzon_amd.dist import sharded_rows, row_slabs, estimate_row_cost, predicted_imbalance
     args, rank, world, dev = ctx["args"], ctx["rank"], ctx["world"], ctx["dev"]
     L = _lib.lib()
-    n, off, A = args.tile or 14401, 16, args.azim
-    steps = args.steps if args.steps is not None else 1
+    c3 = kind == "c3"
+    n, off, A = args.tile or (3601 if c3 else 14401), 16, args.azim
+    steps = args.steps if args.steps is not None else (3 if c3 else 1)
     warmup = args.warmup if args.warmup is not None else 1
     in0 = in1 = n - 2 * off
-    # only the building rank synthesises the mosaic; everybody else receives vertices + LBVH in the one broadcast
+    # only the building rank synthesises the DEM; everybody else receives vertices (+ LBVH) in the one broadcast
     g = synth.fractal_tile(n=n, offset=off) if rank == 0 else None
     scene, scene_stats, t_build, t_bcast = make_scene(ctx, g, n)
     del g
@@ -491,29 +705,40 @@ def run_c5(ctx):
     vptr, d0, d1, height_field = scene.vertices()
     verts = _dist_mod.device_bytes_or_copy(vptr, d0 * d1 * 12, ctx["local_rank"], owner=scene)[0].view(torch.float32).view(d0, d1, 3)
     stats = _lib.hz_stats()
+    cache = {}            # c3: the slab's inputs and output buffers stay resident across the steps (as in the N = 1 line)
 
     def slab_inputs(b, e):
         """Per-cell inputs of rows [b, e) only, made on this rank's GPU (planar frames; tilt from the blob's vertices)."""
+        if c3 and cache.get("rows") == (b, e):
+            return cache["inputs"]
         norm = torch.zeros((e - b, in1, 3), dtype=torch.float32, device=dev); norm[..., 2] = 1.0
         north = torch.zeros((e - b, in1, 3), dtype=torch.float32, device=dev); north[..., 1] = 1.0
         mask = torch.ones((e - b, in1), dtype=torch.uint8, device=dev)
-        return norm, north, mask, _tilt_rows_device(verts, off, in1, b, e)
+        res = (norm, north, mask, _tilt_rows_device(verts, off, in1, b, e))
+        if c3:
+            cache["rows"], cache["inputs"] = (b, e), res
+            cache["hori"] = torch.empty((e - b, in1, A), dtype=torch.float32, device=dev)
+            cache["svf"] = torch.empty((e - b, in1), dtype=torch.float32, device=dev)
+        return res
 
-    def run_slab(b, e, st, azim=A, count=False):
-        svf = torch.full((max(e - b, 0), in1), float("nan"), dtype=torch.float32, device=dev)
+    def run_slab(b, e, st, azim=A, count=False, probe=False):
         if e <= b:
-            return svf
+            return torch.full((0, in1), float("nan"), dtype=torch.float32, device=dev)
         norm, north, mask, tilt = slab_inputs(b, e)
+        materialise = c3 and not probe and cache.get("rows") == (b, e)
+        svf = cache["svf"] if materialise else torch.empty((e - b, in1), dtype=torch.float32, device=dev)
+        svf.fill_(float("nan"))
         opts = _lib.hz_opts()
         opts.device = ctx["local_rank"]
         opts.top_nodes = -1; opts.regroup = -1
         opts.vec_tilt = tilt.data_ptr()
         opts.svf = svf.data_ptr()
         opts.hori_is_slab = 1; opts.inputs_are_slab = 1
-        opts.skip_hori = 1                       # the horizon lives in a bounded device buffer, chunk by chunk
+        opts.skip_hori = 0 if materialise else 1     # c5 / probes: the horizon lives in a bounded device buffer, chunk by chunk
         opts.count_work = int(count)
         opts.row_begin, opts.row_end = b, e
-        rc = L.hz_horizon_gridded_scene(scene._h, norm.data_ptr(), north.data_ptr(), off, off, None, in0, in1, azim,
+        rc = L.hz_horizon_gridded_scene(scene._h, norm.data_ptr(), north.data_ptr(), off, off,
+                                        cache["hori"].data_ptr() if materialise else None, in0, in1, azim,
                                         args.dist_search, 0.25, b"guess_constant", -15.0, mask.data_ptr(), 0.0,
                                         0.01, C.byref(opts), C.byref(st))
         _lib.check(rc)
@@ -534,7 +759,9 @@ def run_c5(ctx):
         st = _lib.hz_stats()
         rb = min(row // 16 * 16, max(in0 - 16, 0))
         re = min(rb + 16, in0)
-        run_slab(rb, re, st, azim=a_probe, count=True)
+        saved = dict(cache); cache.clear()             # probe rows are not the slab: do not disturb the resident buffers
+        run_slab(rb, re, st, azim=a_probe, count=True, probe=True)
+        cache.clear(); cache.update(saved)
         probe_s[0] += time.perf_counter() - t0
         m = VALU_MODEL_DEFAULT
         w = m["node_iter"] * st.wave_node_iters + m["leaf_iter"] * st.wave_leaf_iters + m["refill_iter"] * st.wave_refills
@@ -542,17 +769,34 @@ def run_c5(ctx):
 
     n_samples = args.cost_samples or max(32, 8 * max(world, args.emulate_ranks))
 
-    slab0 = row_slabs(in0, world)[rank]
-    for w in range(warmup):      # a short slab of this rank's rows: clocks, allocator
-        run_slab(slab0[0], min(slab0[0] + 64, slab0[1]), _lib.hz_stats())
+    cost, t_cost = None, 0.0
+    balance_cost = args.balance == "cost" and (world > 1 or os.environ.get("HZ_FORCE_COST"))
+    if c3 and balance_cost:      # c3: the partition is part of the set-up (the resident slab buffers depend on it)
+        tc0 = time.perf_counter()
+        cost = estimate_row_cost(in0, probe, samples=n_samples)
+        t_cost = time.perf_counter() - tc0
+    slab0 = row_slabs(in0, world, cost)[rank]
+    # counter pass and machine calibration for the roofline (rank 0, untimed): c3 only
+    cw = peaks = None
+    if c3:
+        if slab0[1] > slab0[0]:
+            slab_inputs(*slab0)
+        if rank == 0 and not args.no_count and slab0[1] > slab0[0]:
+            cw = _lib.hz_stats()
+            run_slab(slab0[0], slab0[1], cw, count=True)
+        if rank == 0 and not args.no_peaks:
+            peaks = machine_peaks(L, ctx["local_rank"])
+            peaks["class_rates"] = inst_class_rates(L, ctx["local_rank"])
+    for w in range(warmup):      # c3: one pass over this rank's slab; c5: a short slab of its rows (clocks, allocator)
+        run_slab(slab0[0], slab0[1] if c3 else min(slab0[0] + 64, slab0[1]), _lib.hz_stats())
     if args.emulate_ranks > 1:
         return emulate_ranks(ctx, in0, in1, run_slab, probe, n_samples, blob_bytes)
     barrier(ctx)
     t0 = time.perf_counter()
-    res, cost, t_cost = None, None, 0.0
+    res = None
     for s in range(steps):
         probe_s[0] = 0.0
-        if args.balance == "cost" and (world > 1 or os.environ.get("HZ_FORCE_COST")):
+        if balance_cost and not c3:
             tc0 = time.perf_counter()
             cost = estimate_row_cost(in0, probe, samples=n_samples)
             t_cost = time.perf_counter() - tc0
@@ -571,35 +815,61 @@ def run_c5(ctx):
     if res is not None and res["full"] is not None:
         svf_ok = bool(torch.isfinite(res["full"]).all().item()) and tuple(res["full"].shape) == (in0, in1)
         if args.dump_svf_rows and args.dump_path:
-            rows = [int(r) for r in args.dump_svf_rows.split(",")]
-            np.save(args.dump_path, res["full"][rows].cpu().numpy())
+            if args.dump_svf_rows == "all":
+                np.save(args.dump_path, res["full"].cpu().numpy())
+            else:
+                rows = [int(r) for r in args.dump_svf_rows.split(",")]
+                np.save(args.dump_path, res["full"][rows].cpu().numpy())
+    step_s = elapsed / max(steps, 1)
+    config = {
+        "parallelism": "strong scaling: row slabs over %d ranks (dist.row_slabs, balanced by %s), scene broadcast once (%s), "
+                       "slab-local inputs made on each rank's GPU, %sSVF gathered on rank 0"
+                       % (world, "sampled cost" if cost is not None else "cell count",
+                          "vertices only, LBVH rebuilt per rank" if args.bcast == "verts" and ctx["use_dist"] else
+                          "out of the blob allocation",
+                          "horizon written by every rank into its own resident slab, " if c3 else ""),
+        "slabs": res["slabs"] if res else None, "t_ranks_s": res["t_ranks"] if res else None,
+        "load_imbalance_max_over_mean": res["imbalance"] if res else None,
+        "load_imbalance_predicted": res["imbalance_predicted"] if res else None,
+        "load_imbalance_predicted_if_balanced_by_cells":
+            predicted_imbalance(row_slabs(in0, world), cost) if cost is not None else None,
+        "cost_prepass_s": t_cost, "cost_prepass_probe_rows": n_samples if cost is not None else 0,
+        "cost_prepass_probe_azimuths": a_probe,
+        "bvh_build_s": scene_stats["t_bvh_s"] if scene_stats else None, "scene_bytes": int(blob_bytes),
+        "scene_bcast": args.bcast if ctx["use_dist"] else None, "scene_bcast_bytes": int(ctx.get("bcast_bytes", 0)),
+        "scene_bcast_s": t_bcast, "scene_bcast_zero_copy": _dist_mod.last_broadcast_zero_copy, "scene_create_wall_s": t_build,
+        # the job as a user would pay for it once: scene broadcast (+ per-rank rebuild with --bcast verts) + one step
+        "job_s_incl_bcast": t_bcast + step_s,
+        "cells_per_s_incl_bcast": cells_total / max(steps, 1) / (t_bcast + step_s),
+        "kernel_s_rank0": stats.t_kernel_s,
+        "svf_kernel_s_rank0": stats.t_svf_s, "near_prepass_s_rank0": stats.t_near_s,
+        "stack_fallbacks_rank0": int(stats.stack_fallbacks), "stack_redo_blocks_rank0": int(stats.stack_redo_blocks),
+        "guard_events_rank0": int(stats.guard_events), "guard_cells_rank0": int(stats.guard_cells),
+        "height_field": int(height_field), "gathered_svf_finite": svf_ok}
+    if c3:
+        my_rows = slab0[1] - slab0[0]
+        config["workload"] = ("c3: horizon_gridded guess_constant + fused SVF, %dx%d synthetic SRTM-like tile, %d azimuths, "
+                              "dist_search %g km, the whole inner domain (%d rows) per step, split into %d row slab(s)"
+                              % (n, n, A, args.dist_search, in0, world))
+        config["cells_per_step"] = cells_total / max(steps, 1)
+        config["rays_per_cell_azimuth"] = rays_total / max(cells_total * A, 1)
+        roof = roofline(args, stats, steps, cw, peaks, A, n, my_rows)
+        roof["note"] = "rank 0's slab (%d rows); the kernel's N = 1 roofline is the plain `bench.py` line" % my_rows
+        metric = "grid_cells_per_s (horizon_gridded, 360 azimuths, 3601^2 SRTM-like tile)"
+    else:
+        config["workload"] = ("c5: horizon_gridded guess_constant, SVF-fused (horizon never materialised), %dx%d synthetic "
+                              "mosaic, %d azimuths, dist_search %g km; one step = the whole inner domain (%d x %d cells)"
+                              % (n, n, A, args.dist_search, in0, in1))
+        roof = {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None,
+                "traffic": None, "note": "see the c3 line: same kernel; c5 reports scaling, not the kernel roofline"}
+        metric = "grid_cells_per_s (horizon_gridded + SVF, 360 azimuths, 4x4 mosaic of 3601^2 SRTM-like tiles)"
     return {
-        "metric": "grid_cells_per_s (horizon_gridded + SVF, 360 azimuths, 4x4 mosaic of 3601^2 SRTM-like tiles)",
+        "metric": metric,
         "value": cells_total / elapsed, "unit": "cells/s", "mray_per_s": rays_total / elapsed / 1e6,
-        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / max(steps, 1),
+        "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * step_s,
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "c5: horizon_gridded guess_constant, SVF-fused (horizon never materialised), %dx%d synthetic "
-                               "mosaic, %d azimuths, dist_search %g km; one step = the whole inner domain (%d x %d cells)"
-                               % (n, n, A, args.dist_search, in0, in1),
-                   "parallelism": "row slabs over %d ranks (dist.row_slabs, balanced by %s), scene broadcast once out of "
-                                  "the blob allocation, slab-local inputs made on each rank's GPU, SVF gathered on rank 0"
-                                  % (world, "sampled cost" if cost is not None else "cell count"),
-                   "slabs": res["slabs"] if res else None, "t_ranks_s": res["t_ranks"] if res else None,
-                   "load_imbalance_max_over_mean": res["imbalance"] if res else None,
-                   "load_imbalance_predicted": res["imbalance_predicted"] if res else None,
-                   "load_imbalance_predicted_if_balanced_by_cells":
-                       predicted_imbalance(row_slabs(in0, world), cost) if cost is not None else None,
-                   "cost_prepass_s": t_cost, "cost_prepass_probe_rows": n_samples if cost is not None else 0,
-                   "cost_prepass_probe_azimuths": a_probe,
-                   "bvh_build_s": scene_stats["t_bvh_s"] if scene_stats else None, "scene_bytes": int(blob_bytes),
-                   "scene_bcast_s": t_bcast, "scene_bcast_zero_copy": _dist_mod.last_broadcast_zero_copy, "scene_create_wall_s": t_build,
-                   "kernel_s_rank0": stats.t_kernel_s,
-                   "svf_kernel_s_rank0": stats.t_svf_s, "near_prepass_s_rank0": stats.t_near_s,
-                   "stack_fallbacks_rank0": int(stats.stack_fallbacks), "stack_redo_blocks_rank0": int(stats.stack_redo_blocks),
-                   "guard_events_rank0": int(stats.guard_events), "guard_cells_rank0": int(stats.guard_cells),
-                   "height_field": int(height_field), "gathered_svf_finite": svf_ok},
-        "roofline": {"bound": "valu_issue", "achieved": None, "peak": None, "unit": "G wave-instructions/s", "frac": None,
-                     "traffic": None, "note": "see the c3 line: same kernel; c5 reports scaling, not the kernel roofline"},
+        "config": {"workload": config.pop("workload"), **config},
+        "roofline": roof,
     }
 
 

@@ -22,8 +22,8 @@ def _run(port, *args):
     return json.loads(p.stdout.strip().splitlines()[-1])          # the JSON line is the last line of stdout
 
 
-def test_config3_weak_scaling_path_with_two_ranks():
-    d = _run(29621, "--tile", "601", "--azim", "72", "--steps", "2", "--warmup", "1")
+def test_config3_weak_replica_mode_with_two_ranks():
+    d = _run(29621, "--tile", "601", "--azim", "72", "--steps", "2", "--warmup", "1", "--scaling", "weak")
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     cells = 569 * 569
     assert d["config"]["cells_per_step"] == cells
@@ -31,6 +31,74 @@ def test_config3_weak_scaling_path_with_two_ranks():
     assert abs(d["value"] - 2 * 2 * cells / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
     assert d["config"]["scene_bcast_s"] > 0 and d["config"]["load_imbalance_max_over_mean"] >= 1.0
     assert d["roofline"]["bound"] in ("valu_issue", "hbm") and d["roofline"]["kernel_ms_per_launch"] > 0
+
+
+def _plain(tmp_path, name, *args, gpus=1, backend="gloo"):
+    """`python bench.py --gpus N ...` exactly as the driver types it: no torchrun, no rendezvous variables."""
+    dump = str(tmp_path / (name + ".npy"))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["HZ_DIST_BACKEND"] = backend
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--tile", "601", "--azim", "72",
+           "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-e2e", "--dump-svf-rows", "all", "--dump-path", dump, *args]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    return p, dump
+
+
+def test_plain_bench_gpus_2_starts_two_ranks_and_shards_the_tile(tmp_path):
+    """`python bench.py --gpus 2` (no torchrun) must itself start 2 ranks, run the STRONG-scaling row
+    shard of the headline tile through dist.sharded_rows and gather the same SVF a single rank computes."""
+    np = pytest.importorskip("numpy")
+    p, dump2 = _plain(tmp_path, "two", gpus=2)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 2 and d["value"] > 0
+    c = d["config"]
+    sl = c["slabs"]
+    assert len(sl) == 2 and sl[0][0] == 0 and sl[0][1] == sl[1][0] and sl[1][1] == 569 and 0 < sl[0][1] < 569   # disjoint, covering
+    cells = 569 * 569
+    assert c["cells_per_step"] == cells and abs(d["value"] - cells / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert c["gathered_svf_finite"] is True and len(c["t_ranks_s"]) == 2
+    assert c["job_s_incl_bcast"] >= d["ms_per_step"] * 1e-3 and c["scene_bcast"] == "blob" and c["scene_bcast_bytes"] == c["scene_bytes"]
+    assert d["roofline"]["kernel_ms_per_launch"] > 0
+    # one rank through the same sharded code path (HZ_FORCE_DIST) and the plain N = 1 line: the same SVF, bit for bit
+    env1 = dict(os.environ, HZ_FORCE_DIST="1", HZ_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29626")
+    dump1 = str(tmp_path / "one.npy")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--tile", "601", "--azim", "72", "--steps", "1", "--warmup", "0",
+           "--no-cpu-baseline", "--no-e2e", "--no-count", "--no-peaks", "--dump-svf-rows", "all", "--dump-path", dump1]
+    q = subprocess.run(cmd, cwd=ROOT, env=env1, capture_output=True, text=True, timeout=600)
+    assert q.returncode == 0, q.stderr[-3000:]
+    d1 = json.loads(q.stdout.strip().splitlines()[-1])
+    assert d1["n_gpus"] == 1 and d1["scaling"] == "strong" and d1["config"]["slabs"] == [[0, 569]]
+    a, b = np.load(dump2), np.load(dump1)
+    assert a.shape == (569, 569) and np.isfinite(a).all() and np.array_equal(a, b)
+    # ... and the plain N = 1 line (one launch over the whole tile, no process group)
+    r, dump0 = _plain(tmp_path, "plain", "--no-count", "--no-peaks", gpus=1)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d0 = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d0["n_gpus"] == 1 and d0["scaling"] == "strong" and d0["config"]["cells_per_step"] == cells
+    assert np.array_equal(a, np.load(dump0))
+
+
+def test_plain_bench_gpus_2_broadcasting_vertices_only(tmp_path):
+    """--bcast verts: 12 V bytes on the links, every rank rebuilds the LBVH; same SVF as the blob broadcast."""
+    np = pytest.importorskip("numpy")
+    p, dump_v = _plain(tmp_path, "verts", "--bcast", "verts", "--no-count", "--no-peaks", gpus=2)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and c["scene_bcast"] == "verts"
+    assert 12 * 601 * 601 <= c["scene_bcast_bytes"] < 12 * 601 * 601 + 256 and c["scene_bcast_bytes"] < c["scene_bytes"] / 4
+    q, dump_b = _plain(tmp_path, "blob", "--no-count", "--no-peaks", gpus=2)
+    assert q.returncode == 0, q.stderr[-3000:]
+    assert np.array_equal(np.load(dump_v), np.load(dump_b))
+
+
+def test_plain_bench_refuses_more_ranks_than_gpus():
+    """RCCL needs one GPU per rank: `--gpus 9` on this box must fail loudly, not print an n_gpus = 1 line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HZ_DIST_BACKEND")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "9", "--tile", "601"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "GPU(s) visible" in (p.stderr + p.stdout) and "\"n_gpus\"" not in p.stdout
 
 
 def test_config5_row_sharding_with_two_ranks():
