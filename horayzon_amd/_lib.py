@@ -43,7 +43,7 @@ class hz_stats(C.Structure):
                 ("t_svf_s", C.c_double), ("stack_fallbacks", C.c_uint64),
                 ("rays_shortened", C.c_uint64), ("near_violations", C.c_uint64), ("t_near_s", C.c_double),
                 ("stack_redo_blocks", C.c_uint64), ("guard_cells", C.c_uint64),
-                ("height_field", C.c_int32), ("near_used", C.c_int32)]
+                ("height_field", C.c_int32), ("near_used", C.c_int32), ("near_verified", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -51,7 +51,7 @@ class hz_stats(C.Structure):
 
 # every symbol include/horayzon_hip.h declares (tests check that all are exported)
 SYMBOLS = (
-    "hz_last_error", "hz_abi_struct_sizes", "hz_device_count", "hz_device_info",
+    "hz_last_error", "hz_abi_struct_sizes", "hz_abi_version", "hz_device_count", "hz_device_info",
     "hz_scene_create", "hz_scene_blob", "hz_scene_vertices", "hz_scene_adopt", "hz_scene_destroy",
     "hz_horizon_gridded", "hz_horizon_gridded_scene", "hz_horizon_locations",
     "hz_horizon_locations_scene", "hz_horizon_tables",

@@ -207,6 +207,8 @@ struct Terrain {
     int refrac = 0;
     int count_work = 0;                       // hz_terrain_count_work
     unsigned long long *counters = nullptr;   // device u64[16]
+    float *sun_dev = nullptr;                 // persistent device copy of the sun positions of a call (grown on demand: the
+    size_t sun_cap = 0;                       //   drop-in API is called once per time step -- no hipMalloc / hipFree per call)
     hipStream_t stream = nullptr;
     bool initialised = false;
 };
@@ -222,6 +224,7 @@ static void terrain_release_arrays(Terrain *t) {
     t->own_tilt = t->own_norm = t->own_enl = t->own_elev = t->own_mask = false;
     // the counters live on the terrain's current GPU; a re-initialisation may move the terrain to another one
     if (t->counters) { (void)hipFree(t->counters); t->counters = nullptr; }
+    if (t->sun_dev) { (void)hipFree(t->sun_dev); t->sun_dev = nullptr; t->sun_cap = 0; }
     if (t->owns_scene && t->scene) scene_free(t->scene);
     t->scene = nullptr; t->owns_scene = false; t->initialised = false;
 }
@@ -240,11 +243,18 @@ static int persist(const void *src, size_t bytes, hipStream_t st, void **dst, bo
 // runtime (copy kernels on the CUs, host-blocking, 16 GB/s into untouched pages -- scripts/d2h_probe.py) and slows the
 // traversal kernel it is meant to hide behind.  HostPinner page-locks the caller's slab region by region (one region per
 // chunk of rows) on a helper thread, ahead of the copies: 45 ms per GB, done while the first chunks are traced; the copies
-// are then plain DMA (57 GB/s, no CU time).  Regions are page aligned and disjoint; the last bytes of chunk k may lie in
-// region k + 1, so a copy waits for that one too.  If page locking fails (memlock limit, memory that is already
-// registered) the copies simply stay pageable.
+// are then plain DMA (57 GB/s, no CU time).
+// Only pages that lie WHOLLY inside the slab are ever registered (the first region starts at the first page boundary at or
+// after the slab's first byte, the last one ends at the last boundary at or before its end): a neighbouring slab of the
+// same array -- horizon.py's devices=[...] path runs one call per GPU on adjacent slabs of one NumPy array -- never sees one
+// of its pages registered or unregistered by somebody else.  The unaligned head and tail (< 4096 B each) go as pageable
+// copies of their own.  Regions are page aligned and disjoint; a copy is cut at every region boundary it contains (a copy
+// must not straddle two separately registered ranges, nor a registered and a pageable one) and waits for every region it
+// touches.  If page locking fails (memlock limit, memory that is already registered) the remaining regions stay pageable.
+// Outputs below 8 MiB are not pinned at all: the thread and the registration cost more than they save.
 struct HostPinner {
-    std::vector<std::pair<char *, size_t>> regions;
+    std::vector<std::pair<char *, size_t>> regions;      // what is (still) registered: the worker zeroes a size on failure
+    std::vector<std::pair<char *, size_t>> planned;      // the same list as laid out by start()
     std::atomic<int> done{0};
     std::atomic<bool> failed{false};
     std::thread worker;
@@ -252,14 +262,20 @@ struct HostPinner {
     void start(int dev, char *base, const std::vector<size_t> &chunk_bytes) {
         device = dev;
         const uintptr_t page = 4096;
-        uintptr_t lo = reinterpret_cast<uintptr_t>(base) & ~(page - 1);
-        uintptr_t cur = reinterpret_cast<uintptr_t>(base);
+        size_t total = 0;
+        for (size_t b : chunk_bytes) total += b;
+        if (total < ((size_t)8 << 20)) return;
+        const uintptr_t first = reinterpret_cast<uintptr_t>(base);
+        const uintptr_t last_page = (first + total) & ~(page - 1);          // end of the last whole page inside the slab
+        uintptr_t lo = (first + page - 1) & ~(page - 1);                    // first whole page inside the slab
+        uintptr_t cur = first;
         for (size_t k = 0; k < chunk_bytes.size(); k++) {
             cur += chunk_bytes[k];
-            const uintptr_t hi = (k + 1 == chunk_bytes.size()) ? ((cur + page - 1) & ~(page - 1)) : (cur & ~(page - 1));
+            const uintptr_t hi = std::min(cur & ~(page - 1), last_page);
             regions.emplace_back(reinterpret_cast<char *>(lo), hi > lo ? (size_t)(hi - lo) : 0);
             lo = std::max(lo, hi);
         }
+        planned = regions;
         worker = std::thread([this]() {
             (void)hipSetDevice(device);
             for (size_t k = 0; k < regions.size(); k++) {
@@ -275,10 +291,25 @@ struct HostPinner {
             }
         });
     }
-    // regions 0 .. k + 1 are locked (or locking has been given up)
-    void wait_for(int k) const {
-        const int need = std::min((int)regions.size(), k + 2);
+    // Wait until every region that overlaps [dst, dst + bytes) is locked (or locking has been given up), then return the
+    // offsets at which a copy of that range has to be cut: every region boundary strictly inside it.
+    std::vector<size_t> cuts_for(const char *dst, size_t bytes) const {
+        std::vector<size_t> cuts;
+        int need = 0;
+        for (size_t k = 0; k < planned.size(); k++) {          // `planned` is immutable once the worker runs
+            const char *lo = planned[k].first, *hi = lo + planned[k].second;
+            if (planned[k].second && hi > dst && lo < dst + bytes) need = (int)k + 1;
+        }
         while (done.load(std::memory_order_acquire) < need) std::this_thread::yield();
+        for (int k = 0; k < need; k++) {                       // regions[k] is final for k < done (release / acquire)
+            const char *lo = planned[(size_t)k].first, *hi = lo + planned[(size_t)k].second;
+            if (planned[(size_t)k].second == 0) continue;
+            if (lo > dst && lo < dst + bytes) cuts.push_back((size_t)(lo - dst));
+            if (hi > dst && hi < dst + bytes) cuts.push_back((size_t)(hi - dst));
+        }
+        std::sort(cuts.begin(), cuts.end());
+        cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+        return cuts;
     }
     void finish() {          // after every copy has completed
         if (worker.joinable()) worker.join();
@@ -454,10 +485,10 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
                           azim_num <= near_max_azim() && tb.elev_num <= 65534;
     a.near_idx = nullptr; a.near_r = nullptr;
     a.tile_list = nullptr; a.n_list = 0;
-    a.verify_near = (opts && opts->verify_near) ? 1 : 0;
+    a.verify_near = (opts && opts->verify_near > 0) ? opts->verify_near : 0;
     float ms_near = 0.0f;
 
-    unsigned long long cnt[16] = {0};
+    unsigned long long cnt[16] = {0}, n_verified = 0;
     float ms = 0.0f, ms_svf = 0.0f;
     int fallbacks = 0;
     unsigned long long redo_blocks = 0;
@@ -487,6 +518,13 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             sc->near_bytes = need;
         }
     }
+    // HZ_NEAR_REASONS=1: histogram of why cells got no certificate, printed to stderr at the end of the call
+    unsigned *near_reasons = nullptr;
+    struct ReasonsFree { unsigned **p; ~ReasonsFree() { if (*p) (void)hipFree(*p); } } reasons_free{&near_reasons};
+    if (use_near && getenv("HZ_NEAR_REASONS")) {
+        if (hipMalloc((void **)&near_reasons, 16 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); near_reasons = nullptr; }
+        else (void)hipMemsetAsync(near_reasons, 0, 16 * sizeof(unsigned), st);
+    }
     HostPinner pinner;          // declared after the events: destroyed (joined, unregistered) before them
     if (stream_out && !(opts && opts->no_host_pin)) {
         std::vector<size_t> cb;
@@ -500,22 +538,20 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         Ev &e = evs[ev_of[(size_t)k]];
         char *dst = reinterpret_cast<char *>(hori_row0 + (size_t)rb * dim_in_1 * azim_num);
         const size_t bytes = (size_t)(re - rb) * row_bytes;
-        // a copy must not straddle two separately page-locked regions: the last (< 4096) bytes of chunk k lie in region
-        // k + 1 and go as a copy of their own
-        size_t head = bytes;
-        if (!pinner.regions.empty()) {
-            pinner.wait_for(k);
-            if ((size_t)k + 1 < pinner.regions.size()) {      // (also when locking was given up half way: the boundary
-                                                              //  may then separate locked from pageable memory)
-                char *next = pinner.regions[(size_t)k + 1].first;
-                if (next > dst && next < dst + bytes) head = (size_t)(next - dst);
-            }
+        // a copy must not straddle two separately page-locked ranges (nor a locked and a pageable one): cut it at every
+        // region boundary inside the chunk (at most three pieces; the slab's unaligned head and tail stay pageable)
+        std::vector<size_t> cuts;
+        if (!pinner.planned.empty()) cuts = pinner.cuts_for(dst, bytes);
+        cuts.push_back(bytes);
+        if (hipStreamWaitEvent(st_copy, e.c, 0) != hipSuccess)
+            return set_error(HZ_ERR_HIP, "copy of the horizon chunk failed: %s", hipGetErrorString(hipGetLastError()));
+        size_t from = 0;
+        for (size_t to : cuts) {
+            if (to > from && hipMemcpyAsync(dst + from, static_cast<const char *>(src) + from, to - from, hipMemcpyDeviceToHost, st_copy) != hipSuccess)
+                return set_error(HZ_ERR_HIP, "copy of the horizon chunk failed: %s", hipGetErrorString(hipGetLastError()));
+            from = to;
         }
-        if (hipStreamWaitEvent(st_copy, e.c, 0) != hipSuccess ||
-            hipMemcpyAsync(dst, src, head, hipMemcpyDeviceToHost, st_copy) != hipSuccess ||
-            (head < bytes && hipMemcpyAsync(dst + head, static_cast<const char *>(src) + head, bytes - head,
-                                            hipMemcpyDeviceToHost, st_copy) != hipSuccess) ||
-            hipEventRecord(e.d, st_copy) != hipSuccess)
+        if (hipEventRecord(e.d, st_copy) != hipSuccess)
             return set_error(HZ_ERR_HIP, "copy of the horizon chunk failed: %s", hipGetErrorString(hipGetLastError()));
         return HZ_OK;
     };
@@ -548,6 +584,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             na.ray_org_elev = ray_org_elev; na.hori_acc = tb.hori_acc; na.low = tb.low; na.up = tb.up;
             na.near_idx = (unsigned short *)sc->near_buf;
             na.near_r = (float *)((char *)sc->near_buf + idx_bytes);
+            na.reasons = near_reasons;
             hipEvent_t n0 = nullptr, n1 = nullptr;
             if (hipEventCreate(&n0) != hipSuccess || hipEventCreate(&n1) != hipSuccess) return fail(set_error(HZ_ERR_HIP, "hipEventCreate failed"));
             (void)hipEventRecord(n0, st);
@@ -622,6 +659,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             (void)hipEventElapsedTime(&m2, e.b, e.c);
             ms += m1; ms_svf += m2;
             for (int k = 0; k < 16; k++) cnt[k] += c[k];
+            n_verified += c[21];
             if (a.count_work && getenv("HZ_XCD_TRACE")) {      // per-XCD span of this launch (counting instantiation)
                 const unsigned long long t0 = ~c[20];
                 fprintf(stderr, "hz xcd spans [ms] rows %d..%d:", rb, re);
@@ -655,8 +693,18 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         stats->elev_num = tb.elev_num; stats->bvh_height = sc->hdr.height; stats->scene_bytes = sc->hdr.total_bytes;
         stats->stack_fallbacks += (uint64_t)fallbacks; stats->stack_redo_blocks += redo_blocks;
         stats->rays_shortened += cnt[9]; stats->near_violations += cnt[10]; stats->t_near_s += (double)ms_near * 1e-3;
-        stats->guard_cells += cnt[11];
+        stats->guard_cells += cnt[11]; stats->near_verified += n_verified;
         stats->height_field = height_field ? 1 : 0; stats->near_used = use_near ? 1 : 0;
+    }
+    if (near_reasons) {
+        unsigned h[16] = {0};
+        if (hipMemcpy(h, near_reasons, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
+            static const char *nm[13] = {"frame", "vertex_on_axis", "edge_over_axis", "az_tolerance", "inplane_edge", "crossing_near_axis",
+                                         "interval", "precision", "edge_on", "orientation", "origin_below", "axis_in_triangle", "window_or_mask"};
+            fprintf(stderr, "hz near reasons: cells %u certified %u", h[0], h[1]);
+            for (int b = 0; b < 13; b++) if (h[2 + b]) fprintf(stderr, " %s %u", nm[b], h[2 + b]);
+            fprintf(stderr, "\n");
+        }
     }
     if (opts && opts->verbose) {   // the reference's report, horizon_comp.cpp:673-700, 805-810 (same lines, same order)
         static const char *alg_name[3] = {"discrete_sampling", "binary search", "guess horizon from previous azimuth direction"};
@@ -669,6 +717,13 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         printf("Number of rays shot: %llu\n", cnt[0]);
         printf("Average number of rays per location and azimuth: %.2f \n",
                cnt[4] ? (double)((float)cnt[0] / (float)(cnt[4] * (unsigned long long)azim_num)) : 0.0);
+        // (not a line of the reference: why this call ran without the near-field certificates, if it did)
+        if (!use_near && near_opt <= 0) {
+            if (!height_field)
+                printf("Near-field certificates off: %u DEM triangle(s) are near-vertical or oriented against the majority in the "
+                       "(x, y) plane -- the mesh is not a height field (results unaffected, slower)\n", sc->hdr.n_flipped);
+            else if (sc->hdr.n_tin != 0) printf("Near-field certificates off: outer simplified domain present (results unaffected)\n");
+        }
         fflush(stdout);
     }
     return HZ_OK;
@@ -772,6 +827,8 @@ using namespace hz;
 extern "C" {
 
 const char *hz_last_error(void) { return g_error.c_str(); }
+
+int hz_abi_version(void) { return 4; }
 
 int hz_abi_struct_sizes(int *opts_bytes, int *stats_bytes) {
     if (opts_bytes) *opts_bytes = (int)sizeof(hz_opts);
@@ -1340,14 +1397,20 @@ static int terrain_run(Terrain *t, const float *sun_positions, int num_sun, int 
     unsigned long long cnt[16];
     {
         // the sun positions go to the device once; one launch computes up to 32768 of them (grid.y)
-        DevIn<float> d_sun;
-        if ((rc = d_sun.bind(sun.data(), sun.size(), st))) return rc;
+        if (t->sun_cap < sun.size()) {
+            if (t->sun_dev) (void)hipFree(t->sun_dev);
+            t->sun_dev = nullptr; t->sun_cap = 0;
+            const size_t cap = std::max<size_t>(sun.size(), 3 * 256);
+            HZ_HIP(hipMalloc((void **)&t->sun_dev, cap * sizeof(float)));
+            t->sun_cap = cap;
+        }
+        HZ_HIP(hipMemcpyAsync(t->sun_dev, sun.data(), sun.size() * sizeof(float), hipMemcpyHostToDevice, st));
         HZ_HIP(hipMemsetAsync(t->counters, 0, 16 * sizeof(unsigned long long), st));
         hipEvent_t e0, e1;
         HZ_HIP(hipEventCreate(&e0)); HZ_HIP(hipEventCreate(&e1));
         HZ_HIP(hipEventRecord(e0, st));
         for (int s0 = 0; s0 < num_sun; s0 += 32768) {
-            a.suns = d_sun.dev + 3 * (size_t)s0;
+            a.suns = t->sun_dev + 3 * (size_t)s0;
             a.num_sun = std::min(32768, num_sun - s0);
             a.out_u8 = d_u8.dev ? d_u8.dev + nc * (size_t)s0 : nullptr;
             a.out_f32 = d_f32.dev ? d_f32.dev + nc * (size_t)s0 : nullptr;

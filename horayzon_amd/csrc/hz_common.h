@@ -7,7 +7,7 @@
 // vertices : the caller's vert_grid, untouched (ray origins read them;
 //            reference: shared vertex buffer, horizon_comp.cpp:126-127).
 // nodes    : flat LBVH collapsed to 4-wide nodes along the 2-bit digits of the Morton key (= a quadtree over the
-//            (x, y) centroids).  One node is 64 B and holds the conservatively quantised AABBs (8 bit x/y, 11 bit z as half floats,
+//            (x, y) centroids).  One node is 48 B and holds the conservatively quantised AABBs (8 bit x/y, 11 bit z as half floats,
 //            relative to the node's own box) of up to 4 children, stored tallest (largest z-max) first.  ALL nodes
 //            are numbered breadth first and the children of a node are CONTIGUOUS: one index (`first`) addresses
 //            the block of 4 child slots -- 4 consecutive nodes, or 4 consecutive leaf records (a node whose children
@@ -29,7 +29,7 @@
 #include <hip/hip_runtime.h>
 
 #define HZ_BLOB_MAGIC 0x485a4c42u /* "HZLB" */
-#define HZ_BLOB_VERSION 7u
+#define HZ_BLOB_VERSION 8u
 #define HZ_WAVE 64
 
 struct BlobHeader {
@@ -64,17 +64,19 @@ static_assert(sizeof(BlobHeader) == 256, "BlobHeader must be 256 bytes");
 #define HZ_IS_NODE(link) ((unsigned)(link) < 0x7fffffffu)
 #define HZ_LEAF_BIT 0x80000000u
 #define HZ_LEAF_ID(link) ((int)((unsigned)(link) & 0x7fffffffu))
-struct __attribute__((aligned(64))) Node {
-    float org[3];        // lower corner of the node's box (centred frame); x and y shifted by -1024 quantisation steps
-                         // (a child's x bound is org[0] + (1024 + q) * step[0]: the form hz_qbox_hit decodes)
+struct __attribute__((aligned(16))) Node {
+    float org[3];        // origin of the node's quantisation frame (centred scene frame): a child's x bound is
+                         // org[0] + (1024 + q) * step_xy, its z bound org[2] + q * step_z (the forms hz_qbox_hit decodes).
+                         // The quantisation steps are powers of two and live IN these floats: the low 9 mantissa bits of
+                         // org[0] hold the biased exponent of step_xy (x and y share one step), those of org[2] that of
+                         // step_z (bit 8 is zero, so `bits << 23` IS the step).  The build chooses the origins as floats
+                         // with those low bits and quantises against exactly these values (hz_scene.hip: axis_setup).
     int32_t first;       // link of child slot 0; slots 1..3 are first + 1 .. first + 3: 4 consecutive nodes or 4
-                         // consecutive leaf records (blocks are 4-aligned; slot k exists iff bit k of `valid`)
+                         // consecutive leaf records (blocks are 4-aligned).  An unused slot has an empty box (lo > hi).
     uint32_t qxy[4];     // per child slot: xlo | xhi<<8 | ylo<<16 | yhi<<24   (8 bit, 0..255)
-    uint32_t qz[4];      // per child slot: zlo | zhi<<16     (two half floats holding integers 0..2047: org[2] + q * step[2])
-    float step[3];       // quantisation steps of x, y, z (powers of two)
-    uint32_t valid;
+    uint32_t qz[4];      // per child slot: zlo | zhi<<16     (two half floats holding integers 0..2047)
 };
-static_assert(sizeof(Node) == 64, "Node must be 64 bytes");
+static_assert(sizeof(Node) == 48, "Node must be 48 bytes");
 
 struct __attribute__((aligned(16))) Prim {
     float a[3], b[3], c[3], d[3];
@@ -277,10 +279,12 @@ __device__ __forceinline__ RayBox hz_raybox(float ocx, float ocy, float ocz,
 // per-node constants: t = q * a + b maps a quantised coordinate to a ray parameter
 struct NodeRay { float ax, bx, ay, by, az, bz; };
 
-__device__ __forceinline__ NodeRay hz_node_ray(const RayBox &r, float ox, float oy, float oz, float sx, float sy, float sz) {
+__device__ __forceinline__ NodeRay hz_node_ray(const RayBox &r, float ox, float oy, float oz) {
+    // the quantisation steps: the low 9 bits of org[0] / org[2], shifted into the exponent field (Node)
+    const float sxy = __uint_as_float(__float_as_uint(ox) << 23), sz = __uint_as_float(__float_as_uint(oz) << 23);
     NodeRay n;
-    n.ax = sx * r.rdx; n.bx = __builtin_fmaf(ox, r.rdx, -r.ordx);
-    n.ay = sy * r.rdy; n.by = __builtin_fmaf(oy, r.rdy, -r.ordy);
+    n.ax = sxy * r.rdx; n.bx = __builtin_fmaf(ox, r.rdx, -r.ordx);
+    n.ay = sxy * r.rdy; n.by = __builtin_fmaf(oy, r.rdy, -r.ordy);
     n.az = sz * r.rdz; n.bz = __builtin_fmaf(oz, r.rdz, -r.ordz);
     return n;
 }
@@ -324,11 +328,13 @@ __device__ __forceinline__ bool hz_qbox_hit(const NodeRay &n, const RayBox &r, f
 #endif
 }
 
-// One 64 B node = 4 x 16 B global loads issued back to back and waited for once.
-// (hipcc was seen to put an s_waitcnt between the halves of the plain C++ form.)
-__device__ __forceinline__ void hz_load_node(const Node *n, float4 &n0, uint4 &n1, uint4 &n2, float4 &n3) {
-#ifdef HZ_PROBE_EXTRA_LOADS   // measurement probe (scripts/build_variant.sh): two more 16 B loads of the same node per visit
-    float4 x0, x1;          // the other half of the node's 128 B cache line: what a 128 B node would touch
+// One 48 B node = 3 x 16 B global loads issued back to back and waited for once.
+// (hipcc was seen to put an s_waitcnt between the halves of the plain C++ form.)  Rounds 1-3 had 64 B nodes (a fourth load
+// for the three quantisation steps and a valid mask): the vector-memory pipe is the kernel's second limit (+1 load per
+// visit cost 3 %, +2 loads 10 - 12 %, round 3), so the steps moved into the low mantissa bits of the origin.
+__device__ __forceinline__ void hz_load_node(const Node *n, float4 &n0, uint4 &n1, uint4 &n2) {
+#ifdef HZ_PROBE_EXTRA_LOADS   // measurement probe (scripts/build_variant.sh): more 16 B loads of the same cache line per visit
+    float4 x0, x1;
     const Node *n_other = reinterpret_cast<const Node *>(reinterpret_cast<size_t>(n) ^ (size_t)64);
 #if HZ_PROBE_EXTRA_LOADS >= 2
     asm volatile("global_load_dwordx4 %0, %2, off\n\t"
@@ -339,26 +345,24 @@ __device__ __forceinline__ void hz_load_node(const Node *n, float4 &n0, uint4 &n
     (void)x1;
 #endif
 #endif
-    asm volatile("global_load_dwordx4 %0, %4, off\n\t"
-                 "global_load_dwordx4 %1, %4, off offset:16\n\t"
-                 "global_load_dwordx4 %2, %4, off offset:32\n\t"
-                 "global_load_dwordx4 %3, %4, off offset:48\n\t"
+    asm volatile("global_load_dwordx4 %0, %3, off\n\t"
+                 "global_load_dwordx4 %1, %3, off offset:16\n\t"
+                 "global_load_dwordx4 %2, %3, off offset:32\n\t"
                  "s_waitcnt vmcnt(0)"
-                 : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3)
+                 : "=&v"(n0), "=&v"(n1), "=&v"(n2)
                  : "v"(n)
                  : "memory");
 }
 
-// The same node from the LDS nodelet (4 x ds_read_b128, one wait).
-__device__ __forceinline__ void hz_load_node_lds(const float4 *q, float4 &n0, uint4 &n1, uint4 &n2, float4 &n3) {
+// The same node from the LDS nodelet (3 x ds_read_b128, one wait).
+__device__ __forceinline__ void hz_load_node_lds(const float4 *q, float4 &n0, uint4 &n1, uint4 &n2) {
     const unsigned addr = (unsigned)(size_t)reinterpret_cast<const __attribute__((address_space(3))) char *>(
         (const __attribute__((address_space(3))) float4 *)q);
-    asm volatile("ds_read_b128 %0, %4\n\t"
-                 "ds_read_b128 %1, %4 offset:16\n\t"
-                 "ds_read_b128 %2, %4 offset:32\n\t"
-                 "ds_read_b128 %3, %4 offset:48\n\t"
+    asm volatile("ds_read_b128 %0, %3\n\t"
+                 "ds_read_b128 %1, %3 offset:16\n\t"
+                 "ds_read_b128 %2, %3 offset:32\n\t"
                  "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(n0), "=&v"(n1), "=&v"(n2), "=&v"(n3)
+                 : "=&v"(n0), "=&v"(n1), "=&v"(n2)
                  : "v"(addr)
                  : "memory");
 }
@@ -462,14 +466,14 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
         if (n_node * 16 >= n_leaf * leaf_bias) {
             // ---------------- node step ------------------------------------------------------
             if (can_node) {
-                float4 n0, n3; uint4 n1, n2;
+                float4 n0; uint4 n1, n2;
                 // NODELET: top-of-tree nodes from LDS, the rest from global memory (two separate asm paths:
                 // a per-lane pointer select would be compiled into slow flat loads).  Measured 2 % slower
                 // than plain global loads -- the top of the tree is L1 resident -- so it is opt-in.
-                if (NODELET && node < ntop) hz_load_node_lds(top + 4 * node, n0, n1, n2, n3);
-                else hz_load_node(nodes + node, n0, n1, n2, n3);
+                if (NODELET && node < ntop) hz_load_node_lds(top + 3 * node, n0, n1, n2);
+                else hz_load_node(nodes + node, n0, n1, n2);
                 if (COUNT) { cnt.nodes++; HZ_WAVE_TICK(cnt.w_nodes, lane); }
-                const NodeRay nr = hz_node_ray(rb, n0.x, n0.y, n0.z, n3.x, n3.y, n3.z);
+                const NodeRay nr = hz_node_ray(rb, n0.x, n0.y, n0.z);
                 // children are visited in slot order (tallest first).  A front-to-back order (slot r ^ direction
                 // signs, ~45 VALU per step) was measured to be a net loss: these are any-hit rays, a blocked ray
                 // is blocked over a long stretch behind the first ridge, and near-horizon rays that only
@@ -532,10 +536,10 @@ __device__ __forceinline__ bool hz_closest(const Node *__restrict__ nodes, const
     bool any = false;
     while (node != HZ_EMPTY) {
         if (node >= 0) {
-            float4 n0, n3; uint4 n1, n2;
-            hz_load_node(nodes + node, n0, n1, n2, n3);
+            float4 n0; uint4 n1, n2;
+            hz_load_node(nodes + node, n0, n1, n2);
             const float tf = any ? __builtin_fminf(tfar, best * 1.0001f) : tfar;
-            const NodeRay nr = hz_node_ray(rb, n0.x, n0.y, n0.z, n3.x, n3.y, n3.z);
+            const NodeRay nr = hz_node_ray(rb, n0.x, n0.y, n0.z);
             const bool h0 = hz_qbox_hit(nr, rb, tf, n1.x, n2.x), h1 = hz_qbox_hit(nr, rb, tf, n1.y, n2.y);
             const bool h2 = hz_qbox_hit(nr, rb, tf, n1.z, n2.z), h3 = hz_qbox_hit(nr, rb, tf, n1.w, n2.w);
             const int first = __float_as_int(n0.w);

@@ -46,7 +46,8 @@ struct HorizonParams {
     int top_nodes, regroup, stack_bytes, leaf_bias, stage_bytes, hit_cache, stack_cap;
     const unsigned short *near_idx;   // near-field certificates of this launch's rows (hz_near.hip) or null
     const float *near_r;
-    int verify_near;
+    int verify_near;               // 0: off; else re-trace the shortened rays selected by verify_mask over their full length
+    unsigned verify_mask;          //   (power of two - 1: one of every verify_mask + 1 shortened rays; 0: all of them)
     unsigned long long *counters;
     const int *tile_list;          // null, or the n_list blocks (workgroup number * 4 + wave, of the full launch) to repeat
     int n_list;
@@ -56,7 +57,9 @@ struct HorizonParams {
 // LDS: [ per-lane stacks int[depth][256] | output staging float[4][256] | top-of-tree nodelet Node[top_nodes] ]
 // LEVELSTACK: the traversal's stack discipline (hz_common.h).  false = one LDS entry per pending sibling: fewest VALU
 // instructions, `stack_cap` entries, overflow flagged in counters[8]; true = one entry per tree level, cannot overflow.
-template <int ALG, bool COUNT, bool STAGE, bool NODELET, bool LEVELSTACK>
+// VERIFY: the production kernel with the certificate check compiled in (opts.verify_near without count_work): a sample of the
+// shortened rays is traced a second time from parameter 0 and disagreeing decisions are counted (counters[10], [21]).
+template <int ALG, bool COUNT, bool STAGE, bool NODELET, bool LEVELSTACK, bool VERIFY = false>
 __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *stack = reinterpret_cast<int *>(smem);
@@ -66,7 +69,7 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
     if (NODELET && ntop > 0) {   // stage the breadth-first top of the tree in LDS (coalesced 16 B per lane)
         float4 *dst = reinterpret_cast<float4 *>(smem + p.stack_bytes + p.stage_bytes);
         const float4 *src = reinterpret_cast<const float4 *>(p.sv.nodes);
-        for (int i = tid; i < ntop * 4; i += HZ_TPB) dst[i] = src[i];
+        for (int i = tid; i < ntop * 3; i += HZ_TPB) dst[i] = src[i];
         __syncthreads();
     }
 
@@ -144,8 +147,13 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
     unsigned overflow = 0;   // !LEVELSTACK: a ray needed more stack entries than this launch has (see hz_trace)
     // near-field certificate of this cell (hz_near.hip): rays of azimuth k with a table index >= near_idx[k] clear
     // everything within near_r of the origin and start their box tests at parameter near_r
-    unsigned shortened = 0, violations = 0;        // COUNT only
-    bool verifying = false, first_result = false;  // COUNT + verify_near: second, full-length pass of a shortened ray
+    // verify_near (COUNT / VERIFY): a shortened ray that is selected (want_v) is traced a second time over its full length
+    // (verifying) and the two decisions are compared.  Lane state is kept in flags only (lane masks in scalar registers)
+    // and the tallies are wave-uniform popcounts: the VERIFY instantiation needs no vector register the production
+    // kernel does not have.
+    unsigned shortened = 0;                        // COUNT only
+    unsigned w_verified = 0, w_violations = 0;     // wave-uniform
+    bool verifying = false, first_result = false, want_v = false;
     float tn = 0.0f;
 
     while (__ballot(!done) != 0ull) {
@@ -163,6 +171,7 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
                 tn = 0.0f;
                 if (p.near_idx != nullptr && s.ind >= (int)p.near_idx[(size_t)cert * (size_t)t.azim_num + s.k]) tn = p.near_r[cert];
                 if (COUNT && tn > 0.0f) shortened++;
+                if (COUNT || VERIFY) want_v = p.verify_near && tn > 0.0f && (((rays + cert) & p.verify_mask) == 0u);
                 rb = hz_raybox(ocx + tn * dx, ocy + tn * dy, ocz + tn * dz, dx, dy, dz);
                 hz_trav_reset(ts);
                 // a ray below the previous azimuth's horizon is expected to be blocked near the same ridge
@@ -175,21 +184,26 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
             }
         }
         // ---- traversal (hz_common.h: speculative while-while, one postponed leaf per lane) ------
+        bool start_v = false, viol = false;
         if (ray_active) {
             const int r = hz_trace<HZ_TPB, COUNT, HZ_QLEN, NODELET, LEVELSTACK>(p.sv.nodes, p.sv.prims, top, ntop, stack, tid, ox, oy, oz,
                                                  dx, dy, dz, tfar, rb, ts, p.regroup, p.leaf_bias, tc, p.stack_cap, overflow);
             if (r == 0 && second) {                      // nothing in the cached subtree: full traversal
                 second = false; hz_trav_reset(ts);
-            } else if (COUNT && p.verify_near && r != 2 && tn > 0.0f && !verifying) {
+            } else if ((COUNT || VERIFY) && want_v && r != 2) {
                 // the shortened ray is done: trace it again over its full length and compare the decisions
-                verifying = true; first_result = (r == 1);
+                want_v = false; verifying = true; first_result = (r == 1); start_v = true;
                 rb = hz_raybox(ocx, ocy, ocz, dx, dy, dz);
                 hz_trav_reset(ts);
             } else if (r != 2) {
-                if (COUNT && verifying) { if ((r == 1) != first_result) violations++; verifying = false; }
+                if ((COUNT || VERIFY) && verifying) { viol = ((r == 1) != first_result); verifying = false; }
                 ray_active = false; last_hit = (r == 1);
                 if (r == 1) cache = p.sv.anc[HZ_LEAF_ID(ts.lq0)];   // ts.lq0 is the leaf that blocked the ray
             }
+        }
+        if (COUNT || VERIFY) {
+            w_verified += (unsigned)__popcll(__ballot(start_v));
+            w_violations += (unsigned)__popcll(__ballot(viol));
         }
     }
 
@@ -230,17 +244,23 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
             atomicMax(&p.counters[12 + xcc], (unsigned long long)wall_clock64());
             atomicMax(&p.counters[20], ~t_start);
         }
-        unsigned long long sh = shortened, vi = violations;
-        for (int off = 32; off > 0; off >>= 1) { sh += __shfl_xor(sh, off); vi += __shfl_xor(vi, off); }
-        if (lane == 0) { if (sh) atomicAdd(&p.counters[9], sh); if (vi) atomicAdd(&p.counters[10], vi); }
+    }
+    if (COUNT || VERIFY) {
+        unsigned long long sh = shortened;
+        for (int off = 32; off > 0; off >>= 1) sh += __shfl_xor(sh, off);
+        if (lane == 0) {
+            if (sh) atomicAdd(&p.counters[9], sh);
+            if (w_violations) atomicAdd(&p.counters[10], (unsigned long long)w_violations);
+            if (w_verified) atomicAdd(&p.counters[21], (unsigned long long)w_verified);
+        }
     }
 }
 
-template <int ALG, bool COUNT, bool STAGE, bool NODELET, bool LEVELSTACK>
+template <int ALG, bool COUNT, bool STAGE, bool NODELET, bool LEVELSTACK, bool VERIFY = false>
 static int launch_one(const HorizonParams &p, int grid, size_t lds, hipStream_t st) {
-    HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_horizon<ALG, COUNT, STAGE, NODELET, LEVELSTACK>),
+    HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_horizon<ALG, COUNT, STAGE, NODELET, LEVELSTACK, VERIFY>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_horizon<ALG, COUNT, STAGE, NODELET, LEVELSTACK>), dim3(grid), dim3(HZ_TPB), lds, st, p);
+    hipLaunchKernelGGL((k_horizon<ALG, COUNT, STAGE, NODELET, LEVELSTACK, VERIFY>), dim3(grid), dim3(HZ_TPB), lds, st, p);
     HZ_HIP(hipGetLastError());
     return HZ_OK;
 }
@@ -251,6 +271,10 @@ static int launch_alg(const HorizonParams &p, int grid, size_t lds, bool count, 
     if (ALG == ALG_GUESS && !count && p.top_nodes > 0)      // opt-in LDS nodelet variant (opts.top_nodes > 0)
         return stage ? launch_one<ALG_GUESS, false, true, true, true>(p, grid, lds, st)
                      : launch_one<ALG_GUESS, false, false, true, true>(p, grid, lds, st);
+    if (!count && p.verify_near) {                          // production kernel + sampled certificate check
+        if (level_stack) return stage ? launch_one<ALG, false, true, false, true, true>(p, grid, lds, st) : launch_one<ALG, false, false, false, true, true>(p, grid, lds, st);
+        return stage ? launch_one<ALG, false, true, false, false, true>(p, grid, lds, st) : launch_one<ALG, false, false, false, false, true>(p, grid, lds, st);
+    }
     if (level_stack) {
         if (count) return stage ? launch_one<ALG, true, true, false, true>(p, grid, lds, st) : launch_one<ALG, true, false, false, true>(p, grid, lds, st);
         return stage ? launch_one<ALG, false, true, false, true>(p, grid, lds, st) : launch_one<ALG, false, false, false, true>(p, grid, lds, st);
@@ -305,7 +329,13 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
     p.regroup = (a.regroup <= 0) ? 40 : std::min(a.regroup & 0xff, 64);
     p.leaf_bias = (a.regroup >= 256) ? (a.regroup >> 8) : 20;
     p.hit_cache = (a.hit_cache != 0) ? 1 : 0;
-    p.near_idx = a.near_idx; p.near_r = a.near_r; p.verify_near = a.verify_near;
+    p.near_idx = a.near_idx; p.near_r = a.near_r;
+    p.verify_near = (a.verify_near > 0 && a.near_idx != nullptr) ? 1 : 0;
+    {   // one of every N shortened rays, N rounded up to a power of two (1: all)
+        unsigned n = a.verify_near > 1 ? (unsigned)a.verify_near : 1u, m = 1u;
+        while (m < n && m < (1u << 30)) m <<= 1;
+        p.verify_mask = m - 1u;
+    }
     p.counters = a.counters;
     p.tile_list = a.tile_list; p.n_list = a.n_list;
     p.redo_list = reinterpret_cast<int *>(a.counters + 24);
@@ -489,7 +519,11 @@ int topo_launch(int kind, const float *azim, const float *hori, const float *vec
     const size_t ncell = (size_t)len_0 * len_1;
     if (ncell == 0) return HZ_OK;
     const size_t lds = (2 * (size_t)len_2 + 4 * 64 * (HZ_TOPO_CH + 1)) * sizeof(float);
-    if (lds <= 60 * 1024) {
+    // (HZ_TOPO_WIDE=1: force the fallback kernel -- tests compare the two paths on the same input, so that they cannot
+    //  drift apart: k_topo takes the float32 arctangent only where the tilted plane limits, k_topo_wide calls libm's
+    //  float64 routines per azimuth as the Cython code does; both are held to 1e-5 against the reference-made fixtures)
+    const char *force_wide = getenv("HZ_TOPO_WIDE");
+    if (lds <= 60 * 1024 && !(force_wide && force_wide[0] == '1')) {
         const dim3 grid((unsigned)((ncell + 255) / 256)), block(256);
         if (kind == 0) hipLaunchKernelGGL(k_topo<0>, grid, block, lds, st, azim, hori, vec_tilt, ncell, len_2, out);
         else if (kind == 1) hipLaunchKernelGGL(k_topo<1>, grid, block, lds, st, azim, hori, vec_tilt, ncell, len_2, out);

@@ -51,7 +51,13 @@ struct NearParams {
     float ray_org_elev, low, step, up, pad;
     unsigned short *near_idx;          // [n_cells][azim_num]
     float *near_r;                     // [n_cells]
+    unsigned *reasons;                 // null, or 16 counters: [0] cells, [1] with a certificate, [2 + b] refused for reason bit b
 };
+
+// why a cell gets no certificate (bits of the per-wave flag word; HZ_NEAR_REASONS=1 prints the histogram of a call)
+enum { HZ_NR_FRAME = 1, HZ_NR_VERTEX_ON_AXIS = 2, HZ_NR_EDGE_OVER_AXIS = 4, HZ_NR_AZ_TOLERANCE = 8, HZ_NR_INPLANE_EDGE = 16,
+       HZ_NR_CROSSING_NEAR_AXIS = 32, HZ_NR_INTERVAL = 64, HZ_NR_PRECISION = 128, HZ_NR_EDGE_ON = 256, HZ_NR_ORIENTATION = 512,
+       HZ_NR_ORIGIN_BELOW = 1024, HZ_NR_AXIS_IN_TRIANGLE = 2048, HZ_NR_WINDOW = 4096 };
 
 // order-preserving float <-> int so that LDS atomicMax works on floats
 __device__ __forceinline__ int f2o(float f) { const int i = __float_as_int(f); return i >= 0 ? i : (i ^ 0x7fffffff); }
@@ -99,7 +105,20 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
         q[5 * lane + 3] = rx; q[5 * lane + 4] = ry;
     }
     for (int k = lane; k < A; k += 64) E[k] = f2o(-__builtin_inff());
-    if (lane == 0) flags[0] = 0;
+    if (lane == 0) {
+        // The whole construction works in the cell's (east, north, norm) coordinates and assumes that the ray of table
+        // entry (k, i) has azimuth phi_k and elevation elev_ang[i] IN THOSE coordinates: true only for an orthonormal
+        // frame.  The reference accepts any pair of vectors (horizon_comp.cpp:751-779); a frame that is off by more than
+        // 1e-4 (unit length, right angle) gets no certificate (budget: DESIGN.md section 4.3, term F).
+        int bad = 0;
+        if (valid) {
+            const float nx = p.vec_norm[3 * cell], ny = p.vec_norm[3 * cell + 1], nz = p.vec_norm[3 * cell + 2];
+            const float tx = p.vec_north[3 * cell], ty = p.vec_north[3 * cell + 1], tz = p.vec_north[3 * cell + 2];
+            const float nn = (nx * nx + ny * ny) + nz * nz, tt = (tx * tx + ty * ty) + tz * tz, nt = (nx * tx + ny * ty) + nz * tz;
+            if (!(__builtin_fabsf(nn - 1.0f) <= 1.0e-4f && __builtin_fabsf(tt - 1.0f) <= 1.0e-4f && __builtin_fabsf(nt) <= 1.0e-4f)) bad = 1;
+        }
+        flags[0] = bad ? HZ_NR_FRAME : 0;
+    }
     __syncthreads();
     const float dphi = 6.283185307179586f / (float)A;
     auto edge_ends = [&](int e, int &ia, int &ib) {                  // end points (window vertex numbers) of edge e
@@ -120,19 +139,19 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
                 const float ae = q[5 * ia], an = q[5 * ia + 1], be = q[5 * ib], bn = q[5 * ib + 1];
                 const float ra = __builtin_sqrtf(ae * ae + an * an), rb = __builtin_sqrtf(be * be + bn * bn);
                 const float rmin = __builtin_fminf(ra, rb);
-                if (!(rmin > 1.0e-3f)) flags[0] = 1;                 // a vertex (almost) above / below the origin
+                if (!(rmin > 1.0e-3f)) atomicOr(&flags[0], HZ_NR_VERTEX_ON_AXIS);                 // a vertex (almost) above / below the origin
                 else {
                     const float pa = atan2f(ae, an), pb = atan2f(be, bn);   // azimuth clockwise from north
                     float dl = pb - pa;
                     if (dl > 3.14159265f) dl -= 6.2831853f;
                     if (dl < -3.14159265f) dl += 6.2831853f;
-                    if (__builtin_fabsf(dl) > 2.9f) flags[0] = 1;    // the edge passes (almost) over the origin
+                    if (__builtin_fabsf(dl) > 2.9f) atomicOr(&flags[0], HZ_NR_EDGE_OVER_AXIS);    // the edge passes (almost) over the origin
                     else {
                         const float lo = dl >= 0.0f ? pa : pb, span = __builtin_fabsf(dl);
                         const float m_az = 2.0e-3f + 0.02f / rmin;   // end points within the tolerance count as in the plane
                         // (grids with centimetre spacing: the tolerance would span a large part of the circle and the
                         //  bins would leave the (-A, 2 A) range phase 2 wraps once -- no certificate for such a cell)
-                        if (m_az > 0.25f) flags[0] = 1;
+                        if (m_az > 0.25f) atomicOr(&flags[0], HZ_NR_AZ_TOLERANCE);
                         k_lo = (int)__builtin_floorf((lo - m_az) / dphi);
                         bins = (int)__builtin_ceilf((lo + span + m_az) / dphi) - k_lo + 1;
                         if (m_az > 0.25f) bins = 0;
@@ -167,25 +186,56 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
             const float rmin = __builtin_fminf(ra, rb);
             const float tol_a = 1.0e-3f * ra + 0.01f, tol_b = 1.0e-3f * rb + 0.01f;
             const int first = ek[2 * e] + (c - pre[e]) * CH, last = min(first + CH, ek[2 * e] + ek[2 * e + 1]);
+            const float r_big = __builtin_fmaxf(ra, rb);
+            // absolute error bounds of the interpolated (r, z) of a crossing: the window coordinates q carry ~3 roundings of
+            // magnitude <= 2^-24 |q| each, the interpolation two more (term C)
+            const float er = 6.0e-7f * (ra + rb), ez = 6.0e-7f * ((__builtin_fabsf(az) + __builtin_fabsf(bz)) + (ra + rb));
+            // an end point that lies in the plane (|d| <= tol) is seen at r in [ra sqrt(1 - (tol / ra)^2), ra]: the larger
+            // of z / r over that range, once per task instead of a division per azimuth (tol / ra <= 0.126: m_az <= 0.25)
+            const float ta = tol_a / ra, tb = tol_b / rb;
+            const float xa = az > 0.0f ? az / (ra * __builtin_sqrtf(1.0f - ta * ta)) : az / ra;
+            const float xb = bz > 0.0f ? bz / (rb * __builtin_sqrtf(1.0f - tb * tb)) : bz / rb;
+            const float dz = bz - az;
+            const float ninf = -__builtin_inff();
             for (int kk = first; kk < last; kk++) {
+#pragma clang fp contract(fast)      // bounds, not the bit-exact contract: FMAs only remove roundings the error terms allow for
                 int k = kk;                                          // kk lies in (-A, 2 A)
                 if (k < 0) k += A;
                 if (k >= A) k -= A;
                 const float sp = tab[k], cp = tab[A + k];
                 const float da = ae * cp - an * sp, db = be * cp - bn * sp;     // signed distances from the plane
-                float cand = -__builtin_inff();
                 const float fa = ae * sp + an * cp, fb = be * sp + bn * cp;     // along the azimuth (r of the end points)
-                if (__builtin_fabsf(da) <= tol_a && fa > 0.5f * ra) cand = __builtin_fmaxf(cand, az / fa);
-                if (__builtin_fabsf(db) <= tol_b && fb > 0.5f * rb) cand = __builtin_fmaxf(cand, bz / fb);
+                const bool in_a = __builtin_fabsf(da) <= tol_a, in_b = __builtin_fabsf(db) <= tol_b;
+                float cand = (in_a && fa > 0.5f * ra) ? xa : ninf;
+                cand = __builtin_fmaxf(cand, (in_b && fb > 0.5f * rb) ? xb : ninf);
                 if ((da < 0.0f) != (db < 0.0f)) {
-                    const float t = da / (da - db);
-                    const float r = fa + t * (fb - fa), z = az + t * (bz - az);
-                    if (r > 0.0f) {
-                        if (r < 0.25f * rmin) flags[0] = 1;        // crossing close to the axis: not trusted
-                        cand = __builtin_fmaxf(cand, z / r);
+                    // The edge crosses the plane at parameter t = da / (da - db).  da and db are differences of two
+                    // rounded products: |error| <= 4 * 2^-24 * r each, so |t - t_exact| <= dt (first order, a factor 1.6 in
+                    // hand).  With x(t) = z(t) / r(t), z and r linear in t:  x(tau) - x(t) = (tau - t) (dz r(t) - z(t) df) /
+                    // (r(tau) r(t))  EXACTLY, hence |x(tau) - x(t)| <= dt (|dz| + |x| |df|) / (0.95 r) for |tau - t| <= dt as
+                    // long as dt |df| <= 0.05 r: the candidate is x + that bound (v_rcp_f32: 1 ulp, inside the margins).
+                    const float rden = __builtin_amdgcn_rcpf(da - db);
+                    const float dt = 4.0e-7f * r_big * __builtin_fabsf(rden) + 1.0e-6f;
+                    if (!(dt <= 0.1f)) {
+                        // both end points within rounding of the plane: the edge lies IN it; its end-point values bound it
+                        if (!(in_a && in_b)) atomicOr(&flags[0], HZ_NR_INPLANE_EDGE);
+                    } else {
+                        const float t = da * rden, df = fb - fa;
+                        const float r = fa + t * df, z = az + t * dz;
+                        if (r > 0.0f) {
+                            const float rr = __builtin_amdgcn_rcpf(r);
+                            const float x = z * rr, adf = __builtin_fabsf(df), ax = __builtin_fabsf(x);
+                            const float slope = __builtin_fabsf(dz) + ax * adf;
+                            // refusals: a crossing close to the axis; an interval that is not small against r; an
+                            // elevation error (ez + |x| er) / r / (1 + x^2) of this candidate above 5e-4 rad
+                            if (!(r >= 0.25f * rmin)) atomicOr(&flags[0], HZ_NR_CROSSING_NEAR_AXIS);
+                            if (!(dt * adf <= 0.05f * r)) atomicOr(&flags[0], HZ_NR_INTERVAL);
+                            if (!(ez + ax * er <= 5.0e-4f * r * (1.0f + x * x))) atomicOr(&flags[0], HZ_NR_PRECISION);
+                            cand = __builtin_fmaxf(cand, x + 1.06f * dt * slope * rr);
+                        } else if (!(r < -0.05f * rmin)) atomicOr(&flags[0], HZ_NR_CROSSING_NEAR_AXIS);      // (within rounding of the axis)
                     }
                 }
-                if (cand > -__builtin_inff()) atomicMax(&E[k], f2o(cand));
+                if (cand > ninf) atomicMax(&E[k], f2o(cand));
             }
         }
     }
@@ -205,20 +255,31 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
             const int va = r * NV + c, vb = va + 1, vc = va + NV, vd = vc + 1;     // quad corners a, b / c, d
             const int i0 = (t & 1) ? vb : va, i1 = (t & 1) ? vd : vb, i2 = vc;     // (a, b, c) and (b, d, c)
             const float x0 = q[5 * i0], y0 = q[5 * i0 + 1], x1 = q[5 * i1], y1 = q[5 * i1 + 1], x2 = q[5 * i2], y2 = q[5 * i2 + 1];
-            {
-                const float ux = x1 - x0, uy = y1 - y0, uz = q[5 * i1 + 2] - q[5 * i0 + 2];
-                const float vx = x2 - x0, vy = y2 - y0, vz = q[5 * i2 + 2] - q[5 * i0 + 2];
-                const float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;   // nz: local projected area
-                if (!(nz * nz > 1.0e-6f * ((nx * nx + ny * ny) + nz * nz))) flags[0] = 1;
-                else if (nz > 0.0f) pos = true;
-                else neg = true;
+            const float ux = x1 - x0, uy = y1 - y0, uz = q[5 * i1 + 2] - q[5 * i0 + 2];
+            const float vx = x2 - x0, vy = y2 - y0, vz = q[5 * i2 + 2] - q[5 * i0 + 2];
+            const float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;   // nz: local projected area
+            if (!(nz * nz > 1.0e-6f * ((nx * nx + ny * ny) + nz * nz))) atomicOr(&flags[0], HZ_NR_EDGE_ON);
+            else if (nz > 0.0f) pos = true;
+            else neg = true;
+            if (i0 == CENTRE || i1 == CENTRE || i2 == CENTRE) {
+                // The six triangles at the cell's own vertex: the ray origin must lie strictly ABOVE each of their planes
+                // (local z of the plane at the axis: gamma < 0).  Then z / r = slope + gamma / r increases with r on
+                // each of them, the surface along an azimuth is one continuous curve, and its maximum over the inner
+                // ring is taken on the ring's outer edges -- which is why the spokes may be skipped.  Normally
+                // gamma = -ray_org_elev; with coordinates of 1e6 m the origin v + norm * ray_org_elev is rounded to a
+                // 0.25 m grid and can land ON or BELOW a steep adjacent triangle: no certificate then.
+                const float z00 = q[5 * i0 + 2];
+                const float lift = (nx * x0 + ny * y0) / nz;                     // nz != 0: checked above
+                const float gamma = z00 + lift;
+                const float tol_g = 1.0e-5f * (__builtin_fabsf(z00) + __builtin_fabsf(lift)) + 1.0e-6f;
+                if (!(gamma < -tol_g)) atomicOr(&flags[0], HZ_NR_ORIGIN_BELOW);
+                continue;
             }
-            if (i0 == CENTRE || i1 == CENTRE || i2 == CENTRE) continue;
             const float c0 = x0 * y1 - x1 * y0, c1 = x1 * y2 - x2 * y1, c2 = x2 * y0 - x0 * y2;   // origin vs the three edges
             const float tol = 1.0e-3f * (__builtin_fabsf(c0) + __builtin_fabsf(c1) + __builtin_fabsf(c2));
-            if ((c0 >= -tol && c1 >= -tol && c2 >= -tol) || (c0 <= tol && c1 <= tol && c2 <= tol)) flags[0] = 1;
+            if ((c0 >= -tol && c1 >= -tol && c2 >= -tol) || (c0 <= tol && c1 <= tol && c2 <= tol)) atomicOr(&flags[0], HZ_NR_AXIS_IN_TRIANGLE);
         }
-        if (__ballot(pos) != 0ull && __ballot(neg) != 0ull && lane == 0) flags[0] = 1;
+        if (__ballot(pos) != 0ull && __ballot(neg) != 0ull && lane == 0) atomicOr(&flags[0], HZ_NR_ORIENTATION);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -242,6 +303,12 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
     }
     for (int off = 32; off > 0; off >>= 1) rin = __builtin_fminf(rin, __shfl_xor(rin, off));
     const bool ok = valid && flags[0] == 0 && rin < 1.0e30f;
+    if (p.reasons != nullptr && have && lane == 0) {      // debug histogram (HZ_NEAR_REASONS=1): why cells got no certificate
+        const int f = valid ? flags[0] : HZ_NR_WINDOW;
+        atomicAdd(&p.reasons[0], 1u);
+        if (ok) atomicAdd(&p.reasons[1], 1u);
+        for (int b = 0; b < 14; b++) if (f & (1 << b)) atomicAdd(&p.reasons[2 + b], 1u);
+    }
     // ---- table index per azimuth ---------------------------------------------------------------------------------
     if (have) {
         // elevation margin: two table steps, at least 2 mrad (a ray that clears the window by less is not shortened)
@@ -274,7 +341,7 @@ int near_launch(const Scene *sc, const NearArgs &a, hipStream_t st) {
     p.azim_num = a.azim_num; p.elev_num = a.elev_num;
     p.ray_org_elev = a.ray_org_elev; p.low = a.low; p.step = (float)((double)a.hori_acc / 5.0); p.up = a.up;
     p.pad = sc->hdr.pad;
-    p.near_idx = a.near_idx; p.near_r = a.near_r;
+    p.near_idx = a.near_idx; p.near_r = a.near_r; p.reasons = a.reasons;
     if (p.n_cells <= 0) return HZ_OK;
     constexpr int NVERT = (2 * HZ_NEAR_W + 1) * (2 * HZ_NEAR_W + 1);
     constexpr int NV = 2 * HZ_NEAR_W + 1, NEDGE = 2 * NV * (NV - 1) + (NV - 1) * (NV - 1);

@@ -274,8 +274,8 @@ __global__ __launch_bounds__(256) void k_roots(int n_nodes, const int *__restric
 // the breadth-first pass below turns these into the final `Node`s with contiguous children
 #define HZ_TMP_EMPTY ((int)0x80000000)   // "no child" among the temp links (>= 0 temp node, < 0 leaf = ~sorted position)
 struct NodeTmp {
-    float org[3];
-    uint32_t scale;      // biased float exponents of the x | y<<8 | z<<16 quantisation steps
+    float org[3];        // quantisation origins with the step exponents in their low mantissa bits (hz_common.h: Node)
+    uint32_t pad_;
     uint32_t qxy[4], qz[4];
     int32_t link[4];     // >= 0 temp node, < 0 leaf (~sorted position), HZ_TMP_EMPTY none
 };
@@ -323,18 +323,59 @@ __device__ __forceinline__ uint32_t step_exponent(float extent, float qmax) {
 // structure the leaf padding has covered since round 1.
 struct AxisQ { uint32_t e; float s, o, m; };
 __device__ __forceinline__ double axis_plane(const AxisQ &a, float q) { return (double)a.o + (double)(1024.0f + q) * (double)a.s; }
-__device__ __forceinline__ AxisQ axis_setup(float nl, float nh) {
-    AxisQ a;
-    a.e = step_exponent(nh - nl, 253.0f);
-    for (;;) {
-        a.s = __uint_as_float(a.e << 23);
-        a.m = a.s * (1.0f / 4096.0f);
-        a.o = nl - 1024.0f * a.s;
-        for (int g = 0; g < 16 && axis_plane(a, 0.0f) > (double)nl - (double)a.m; g++) a.o = nextafterf(a.o, -INFINITY);
-        if (axis_plane(a, 255.0f) >= (double)nh + (double)a.m || a.e >= 254u) break;
-        a.e++;
+// The step exponents travel in the low 9 mantissa bits of the node's x and z origins (bit 8 zero, bits 7..0 the biased
+// exponent: `bits << 23` is the step).  embed_down: the largest float <= target with those low bits; embed_below: the next
+// such float below f.  (Moves an origin down by at most 511 ulp: 4 m at |o| = 1e5 -- the quantisation below is done
+// against the float that is actually stored, so this only costs a few of the 256 codes at the finest levels.)
+__device__ __forceinline__ float embed_down(float target, uint32_t e) {
+    if (!(__builtin_fabsf(target) > 1.0e-30f)) target = -1.0e-30f;
+    const uint32_t b = __float_as_uint(target);
+    if ((b >> 31) == 0u) {
+        uint32_t c = (b & ~0x1ffu) | e;
+        if (c > b) {
+            if (c < 0x200u + 0x00800000u) return embed_down(-1.0e-30f, e);      // would leave the normal positives
+            c -= 0x200u;
+        }
+        return __uint_as_float(c);
     }
-    return a;
+    const uint32_t mag = b & 0x7fffffffu;
+    uint32_t c = (mag & ~0x1ffu) | e;
+    if (c < mag) c += 0x200u;
+    return __uint_as_float(0x80000000u | c);
+}
+__device__ __forceinline__ float embed_below(float f, uint32_t e) {
+    const uint32_t b = __float_as_uint(f);
+    if ((b >> 31) == 0u) return (b >= 0x200u + 0x00800000u) ? __uint_as_float(b - 0x200u) : embed_down(-1.0e-30f, e);
+    return __uint_as_float(b + 0x200u);
+}
+// x and y share one step.  embed = true (x): the origin carries the exponent bits.
+__device__ __forceinline__ bool axis_try(AxisQ &a, float nl, float nh, uint32_t e, bool embed) {
+    a.e = e;
+    a.s = __uint_as_float(e << 23);
+    a.m = a.s * (1.0f / 4096.0f);
+    a.o = nl - 1024.0f * a.s;
+    if (embed) a.o = embed_down(a.o, e);
+    for (int g = 0; g < 16 && axis_plane(a, 0.0f) > (double)nl - (double)a.m; g++)
+        a.o = embed ? embed_below(a.o, e) : nextafterf(a.o, -INFINITY);
+    return axis_plane(a, 0.0f) <= (double)nl - (double)a.m && axis_plane(a, 255.0f) >= (double)nh + (double)a.m;
+}
+__device__ __forceinline__ void axes_setup(float xl, float xh, float yl, float yh, AxisQ &ax, AxisQ &ay) {
+    uint32_t e = max(step_exponent(xh - xl, 250.0f), step_exponent(yh - yl, 250.0f));
+    for (;;) {
+        const bool okx = axis_try(ax, xl, xh, e, true), oky = axis_try(ay, yl, yh, e, false);
+        if ((okx && oky) || e >= 254u) break;
+        e++;
+    }
+}
+// z: origin with the exponent bits at or below the node's lower bound, step such that code 2047 reaches its upper bound
+__device__ __forceinline__ void z_setup(float zl, float zh, float &oz, float &sz) {
+    uint32_t e = step_exponent(zh - zl, 2040.0f);
+    for (;;) {
+        sz = __uint_as_float(e << 23);
+        oz = embed_down(zl, e);
+        if (__builtin_fmaf(2047.0f, sz, oz) >= zh || e >= 254u) break;
+        e++;
+    }
 }
 __device__ __forceinline__ uint32_t axis_lo(const AxisQ &a, float lo) {
     const double want = (double)lo - (double)a.m;
@@ -413,21 +454,20 @@ __global__ __launch_bounds__(256) void k_emit4(Emit4 e, NodeTmp *__restrict__ no
         cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
     }
     const float4 nl = e.node_lo[i], nh = e.node_hi[i];
-    const float org[3] = {nl.x, nl.y, nl.z};
-    const float ext[3] = {nh.x - nl.x, nh.y - nl.y, nh.z - nl.z};
-    const AxisQ ax = axis_setup(nl.x, nh.x), ay = axis_setup(nl.y, nh.y);
-    const uint32_t ez = step_exponent(ext[2], HZ_QZ_MAX);
-    const float sz = __uint_as_float(ez << 23);
+    AxisQ ax, ay;
+    axes_setup(nl.x, nh.x, nl.y, nh.y, ax, ay);
+    float oz, sz;
+    z_setup(nl.z, nh.z, oz, sz);
     NodeTmp n;
-    n.org[0] = ax.o; n.org[1] = ay.o; n.org[2] = org[2];
-    n.scale = ax.e | (ay.e << 8) | (ez << 16);
+    n.org[0] = ax.o; n.org[1] = ay.o; n.org[2] = oz;
+    n.pad_ = 0u;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         n.link[k] = link[k];
         if (link[k] == HZ_TMP_EMPTY) { n.qxy[k] = HZ_QXY_EMPTY; n.qz[k] = HZ_QZ_EMPTY; continue; }   // lo > hi: never hit
         const uint32_t xl = axis_lo(ax, lo[k][0]), xh = axis_hi(ax, hi[k][0]);
         const uint32_t yl = axis_lo(ay, lo[k][1]), yh = axis_hi(ay, hi[k][1]);
-        const uint32_t zl = quant_lo(lo[k][2], org[2], sz, HZ_QZ_MAX), zh = quant_hi(hi[k][2], org[2], sz, HZ_QZ_MAX);
+        const uint32_t zl = quant_lo(lo[k][2], oz, sz, HZ_QZ_MAX), zh = quant_hi(hi[k][2], oz, sz, HZ_QZ_MAX);
         n.qxy[k] = xl | (xh << 8) | (yl << 16) | (yh << 24);
         n.qz[k] = half_bits(zl) | (half_bits(zh) << 16);
     }
@@ -513,12 +553,8 @@ __global__ __launch_bounds__(256) void k_bfs_emit(BfsEmit e, BuildParams b) {
     bfs_kinds(t, ni, nl);
     Node n;
     n.org[0] = t.org[0]; n.org[1] = t.org[1]; n.org[2] = t.org[2];
-    n.step[0] = __uint_as_float((t.scale & 0xffu) << 23);
-    n.step[1] = __uint_as_float(((t.scale >> 8) & 0xffu) << 23);
-    n.step[2] = __uint_as_float(((t.scale >> 16) & 0xffu) << 23);
-    n.valid = 0;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { n.qxy[k] = t.qxy[k]; n.qz[k] = t.qz[k]; if (t.link[k] != HZ_TMP_EMPTY) n.valid |= 1u << k; }
+    for (int k = 0; k < 4; k++) { n.qxy[k] = t.qxy[k]; n.qz[k] = t.qz[k]; }
     if (ni == 0) {                                        // all children are leaves: one leaf block
         const int lb = e.leaf_blocks_before + (int)e.scan_leaf[pos];
         n.first = (int)(HZ_LEAF_BIT | (unsigned)(4 * lb));
@@ -537,8 +573,7 @@ __global__ __launch_bounds__(256) void k_bfs_emit(BfsEmit e, BuildParams b) {
                 f = -2 - (~t.link[k]);
                 Node w;                                    // single-child node: this slot's box in this node's frame
                 w.org[0] = n.org[0]; w.org[1] = n.org[1]; w.org[2] = n.org[2];
-                w.step[0] = n.step[0]; w.step[1] = n.step[1]; w.step[2] = n.step[2];
-                w.first = 0; w.valid = 1u;
+                w.first = 0;
                 for (int q = 0; q < 4; q++) { w.qxy[q] = HZ_QXY_EMPTY; w.qz[q] = HZ_QZ_EMPTY; }
                 w.qxy[0] = t.qxy[k]; w.qz[0] = t.qz[k];
                 e.nodes[first + k] = w;
@@ -567,16 +602,17 @@ __global__ __launch_bounds__(256) void k_anc_bfs(int n_leaf_blocks, int levels, 
 // single primitive: a temp root whose slot 0 is the leaf, quantised against its own box
 __global__ void k_single_tmp(const float4 *leaf_lo, const float4 *leaf_hi, NodeTmp *nodes) {
     const float4 l = leaf_lo[0], h = leaf_hi[0];
-    const AxisQ ax = axis_setup(l.x, h.x), ay = axis_setup(l.y, h.y);
-    const uint32_t ez = step_exponent(h.z - l.z, HZ_QZ_MAX);
-    const float sz = __uint_as_float(ez << 23);
+    AxisQ ax, ay;
+    axes_setup(l.x, h.x, l.y, h.y, ax, ay);
+    float oz, sz;
+    z_setup(l.z, h.z, oz, sz);
     NodeTmp n;
-    n.org[0] = ax.o; n.org[1] = ay.o; n.org[2] = l.z;
-    n.scale = ax.e | (ay.e << 8) | (ez << 16);
+    n.org[0] = ax.o; n.org[1] = ay.o; n.org[2] = oz;
+    n.pad_ = 0u;
     for (int k = 0; k < 4; k++) { n.link[k] = HZ_TMP_EMPTY; n.qxy[k] = HZ_QXY_EMPTY; n.qz[k] = HZ_QZ_EMPTY; }
     n.link[0] = ~0;
     n.qxy[0] = axis_lo(ax, l.x) | (axis_hi(ax, h.x) << 8) | (axis_lo(ay, l.y) << 16) | (axis_hi(ay, h.y) << 24);
-    n.qz[0] = half_bits(quant_lo(l.z, l.z, sz, HZ_QZ_MAX)) | (half_bits(quant_hi(h.z, l.z, sz, HZ_QZ_MAX)) << 16);
+    n.qz[0] = half_bits(quant_lo(l.z, oz, sz, HZ_QZ_MAX)) | (half_bits(quant_hi(h.z, oz, sz, HZ_QZ_MAX)) << 16);
     nodes[0] = n;
 }
 

@@ -46,6 +46,70 @@ def import_reference():
     return ref, hz, sh, tp
 
 
+def import_stub():
+    """--dry-run: stand-ins with the reference's call signatures and its stdout report (horizon_comp.cpp:225-227,
+    802-818), backed by this repository's CPU oracle.  The files a dry run writes say so ("version": "DRY-RUN ...") and
+    are only good for checking this script (case list, shapes, dtypes, file layout, timing schema) -- never as fixtures."""
+    import types
+    sys.path.insert(0, ROOT)
+    from oracle import oracle as orc
+
+    def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north, offset_0, offset_1, dist_search=50.0, **kw):
+        hori, azim, st = orc.horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north, offset_0, offset_1,
+                                             dist_search=dist_search, return_stats=True, **kw)
+        mask = kw.get("mask")
+        cells = int((np.asarray(mask) == 1).sum()) if mask is not None else int(vec_norm.shape[0] * vec_norm.shape[1])
+        # the reference reports from C++ (printf on file descriptor 1): write there, not through sys.stdout
+        os.write(1, ("BVH build time: %g s\nNumber of grid cells for which horizon is computed: %d \nRay tracing time: %g s\n"
+                     "Number of rays shot: %d\nTotal run time: %g s\n"
+                     % (st["t_build_s"], cells, st["t_rays_s"], st["rays"], st["t_build_s"] + st["t_rays_s"])).encode())
+        return hori, azim
+
+    ref = types.SimpleNamespace(__version__="DRY-RUN (CPU oracle of this repository, NOT the Embree reference)")
+    hz = types.SimpleNamespace(horizon_gridded=horizon_gridded)
+    sh = types.SimpleNamespace(Terrain=orc.Terrain)
+    tp = types.SimpleNamespace(sky_view_factor=orc.sky_view_factor)
+    return ref, hz, sh, tp
+
+
+def validate(out_dir, n_bench_rows):
+    """Shape / dtype / layout check of everything main() wrote, against the case list the pin tests replay
+    (tests/embree_pin.py).  Raises AssertionError with the offending key."""
+    import json
+    hz_npz = np.load(os.path.join(out_dir, "embree_horizon.npz"))
+    names = []
+    for name, kw, par in pin_cases():
+        in0, in1 = kw["vec_norm"].shape[:2]
+        A = par.get("azim_num", 360)
+        h, a = hz_npz["hori__" + name], hz_npz["azim__" + name]
+        assert h.dtype == np.float32 and h.shape == (in0, in1, A), ("hori__" + name, h.dtype, h.shape)
+        assert a.dtype == np.float32 and a.shape == (A,), ("azim__" + name, a.dtype, a.shape)
+        assert np.isfinite(h).all(), "hori__" + name
+        names.append(name)
+    first = names[0]
+    assert hz_npz["svf__" + first].shape == hz_npz["hori__" + first].shape[:2] and hz_npz["svf__" + first].dtype == np.float32
+    assert "version" in hz_npz.files
+    sh_npz = np.load(os.path.join(out_dir, "embree_shadow.npz"))
+    g, (vec_tilt, vec_norm, enl, elev, mask), suns = shadow_case()
+    assert sh_npz["suns"].shape == suns.shape and sh_npz["suns"].dtype == np.float32
+    for refrac in (0, 1):
+        for geom in ("triangle", "grid"):
+            k = "%s_refrac%d" % (geom, refrac)
+            assert sh_npz["shadow__" + k].shape == (suns.shape[0],) + mask.shape and sh_npz["shadow__" + k].dtype == np.uint8, k
+            assert sh_npz["sw_dir_cor__" + k].shape == (suns.shape[0],) + mask.shape and sh_npz["sw_dir_cor__" + k].dtype == np.float32, k
+            assert sh_npz["shadow__" + k].max() <= 3, k
+    tj = json.load(open(os.path.join(out_dir, "embree_timing.json")))
+    assert set(tj) >= {"reference_version", "cases", "environment"} and set(tj["cases"]) == set(names)
+    for name, rep in tj["cases"].items():
+        assert {"ray_tracing_s", "rays"} <= set(rep), (name, rep)       # what bench.py / DESIGN.md quote
+    assert tj["environment"]["logical_cores"] >= 1
+    if n_bench_rows > 0:
+        c3 = tj["c3_tile"]
+        assert {"cells_per_s", "mray_per_s", "rows", "ray_tracing_s", "rays", "tile"} <= set(c3), c3   # bench.py: cpu_baseline.embree
+        assert c3["rows"] == n_bench_rows and c3["cells_per_s"] > 0
+    return len(names)
+
+
 def pin_cases():
     """(name, grid kwargs, parameters): the configurations tests/test_gpu_embree_pin.py replays.  Searches that the
     reference cannot finish (guard events) are avoided by the choice of elev_ang_low_lim."""
@@ -164,7 +228,7 @@ def bench_tile(hz, n=3601, rows=64):
     mask = np.zeros((in0, in0), np.uint8)
     mask[in0 // 2:in0 // 2 + rows] = 1
     with CaptureStdout() as cap:
-        hz.horizon_gridded(g["vert_grid"], n, n, g["vec_norm"], g["vec_north"], off, off, 50.0, azim_num=360, mask=mask)
+        hz.horizon_gridded(g["vert_grid"], n, n, g["vec_norm"], g["vec_north"], off, off, 50.0, azim_num=360, mask=mask)   # noqa
     rep = parse_report(cap.text)
     rep.update(tile=n, rows=rows, cells_expected=rows * in0, azim_num=360, dist_search_km=50.0, ray_algorithm="guess_constant")
     if rep.get("ray_tracing_s") and rep.get("rays"):
@@ -173,12 +237,19 @@ def bench_tile(hz, n=3601, rows=64):
     return rep
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
     ap.add_argument("--bench-rows", type=int, default=64, help="rows of the 3601^2 tile timed with the reference (0: skip)")
-    args = ap.parse_args()
-    ref, hz, sh, tp = import_reference()
+    ap.add_argument("--bench-tile", type=int, default=3601, help="size of the timed tile (the dry run uses a small one)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="run the whole case list against a stand-in for the reference (this repository's CPU oracle) to check "
+                         "the script itself: shapes, dtypes, file layout, timing schema.  Writes to --out, which must NOT be "
+                         "tests/golden")
+    args = ap.parse_args(argv)
+    if args.dry_run and os.path.abspath(args.out) == os.path.join(ROOT, "tests", "golden"):
+        raise SystemExit("--dry-run must not write into tests/golden (its outputs are not fixtures): pass --out <tmp dir>")
+    ref, hz, sh, tp = import_stub() if args.dry_run else import_reference()
     os.makedirs(args.out, exist_ok=True)
     store = {}
     timing = {"reference_version": getattr(ref, "__version__", "unknown"), "cases": {}}
@@ -215,11 +286,13 @@ def main():
     timing["environment"] = environment()
     if args.bench_rows > 0:
         print("reference horizon_gridded: 3601^2 tile, %d rows (timing)" % args.bench_rows, flush=True)
-        timing["c3_tile"] = bench_tile(hz, rows=args.bench_rows)
+        timing["c3_tile"] = bench_tile(hz, n=args.bench_tile, rows=args.bench_rows)
     import json
     with open(os.path.join(args.out, "embree_timing.json"), "w") as f:
         json.dump(timing, f, indent=1)
-    print("wrote", os.path.join(args.out, "embree_horizon.npz"), ", embree_shadow.npz and embree_timing.json")
+    n = validate(args.out, args.bench_rows)
+    print("wrote", os.path.join(args.out, "embree_horizon.npz"), ", embree_shadow.npz and embree_timing.json (%d horizon cases, layout "
+          "validated)%s" % (n, " -- DRY RUN, not fixtures" if args.dry_run else ""))
 
 
 if __name__ == "__main__":

@@ -123,3 +123,74 @@ def fuzz_case(rng):
         tilt = np.stack([np.sin(b), -np.sin(a) * np.cos(b), np.cos(a) * np.cos(b)], axis=2).astype(np.float32)
         extra["svf_vec_tilt"] = tilt
     return kw, par, extra, tilt
+
+
+ADV_ASPECTS = ((1.0, 90.0), (90.0, 1.0), (0.5, 45.0), (45.0, 0.5), (2.0, 180.0), (30.0, 30.0), (10.0, 10.0), (1.0, 1.0),
+               (10.0, 900.0), (900.0, 10.0), (5.0, 20.0), (20.0, 5.0))
+
+
+def adversarial_near_case(rng, max_n=40):
+    """One configuration aimed at the near-field certificates (hz_near.hip): cells of aspect 1:90 and
+    90:1, per-cell frames tilted by up to 5 degrees in random directions, cliffs / single spikes / pits / terraces next to
+    the cells, ray origins 0.005 ... 20 m above the surface, coordinates of 2.6e6 (where the ray origin is rounded to a
+    0.25 m grid).  No outer TIN and a plain height field, so the certificates are active.  Returns (grid kwargs,
+    parameters, description)."""
+    n0, n1 = int(rng.integers(9, max_n)), int(rng.integers(9, max_n))
+    off = int(rng.integers(0, 4))
+    dx, dy = ADV_ASPECTS[int(rng.integers(len(ADV_ASPECTS)))]
+    scale = float(min(dx, dy))
+    relief = float(rng.choice([0.0, 3.0, 30.0, 300.0])) * scale ** 0.5
+    origin = (float(rng.choice([0.0, 2.6e6])), float(rng.choice([0.0, 1.2e6])))
+    z = synth.fractal_elevation(n0, n1, seed=int(rng.integers(1 << 30)), z_min=100.0, z_max=100.0 + relief).astype(np.float64)
+    feats = []
+    ii, jj = np.meshgrid(np.arange(n0), np.arange(n1), indexing="ij")
+    if rng.integers(2):                       # a cliff along a row, a column or a diagonal
+        h = float(rng.choice([5.0, 40.0, 400.0])) * float(rng.choice([scale ** 0.5, 1.0]))
+        kind = int(rng.integers(3))
+        c = int(rng.integers(2, max(3, min(n0, n1) - 2)))
+        side = (ii > c) if kind == 0 else ((jj > c) if kind == 1 else (ii + jj > 2 * c))
+        z = z + h * side
+        feats.append("cliff%d:%g" % (kind, h))
+    for _ in range(int(rng.integers(0, 5))):  # single spikes and pits
+        h = float(rng.choice([-200.0, -20.0, 3.0, 30.0, 300.0]))
+        z[int(rng.integers(n0)), int(rng.integers(n1))] += h
+        feats.append("spike:%g" % h)
+    if rng.integers(4) == 0:                  # terraces: flat steps with vertical-ish risers
+        t = float(rng.choice([1.0, 10.0, 100.0]))
+        z = np.round(z / t) * t
+        feats.append("terrace:%g" % t)
+    z = z.astype(np.float32)
+    x = (origin[0] + np.arange(n1) * dx).astype(np.float32)
+    y = (origin[1] + (n0 - 1 - np.arange(n0)) * dy).astype(np.float32)
+    xx, yy = np.meshgrid(x, y)
+    in0, in1 = n0 - 2 * off, n1 - 2 * off
+    tmax = np.deg2rad(float(rng.choice([0.0, 0.4, 2.0, 5.0])))
+    mag = tmax * rng.random((in0, in1))
+    dirn = rng.uniform(0.0, 2.0 * np.pi, (in0, in1))
+    nrm = np.stack([np.sin(mag) * np.cos(dirn), np.sin(mag) * np.sin(dirn), np.cos(mag)], axis=2)
+    north0 = np.array([0.0, 1.0, 0.0])
+    north = north0[None, None, :] - (nrm * north0).sum(axis=2, keepdims=True) * nrm
+    north /= np.linalg.norm(north, axis=2, keepdims=True)
+    ang = float(rng.choice([0.0, 0.05, 1.0])) * rng.standard_normal((in0, in1, 1))
+    east = np.cross(north, nrm)
+    north = np.cos(ang) * north + np.sin(ang) * east
+    skew = float(rng.choice([0.0, 0.0, 0.0, 3.0e-5, 2.0e-3]))      # frames that are not quite orthonormal (the library
+    if skew:                                                     #  must refuse certificates beyond 1e-4, not err)
+        north = north + skew * nrm
+        nrm = nrm * (1.0 + 0.5 * skew)
+    kw = dict(vert_grid=synth.pack_vertices(xx, yy, z), dem_dim_0=n0, dem_dim_1=n1,
+              vec_norm=np.ascontiguousarray(nrm, np.float32), vec_north=np.ascontiguousarray(north, np.float32),
+              offset_0=off, offset_1=off)
+    span = max(n0 * dy, n1 * dx) / 1000.0
+    par = dict(dist_search=float(rng.choice([0.3, 1.0, 3.0])) * span,
+               azim_num=int(rng.choice([8, 36, 90, 360])),
+               hori_acc=float(rng.choice([0.1, 0.25, 1.0])),
+               ray_algorithm=str(rng.choice(["guess_constant", "guess_constant", "binary_search", "discrete_sampling"])),
+               elev_ang_low_lim=float(rng.choice([-15.0, -45.0, -89.98])),
+               ray_org_elev=float(rng.choice([0.005, 0.01, 0.1, 2.0, 20.0])))
+    if par["ray_algorithm"] == "discrete_sampling":         # ~45 ... 900 rays per azimuth: keep the CPU oracle's share small
+        par["azim_num"] = min(par["azim_num"], 36)
+        par["hori_acc"] = max(par["hori_acc"], 0.25)
+    desc = dict(dem=[n0, n1], off=off, dx=dx, dy=dy, relief=relief, origin=list(origin), tilt_deg=float(np.rad2deg(tmax)),
+                skew=skew, feats=feats, **{k: v for k, v in par.items()})
+    return kw, par, desc

@@ -83,6 +83,22 @@ def test_c5_rows_against_the_oracle(hip, orc, c5_job):
             A, 50.0, 0.25, b"guess_constant", -15.0, d_mask.data_ptr(), 0.0, 0.01, C.byref(opts), C.byref(st)))
     assert st.num_cells == rows * IN and st.guard_events == 0 and st.height_field == 1 and st.near_used == 1
     mid = d_hori[:1].cpu().numpy()
+    # four 32-row slabs of the mosaic (both rims) with every shortened ray traced a second time
+    near = dict(rays=0, rays_shortened=0, retraced=0, violations=0)
+    for b in (0, 4801, 9613, IN - rows):
+        o2 = _lib.hz_opts(); o2.device = 0; o2.top_nodes = -1; o2.regroup = -1
+        o2.row_begin, o2.row_end = b, b + rows
+        o2.hori_is_slab = 1; o2.inputs_are_slab = 1; o2.count_work = 1; o2.verify_near = 1
+        s2 = _lib.hz_stats()
+        _lib.check(_lib.lib().hz_horizon_gridded_scene(
+            sc._h, d_norm.data_ptr(), d_north.data_ptr(), OFF, OFF, d_hori.data_ptr(), IN, IN,
+            A, 50.0, 0.25, b"guess_constant", -15.0, d_mask.data_ptr(), 0.0, 0.01, C.byref(o2), C.byref(s2)))
+        assert s2.near_used == 1 and s2.near_violations == 0, (b, s2.near_violations)
+        assert s2.near_verified == s2.rays_shortened and s2.rays_shortened > 0.6 * s2.num_rays
+        near["rays"] += s2.num_rays; near["rays_shortened"] += s2.rays_shortened
+        near["retraced"] += s2.near_verified; near["violations"] += s2.near_violations
+    from tests.test_gpu_fullsize import _log_r04
+    _log_r04("c5_mosaic_4x32_rows", dict(near, shortened_fraction=near["rays_shortened"] / near["rays"]))
     del d_hori, sc
     torch.cuda.empty_cache()
     kw = {k: g[k] for k in ("vert_grid", "dem_dim_0", "dem_dim_1", "vec_norm", "vec_north", "offset_0", "offset_1")}

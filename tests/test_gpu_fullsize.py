@@ -147,3 +147,90 @@ def test_c3_row_bands_bit_identical(hip, orc, tile):
         total += (rows[1] - rows[0]) * ref.shape[1]
         del got, ref
     print("bit-identical cells: %d" % total)
+
+
+def _log_r04(name, rec):
+    """Append one JSON record to gpurun_out/r04_near_verify.jsonl (copied into profiles/r04/ by hand after a GPU run)."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(root, "gpurun_out", "r04_near_verify.jsonl"), "a") as f:
+        f.write(json.dumps(dict(test=name, **rec)) + "\n")
+    print(json.dumps(dict(test=name, **rec)))
+
+
+def test_c3_whole_tile_certificates_retraced(hip, tile):
+    """EVERY ray of the whole config-3 tile that a near-field certificate shortened (79 % of 9.9e9
+    rays) is traced a second time over its full length (counting instantiation, opts.verify_near = 1): no decision may
+    differ.  Then the production kernel with the sampled check compiled in (verify_near = 256): same output bit for bit,
+    no violation, and what the monitoring costs."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    from horayzon_amd import _lib
+    kw = cases.grid_kwargs(tile)
+    in0 = in1 = 3569
+    A, dev = 360, "cuda:0"
+    sc = hip.Scene.create(kw["vert_grid"], 3601, 3601)
+    d_norm = torch.from_numpy(kw["vec_norm"]).to(dev); d_north = torch.from_numpy(kw["vec_north"]).to(dev)
+    d_mask = torch.ones((in0, in1), dtype=torch.uint8, device=dev)
+
+    def run(out, count, verify):
+        opts = _lib.hz_opts(); opts.device = 0; opts.top_nodes = -1; opts.regroup = -1
+        opts.hori_is_slab = 1; opts.count_work = count; opts.verify_near = verify
+        st = _lib.hz_stats()
+        _lib.check(_lib.lib().hz_horizon_gridded_scene(
+            sc._h, d_norm.data_ptr(), d_north.data_ptr(), 16, 16, out.data_ptr(), in0, in1, A, 50.0, 0.25,
+            b"guess_constant", -15.0, d_mask.data_ptr(), 0.0, 0.01, C.byref(opts), C.byref(st)))
+        return st
+
+    plain = torch.empty((in0, in1, A), dtype=torch.float32, device=dev)
+    other = torch.empty((in0, in1, A), dtype=torch.float32, device=dev)
+    run(plain, 0, 0)
+    s0 = run(plain, 0, 0)
+    sv = run(other, 1, 1)
+    assert sv.near_used == 1 and sv.height_field == 1
+    assert sv.near_violations == 0, "a near-field certificate shortened a ray that hits nearby"
+    assert sv.near_verified == sv.rays_shortened and sv.rays_shortened > 0.7 * sv.num_rays
+    assert sv.num_rays == s0.num_rays and bool((plain == other).all().item())
+    other.fill_(float("nan"))
+    ss = run(other, 0, 256)
+    assert ss.near_violations == 0 and bool((plain == other).all().item()) and ss.num_rays == s0.num_rays
+    assert 0.5 * sv.rays_shortened / 256 <= ss.near_verified <= 2.0 * sv.rays_shortened / 256
+    _log_r04("c3_planar_whole_tile", dict(rays=int(sv.num_rays), rays_shortened=int(sv.rays_shortened),
+                                          shortened_fraction=sv.rays_shortened / sv.num_rays, retraced=int(sv.near_verified),
+                                          violations=int(sv.near_violations), kernel_s_plain=s0.t_kernel_s,
+                                          kernel_s_sampled_1_of_256=ss.t_kernel_s, sampled_retraced=int(ss.near_verified),
+                                          sampled_overhead=ss.t_kernel_s / s0.t_kernel_s - 1.0))
+    assert ss.t_kernel_s <= 1.03 * s0.t_kernel_s          # the monitor is meant to cost < 0.5 % (logged); 3 % is the alarm
+
+
+def test_c3_curved_tile_certificates_retraced(hip, tile):
+    """The same full re-trace on the CURVED variant of the tile (frames that are not axis aligned, prepared on the
+    device): 1024 rows across the tile (both rims, where the ENU frames tilt most, and the middle)."""
+    torch = pytest.importorskip("torch")
+    import ctypes as C
+    import bench
+    from horayzon_amd import _lib
+    L = _lib.lib()
+    n, off, A, dev = 3601, 16, 360, "cuda:0"
+    in0 = in1 = n - 2 * off
+    vert_grid, c_norm, c_north, c_tilt = bench.curved_tile_device(L, torch, n, off, 0, np.ascontiguousarray(tile["z"], np.float32))
+    sc = hip.Scene.create(vert_grid, n, n)
+    d_mask = torch.ones((in0, in1), dtype=torch.uint8, device=dev)
+    tot = dict(rays=0, rays_shortened=0, retraced=0, violations=0)
+    for rb in (0, 1264, 2033, in0 - 256):
+        re = rb + 256
+        out = torch.empty((re - rb, in1, A), dtype=torch.float32, device=dev)
+        opts = _lib.hz_opts(); opts.device = 0; opts.top_nodes = -1; opts.regroup = -1
+        opts.row_begin, opts.row_end, opts.hori_is_slab = rb, re, 1
+        opts.count_work = 1; opts.verify_near = 1
+        st = _lib.hz_stats()
+        _lib.check(L.hz_horizon_gridded_scene(sc._h, c_norm.data_ptr(), c_north.data_ptr(), off, off, out.data_ptr(), in0, in1, A,
+                                              50.0, 0.25, b"guess_constant", -15.0, d_mask.data_ptr(), 0.0, 0.01,
+                                              C.byref(opts), C.byref(st)))
+        assert st.near_used == 1 and st.near_violations == 0, (rb, st.near_violations)
+        assert st.near_verified == st.rays_shortened and st.rays_shortened > 0.6 * st.num_rays
+        tot["rays"] += st.num_rays; tot["rays_shortened"] += st.rays_shortened
+        tot["retraced"] += st.near_verified; tot["violations"] += st.near_violations
+    _log_r04("c3_curved_1024_rows", dict(tot, shortened_fraction=tot["rays_shortened"] / tot["rays"]))

@@ -49,6 +49,32 @@ def test_random_configurations(hip, orc):
     print("configurations with blocks repeated one by one:", redo_seen)
 
 
+def test_adversarial_near_field_configurations(hip, orc):
+    """Configurations aimed at the near-field certificates (tests/cases.py: adversarial_near_case -- extreme cell aspects,
+    randomly tilted frames, cliffs, spikes, terraces, 0.005 ... 20 m ray origins, coordinates of 2.6e6, frames that are not
+    quite orthonormal): every shortened ray is traced a second time over its full length, and horizon, ray and guard counts
+    equal the oracle's.  scripts/fuzz_near_adversarial.py runs the same generator wide (profiles/r04/)."""
+    n = int(os.environ.get("HZ_FUZZ_N", "24")) * 2
+    rng = np.random.default_rng(int(os.environ.get("HZ_FUZZ_SEED", "20260928")) + 7)
+    with_cert = 0
+    for it in range(n):
+        kw, par, desc = cases.adversarial_near_case(rng)
+        h, a = hip.horizon.horizon_gridded(**kw, **par, count_work=True, _verify_near=1)
+        st = hip.horizon.last_stats
+        assert st["near_violations"] == 0 and st["near_verified"] == st["rays_shortened"], (it, desc, st["near_violations"])
+        with_cert += int(st["rays_shortened"] > 0)
+        ho, ao, so = orc.horizon_gridded(**kw, **par, return_stats=True)
+        assert np.array_equal(h, ho, equal_nan=True), (it, desc)
+        assert st["num_rays"] == so["rays"] and st["guard_events"] == so["guards"], (it, desc)
+        # the production kernel with the sampled check compiled in gives the same answer
+        if it % 4 == 0:
+            h2, _ = hip.horizon.horizon_gridded(**kw, **par, _verify_near=4)
+            s2 = hip.horizon.last_stats
+            assert np.array_equal(h2, ho, equal_nan=True) and s2["near_violations"] == 0, (it, desc)
+    assert with_cert >= n // 3          # the generator must actually exercise the certificates
+    print("adversarial configurations with shortened rays: %d of %d" % (with_cert, n))
+
+
 def test_random_locations(hip, orc):
     """horizon_locations (+ distance) on random terrains, locations, frames and parameters."""
     n = int(os.environ.get("HZ_FUZZ_N", "24")) // 2

@@ -28,6 +28,28 @@ def test_visible_sky_fraction_and_openness(hip):
         assert np.abs(svf - d["svf_" + n]).max() <= 1e-5
 
 
+def test_topo_kernels_agree_with_each_other(hip):
+    """The tiled kernel (k_topo: azimuth tables in LDS, float32 arctangent only where the tilted plane limits) and the
+    fallback for very large azimuth counts (k_topo_wide: libm's float64 routines per azimuth, as the Cython code) must not
+    drift apart: same fixtures, both within 1e-5 of the reference's values and within 2e-6 of each other."""
+    d = np.load(os.path.join(os.path.dirname(GOLD), "svf_reference.npz"))
+    T = hip.topo_param
+    for n in "abc":
+        a = (T.sky_view_factor(d["azim_" + n], d["hori_" + n], d["tilt_" + n]),
+             T.visible_sky_fraction(d["azim_" + n], d["hori_" + n], d["tilt_" + n]),
+             T.topographic_openness(d["azim_" + n], d["hori_" + n]))
+        os.environ["HZ_TOPO_WIDE"] = "1"
+        try:
+            b = (T.sky_view_factor(d["azim_" + n], d["hori_" + n], d["tilt_" + n]),
+                 T.visible_sky_fraction(d["azim_" + n], d["hori_" + n], d["tilt_" + n]),
+                 T.topographic_openness(d["azim_" + n], d["hori_" + n]))
+        finally:
+            del os.environ["HZ_TOPO_WIDE"]
+        for x, y, key in zip(a, b, ("svf_", "vsf_", "top_")):
+            assert np.abs(x - y).max() <= 2.0e-6, key
+            assert np.abs(y - d[key + n]).max() <= 1.0e-5, key
+
+
 def test_slope_planar(hip):
     d = np.load(GOLD)
     tp = hip.topo_param.slope_plane_meth(d["pl_x"], d["pl_y"], d["pl_z"])

@@ -479,3 +479,30 @@ def test_embree_fixture_script_parses_the_reference_report():
     assert rep == {"bvh_build_s": 0.731, "ray_tracing_s": 12.5, "rays": 177000000, "cells": 228416, "total_run_s": 14.1}
     env = mef.environment()
     assert env["logical_cores"] >= 1 and "host" in env
+
+
+def test_embree_fixture_script_dry_run(orc, tmp_path):
+    """the one maintainer run of scripts/make_embree_fixtures.py must not be able to fail on a typo.
+    --dry-run executes the script's WHOLE case list against a stand-in with the reference's signatures and stdout report
+    (the CPU oracle), writes the three files, validates shapes / dtypes / layout / the timing schema bench.py reads, and the
+    pin comparison code then replays them (0 mismatches by construction) -- including the worst-cell report."""
+    h = embree_pin._harness()
+    out = str(tmp_path / "dry")
+    h.main(["--dry-run", "--out", out, "--bench-tile", "161", "--bench-rows", "4"])
+    import json
+    tj = json.load(open(os.path.join(out, "embree_timing.json")))
+    assert "DRY-RUN" in tj["reference_version"] and tj["c3_tile"]["tile"] == 161 and tj["c3_tile"]["rays"] > 0
+    assert tj["c3_tile"]["cells"] == 4 * (161 - 32) and len(tj["cases"]) == 15
+    rep = embree_pin.compare_horizon(orc.horizon_gridded, path=os.path.join(out, "embree_horizon.npz"))
+    assert len(rep) == 15 and all(v["mismatches"] == 0 and v["worst_cells_row_col_azim_got_ref"] == [] for v in rep.values())
+    rs = embree_pin.compare_shadow(orc.Terrain, path=os.path.join(out, "embree_shadow.npz"))
+    assert all(v["differing_codes"] == 0 and v["confusion_got_to_ref"] == {} for v in rs.values())
+    # a perturbed fixture is reported with its fraction and its worst cells (and fails the check)
+    z = dict(np.load(os.path.join(out, "embree_horizon.npz")))
+    z["hori__flat"] = z["hori__flat"].copy(); z["hori__flat"][3, 4, 5] += 0.02
+    np.savez_compressed(os.path.join(out, "perturbed.npz"), **z)
+    rep = embree_pin.compare_horizon(orc.horizon_gridded, path=os.path.join(out, "perturbed.npz"), check=False)
+    assert rep["flat"]["mismatches"] == 1 and rep["flat"]["worst_cells_row_col_azim_got_ref"][0][:3] == [3, 4, 5]
+    # and the script refuses to write dry-run output into tests/golden
+    with pytest.raises(SystemExit):
+        h.main(["--dry-run"])
