@@ -53,6 +53,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+NODE_BYTES = 48.0       # one 4-wide LBVH node (hz_common.h: Node; 64 B until round 3): the bytes a node visit reads
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable
 KERNEL_SOURCES = ("hz_common.h", "hz_search.h", "hz_horizon.hip")   # what the traffic figure was measured for
 
@@ -74,6 +75,8 @@ def parse():
                     help="several ranks: broadcast the finished scene blob (vertices + LBVH), or only the 12 V bytes of "
                          "vertices and rebuild the LBVH on every rank")
     ap.add_argument("--no-e2e", action="store_true", help="c3: skip the untimed NumPy-in / NumPy-out call of horizon_gridded")
+    ap.add_argument("--no-c5-extra", action="store_true",
+                    help="c3, one rank: skip the config-5 job (14401^2 mosaic, ~2 min incl. synthesis) among the untimed extras")
     ap.add_argument("--no-extras", action="store_true",
                     help="c3, one rank: skip the untimed extras (whole-tile binary_search / discrete_sampling, the curved tile, c4)")
     ap.add_argument("--suns", type=int, default=144, help="c4: sun positions per step")
@@ -82,6 +85,9 @@ def parse():
     ap.add_argument("--balance", choices=("cost", "cells"), default="cells",
                     help="c5: row slabs balanced by cell count (default) or by the sampled cost pre-pass (measured on the "
                          "synthetic mosaic, 8 emulated ranks: 1.028 against 1.033 max/mean, less than the pre-pass costs)")
+    ap.add_argument("--plain-fraction", type=float, default=0.0,
+                    help="sharded runs: scale the relief of this share of the DEM's rows (the northern ones) down to 3 %% -- an "
+                         "inhomogeneous DEM on which balancing the row slabs by cell count and by sampled cost differ")
     ap.add_argument("--cost-samples", type=int, default=0, help="c5: probe rows of the cost pre-pass (0: max(16, 4 x ranks))")
     ap.add_argument("--emulate-ranks", type=int, default=0, help="c5, one GPU: time the slabs of an R-rank partition one by one")
     ap.add_argument("--dump-svf-rows", default="", help="sharded runs: comma separated inner-domain rows of the gathered SVF to save ('all': every row)")
@@ -103,6 +109,31 @@ def kernel_source_sha():
         with open(os.path.join(ROOT, "horayzon_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
+
+
+def load_valu_model():
+    """(instructions per wave iteration, fast-class share per section, notes): profiles/valu_model.json and
+    profiles/valu_class_mix.json when they were measured for the present kernel sources, else the built-in constants."""
+    model, mix = dict(VALU_MODEL_DEFAULT), dict(CLASS_MIX_DEFAULT)
+    notes = {"valu_model": "built-in constants", "class_mix_note": "built-in class mix"}
+    sha = kernel_source_sha()
+    try:
+        mj = json.load(open(os.path.join(ROOT, "profiles", "valu_model.json")))
+        if mj.get("kernel_source_sha") == sha:
+            model.update({k: mj[k] for k in model if k in mj})
+            notes["valu_model"] = "profiles/valu_model.json (calibrated on SQ_INSTS_VALU, same kernel sources)"
+        else:
+            notes["valu_model"] = "built-in constants (profiles/valu_model.json was measured for other kernel sources)"
+    except Exception:
+        pass
+    try:
+        cj = json.load(open(os.path.join(ROOT, "profiles", "valu_class_mix.json")))
+        if cj.get("kernel_source_sha") == sha:
+            mix = {k: cj[k]["fast_fraction"] for k in mix if k in cj}
+            notes["class_mix_note"] = "profiles/valu_class_mix.json (scripts/isa_class_mix.py, same kernel sources)"
+    except Exception:
+        pass
+    return model, mix, notes
 
 
 def machine_peaks(L, dev_index):
@@ -395,18 +426,33 @@ def run_c3(ctx):
                    "guard_events_per_step": stats.guard_events / max(steps, 1),
                    "guard_cells_per_step": stats.guard_cells / max(steps, 1),
                    "stack_fallbacks": int(stats.stack_fallbacks), "stack_redo_blocks": int(stats.stack_redo_blocks),
-                   "height_field": int(stats.height_field), "near_certificates_used": int(stats.near_used)},
+                   "height_field": int(stats.height_field), "near_certificates_used": int(stats.near_used),
+                   "device": torch.cuda.get_device_name(ctx["local_rank"]), "rocm": getattr(torch.version, "hip", None)},
         "roofline": roofline(args, stats, steps, cw, peaks, A, n, rps),
     }
+    # the committed counter files were measured on one box with one ROCm: say so when this run is on another
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if tj.get("rocm") and (tj.get("rocm") != out["config"]["rocm"] or tj.get("device") != out["config"]["device"]):
+            out["roofline"]["traffic_note"] += " -- measured with ROCm %s on %s, this run: %s on %s" % (
+                tj.get("rocm"), tj.get("device"), out["config"]["rocm"], out["config"]["device"])
+    except Exception:
+        pass
     if args.dump_path and args.dump_svf_rows == "all" and n_slabs == 1:
         np.save(args.dump_path, d_svf.cpu().numpy())
     if world == 1 and not args.no_extras and n_slabs == 1:
         out["extras"] = c3_extras(ctx, L, scene, step_args=dict(d_norm=d_norm, d_north=d_north, d_mask=d_mask, d_tilt=d_tilt,
                                                                  d_hori=d_hori, d_svf=d_svf, in0=in0, in1=in1, off=off, A=A, n=n),
                                   peaks=peaks, g=g)
+    if world == 1 and not args.no_extras and not args.no_c5_extra and n_slabs == 1 and n == 3601:
+        del d_hori
+        torch.cuda.empty_cache()
+        out["extras"]["c5"] = c5_extra()
+        d_hori = None
     if world == 1 and not args.no_e2e:
         # free the resident buffers of the timed region first: the drop-in call allocates its own
-        del d_hori, d_svf, d_tilt, d_norm, d_north, d_mask
+        del d_svf, d_tilt, d_norm, d_north, d_mask
+        d_hori = None
         torch.cuda.empty_cache()
         out["config"]["e2e_numpy_call"] = e2e_numpy_call(g, vec_tilt_h, args, A)
     if world == 1 and not args.no_cpu_baseline:
@@ -537,6 +583,28 @@ def c3_extras(ctx, L, scene, step_args, peaks, g):
     return res
 
 
+def c5_extra():
+    """UNTIMED extra: BASELINE config 5 (the 14401^2 mosaic, SVF-fused, through dist.sharded_rows with one rank) as its own
+    process -- `python bench.py --workload c5` -- so that the driver-run line carries a config-5 figure too."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    t0 = time.perf_counter()
+    try:
+        p = subprocess.run([sys.executable, os.path.abspath(__file__), "--workload", "c5", "--steps", "1", "--warmup", "1"],
+                           env=env, capture_output=True, text=True, timeout=900)
+        d = json.loads(p.stdout.strip().splitlines()[-1])
+    except Exception as e:          # the extras never fail the headline line
+        return {"error": repr(e)[:300]}
+    c = d["config"]
+    return {"metric": d["metric"], "cells_per_s": d["value"], "job_s": d["ms_per_step"] * 1e-3, "mray_per_s": d["mray_per_s"],
+            "n_gpus": d["n_gpus"], "scaling": d["scaling"], "kernel_s": c["kernel_s_rank0"], "near_prepass_s": c["near_prepass_s_rank0"],
+            "svf_kernel_s": c["svf_kernel_s_rank0"], "bvh_build_s": c["bvh_build_s"], "scene_bytes": c["scene_bytes"],
+            "stack_redo_blocks": c["stack_redo_blocks_rank0"], "gathered_svf_finite": c["gathered_svf_finite"],
+            "wall_s_incl_synthesis": time.perf_counter() - t0,
+            "note": "subprocess `bench.py --workload c5 --steps 1 --warmup 1`: whole 206.5 M-cell inner domain, one rank"}
+
+
 def e2e_numpy_call(g, vec_tilt, args, A):
     """UNTIMED (not part of `value`): the drop-in call as a user of the reference makes it -- NumPy in, NumPy out
     (horizon.pyx:170-197): vertices and per-cell inputs uploaded, BVH built, horizon traced in chunks that are
@@ -570,19 +638,9 @@ def roofline(args, stats, steps, cw, peaks, A, n, rps):
     r = {"kernel": "hz::k_horizon<2,false,true,false,false> (guess_constant, staged output, fast stack discipline)", "kernel_ms_per_launch": 1e3 * k_launch_s,
          "mray_per_s_kernel": rays_launch / k_launch_s / 1e6 if k_launch_s else None,
          "svf_kernel_ms_per_launch": 1e3 * stats.t_svf_s / max(steps, 1)}
-    model = dict(VALU_MODEL_DEFAULT)
-    mpath = os.path.join(ROOT, "profiles", "valu_model.json")
+    model, mix0, mnotes = load_valu_model()
     sha = kernel_source_sha()
-    if os.path.exists(mpath):
-        try:
-            mj = json.load(open(mpath))
-            if mj.get("kernel_source_sha") == sha:
-                model.update({k: mj[k] for k in model if k in mj})
-                r["valu_model"] = "profiles/valu_model.json (calibrated on SQ_INSTS_VALU, same kernel sources)"
-            else:
-                r["valu_model"] = "default constants (profiles/valu_model.json was measured for other kernel sources)"
-        except Exception:
-            pass
+    r["valu_model"] = mnotes["valu_model"]
     b_trav = 0.0
     if cw is not None and cw.num_rays:
         # the counter pass ran one slab: scale its wave-level counts to a mean launch by the ray count
@@ -591,7 +649,7 @@ def roofline(args, stats, steps, cw, peaks, A, n, rps):
                          + cw.wave_refills * model["refill_iter"]) + model["per_cell"] * cells_launch / 64.0
         nodes_per_ray = cw.nodes_visited / cw.num_rays
         tris_per_ray = cw.tris_tested / cw.num_rays
-        b_trav = rays_launch * (nodes_per_ray * 64.0 + tris_per_ray * 24.0)
+        b_trav = rays_launch * (nodes_per_ray * NODE_BYTES + tris_per_ray * 24.0)      # SURVEY 8(d) with this round's node size
         lanes = (cw.nodes_visited + cw.tris_tested / 2.0) / max(64.0 * (cw.wave_node_iters + cw.wave_leaf_iters), 1.0)
         r.update({"nodes_per_ray": nodes_per_ray, "tris_per_ray": tris_per_ray,
                   "valu_winst_per_launch": winst, "valu_model_constants": model, "lane_utilisation_node_leaf_steps": lanes})
@@ -603,17 +661,7 @@ def roofline(args, stats, steps, cw, peaks, A, n, rps):
             # iteration counters x calibrated instructions per iteration x static class mix of the section), peak = the
             # SIMD cycles the launch had.  `frac` is therefore a LOWER bound of the VALU-busy share; with every fast
             # instruction colliding it is frac_uniform_4_cycle (the round-1/2 model).
-            mix = dict(CLASS_MIX_DEFAULT)
-            mix_note = "default class mix"
-            cpath = os.path.join(ROOT, "profiles", "valu_class_mix.json")
-            if os.path.exists(cpath):
-                try:
-                    cj = json.load(open(cpath))
-                    if cj.get("kernel_source_sha") == sha:
-                        mix = {k: cj[k]["fast_fraction"] for k in mix if k in cj}
-                        mix_note = "profiles/valu_class_mix.json (scripts/isa_class_mix.py, same kernel sources)"
-                except Exception:
-                    pass
+            mix, mix_note = mix0, mnotes["class_mix_note"]
             cr = peaks.get("class_rates") or {"fast_cycles": 2.4, "slow_cycles": 4.15}
             cyc = lambda f: f * cr["fast_cycles"] + (1.0 - f) * cr["slow_cycles"]
             cycles_need = scale * (cw.wave_node_iters * model["node_iter"] * cyc(mix["node_step"])
@@ -698,7 +746,7 @@ def run_sharded(ctx, kind):
     warmup = args.warmup if args.warmup is not None else 1
     in0 = in1 = n - 2 * off
     # only the building rank synthesises the DEM; everybody else receives vertices (+ LBVH) in the one broadcast
-    g = synth.fractal_tile(n=n, offset=off) if rank == 0 else None
+    g = synth.fractal_tile(n=n, offset=off, plain_fraction=args.plain_fraction) if rank == 0 else None
     scene, scene_stats, t_build, t_bcast = make_scene(ctx, g, n)
     del g
     blob_ptr, blob_bytes = scene.blob()
@@ -721,10 +769,12 @@ def run_sharded(ctx, kind):
             cache["svf"] = torch.empty((e - b, in1), dtype=torch.float32, device=dev)
         return res
 
-    def run_slab(b, e, st, azim=A, count=False, probe=False):
+    def run_slab(b, e, st, azim=A, count=False, probe=False, mask_override=None):
         if e <= b:
             return torch.full((0, in1), float("nan"), dtype=torch.float32, device=dev)
         norm, north, mask, tilt = slab_inputs(b, e)
+        if mask_override is not None:
+            mask = mask_override
         materialise = c3 and not probe and cache.get("rows") == (b, e)
         svf = cache["svf"] if materialise else torch.empty((e - b, in1), dtype=torch.float32, device=dev)
         svf.fill_(float("nan"))
@@ -748,19 +798,26 @@ def run_sharded(ctx, kind):
         return run_slab(b, e, stats)
 
     # cost of a row: the wave-level VALU work (calibrated instructions per wave iteration x the wave-iteration counters
-    # of the counting instantiation) of the 16-row tile row that holds it, with an eighth of the azimuths.  Full 8 x 8
-    # blocks per wave, as in the real launch: the SIMT cost is what is measured, not lane-level ray / node counts
-    # (round 3: one-row probes with lane counts predicted the slab times WORSE than the plain cell count).
-    a_probe = max(8, (A // 8) // 4 * 4)
+    # of the counting instantiation) of the 16-row tile row that holds it, measured on every 8th 16 x 16 tile of that tile
+    # row with ALL azimuths.  Full 8 x 8 blocks per wave, as in the real launch: the SIMT cost is what is measured, not
+    # lane-level ray / node counts (round 3: one-row probes with lane counts predicted the slab times WORSE than the plain
+    # cell count).  Round 3 probed every cell with an eighth of the azimuths instead: guess_constant then starts every
+    # search 8 sectors away from its last result, which overprices rough terrain against smooth terrain -- on the half-plain
+    # DEM of --plain-fraction it predicted the wrong half to be the expensive one (profiles/r04/).
+    a_probe = A
     probe_s = [0.0]
+    tile_cols = (in1 + 15) // 16
 
     def probe(row):
         t0 = time.perf_counter()
         st = _lib.hz_stats()
         rb = min(row // 16 * 16, max(in0 - 16, 0))
         re = min(rb + 16, in0)
+        pm = torch.zeros((re - rb, tile_cols, 16), dtype=torch.uint8, device=dev)
+        pm[:, (rb // 16) % 8::8, :] = 1                 # every 8th tile of this tile row, staggered from row to row
+        pm = pm.reshape(re - rb, tile_cols * 16)[:, :in1].contiguous()
         saved = dict(cache); cache.clear()             # probe rows are not the slab: do not disturb the resident buffers
-        run_slab(rb, re, st, azim=a_probe, count=True, probe=True)
+        run_slab(rb, re, st, azim=a_probe, count=True, probe=True, mask_override=pm)
         cache.clear(); cache.update(saved)
         probe_s[0] += time.perf_counter() - t0
         m = VALU_MODEL_DEFAULT
@@ -959,9 +1016,9 @@ def run_c4(ctx):
     V = n * n
     out_b = 1 if shadow else 4
     # SURVEY 8(d) "shadow bytes": 12 V + 33 C once at initialise, 1 C (shadow) / 4 C (sw_dir_cor) per sun position;
-    # B_trav = rays x (node visits x 64 B + triangle tests x 24 B) from the counting pass -- served by the caches
+    # B_trav = rays x (node visits x 48 B + triangle tests x 24 B) from the counting pass -- served by the caches
     b_io = S * out_b * cells + (12.0 * V + 33.0 * cells)
-    b_trav = (cw["nodes_visited"] * 64.0 + cw["tris_tested"] * 24.0) if cw else 0.0
+    b_trav = (cw["nodes_visited"] * NODE_BYTES + cw["tris_tested"] * 24.0) if cw else 0.0
     alg = (b_io + b_trav) / k_step / 1e9 if k_step else None
     codes = None
     if shadow:
@@ -980,7 +1037,8 @@ def run_c4(ctx):
         setup = SHADOW_SETUP_WINST[int(bool(args.refrac))]
         n_it, l_it = cw["wave_node_iters"], cw["wave_leaf_iters"]
         rounds = S * cells / 64.0
-        winst = VALU_MODEL_DEFAULT["node_iter"] * n_it + VALU_MODEL_DEFAULT["leaf_iter"] * l_it + setup * rounds
+        vm, vmix, vnotes = load_valu_model()
+        winst = vm["node_iter"] * n_it + vm["leaf_iter"] * l_it + setup * rounds
         roof.update({"nodes_per_ray": cw["nodes_visited"] / max(cw["num_rays"], 1), "tris_per_ray": cw["tris_tested"] / max(cw["num_rays"], 1),
                      "wave_node_iters": n_it, "wave_leaf_iters": l_it,
                      "lane_utilisation_node_leaf_steps": (cw["nodes_visited"] + cw["tris_tested"] / 2.0) / max(64.0 * (n_it + l_it), 1.0),
@@ -989,12 +1047,13 @@ def run_c4(ctx):
         if peaks:
             cr = inst_class_rates(_lib.lib(), ctx["local_rank"])
             cyc = lambda f: f * cr["fast_cycles"] + (1.0 - f) * cr["slow_cycles"]
-            need = (VALU_MODEL_DEFAULT["node_iter"] * n_it * cyc(CLASS_MIX_DEFAULT["node_step"])
-                    + VALU_MODEL_DEFAULT["leaf_iter"] * l_it * cyc(CLASS_MIX_DEFAULT["leaf_step"]) + setup * rounds * cyc(0.7))
+            need = (vm["node_iter"] * n_it * cyc(vmix["node_step"])
+                    + vm["leaf_iter"] * l_it * cyc(vmix["leaf_step"]) + setup * rounds * cyc(0.7))
             have = peaks["simds"] * peaks["clock_ghz"] * 1e9 * k_step
             roof.update({"bound": "valu_issue", "achieved": need / k_step / 1e9, "peak": peaks["simds"] * peaks["clock_ghz"],
                          "unit": "G SIMD-cycles/s (VALU busy)", "frac": need / have,
                          "frac_uniform_4_cycle": 4.0 * winst / have, "class_rates_cycles_per_wave_inst": cr,
+                         "valu_model": vnotes["valu_model"], "valu_model_constants": vm, "class_mix_fast_fraction": vmix,
                          "peak_note": "as for k_horizon (c3 line): SIMD cycles the instructions need at the measured issue rates of "
                                       "the two VALU classes over the SIMD cycles of the launch; a lower bound of the VALU-busy share"})
     if "bound" not in roof:

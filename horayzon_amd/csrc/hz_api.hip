@@ -319,6 +319,63 @@ struct HostPinner {
     ~HostPinner() { finish(); }
 };
 
+// The certificate monitor of opts.verify_near without count_work: see horizon_run.
+struct NearMonitor {
+    int device = 0;
+    hipStream_t st_mon = nullptr;
+    hipEvent_t ready = nullptr, done = nullptr;
+    void *buf = nullptr;
+    unsigned long long *cnt = nullptr;
+    bool active = false;
+    int launch(const Scene *sc, const HorizonArgs &a, int n, int seed, hipStream_t st) {
+        device = sc->device;
+        const int nb = horizon_num_blocks(a);
+        std::vector<int> pick;
+        for (int b = 0; b < nb; b++) {
+            uint32_t h = (uint32_t)b * 2654435761u + (uint32_t)seed * 40503u;
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            if (h % (uint32_t)n == 0u) pick.push_back(b);
+        }
+        if (pick.empty()) return HZ_OK;
+        int rc;
+        if (!st_mon && (rc = stream_acquire(device, &st_mon))) return rc;
+        if (!ready) { HZ_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming)); HZ_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming)); }
+        const size_t cbytes = 24 * sizeof(unsigned long long) + HZ_REDO_CAP * sizeof(int);
+        if (buf) { (void)hipFree(buf); buf = nullptr; }
+        HZ_HIP(hipMalloc(&buf, cbytes + pick.size() * sizeof(int)));
+        cnt = (unsigned long long *)buf;
+        int *d_list = (int *)((char *)buf + cbytes);
+        HZ_HIP(hipEventRecord(ready, st));                    // certificates (and everything enqueued before) are complete
+        HZ_HIP(hipStreamWaitEvent(st_mon, ready, 0));
+        HZ_HIP(hipMemsetAsync(buf, 0, cbytes, st_mon));
+        HZ_HIP(hipMemcpyAsync(d_list, pick.data(), pick.size() * sizeof(int), hipMemcpyHostToDevice, st_mon));
+        HZ_HIP(hipStreamSynchronize(st_mon));                 // `pick` is host memory of this scope; the copy is tiny
+        HorizonArgs v = a;
+        v.count_work = 1; v.verify_near = 1; v.level_stack = 1;
+        v.counters = cnt; v.tile_list = d_list; v.n_list = (int)pick.size();
+        if ((rc = horizon_launch(sc, v, st_mon, nullptr))) return rc;
+        HZ_HIP(hipEventRecord(done, st_mon));
+        active = true;
+        return HZ_OK;
+    }
+    // the production stream waits for the monitor (later kernels read the rows it rewrote); tallies are added up
+    int collect(hipStream_t st, unsigned long long *verified, unsigned long long *violations) {
+        unsigned long long c2[24] = {0};
+        HZ_HIP(hipStreamWaitEvent(st, done, 0));
+        HZ_HIP(hipMemcpyAsync(c2, cnt, sizeof(c2), hipMemcpyDeviceToHost, st_mon));
+        HZ_HIP(hipStreamSynchronize(st_mon));
+        *verified += c2[21]; *violations += c2[10];
+        active = false;
+        return HZ_OK;
+    }
+    ~NearMonitor() {
+        if (st_mon) { (void)hipSetDevice(device); stream_release(device, st_mon); }
+        if (ready) (void)hipEventDestroy(ready);
+        if (done) (void)hipEventDestroy(done);
+        if (buf) (void)hipFree(buf);
+    }
+};
+
 static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_north, int offset_0,
                        int offset_1, float *hori_buffer, int dim_in_0, int dim_in_1, int azim_num,
                        float dist_search, float hori_acc, const char *ray_algorithm,
@@ -485,10 +542,15 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
                           azim_num <= near_max_azim() && tb.elev_num <= 65534;
     a.near_idx = nullptr; a.near_r = nullptr;
     a.tile_list = nullptr; a.n_list = 0;
-    a.verify_near = (opts && opts->verify_near > 0) ? opts->verify_near : 0;
+    // opts.verify_near = N: with count_work the counting instantiation re-traces one of every N shortened rays; without it
+    // the production launch stays as it is and a second, counting launch re-traces EVERY shortened ray of one of every N
+    // 8 x 8 blocks (the monitor for production inputs)
+    const int verify_n = (opts && opts->verify_near > 0) ? opts->verify_near : 0;
+    a.verify_near = (opts && opts->count_work) ? verify_n : 0;
     float ms_near = 0.0f;
 
-    unsigned long long cnt[16] = {0}, n_verified = 0;
+    unsigned long long cnt[16] = {0}, n_verified = 0, n_mon_violations = 0;
+    NearMonitor mon;
     float ms = 0.0f, ms_svf = 0.0f;
     int fallbacks = 0;
     unsigned long long redo_blocks = 0;
@@ -522,8 +584,8 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     unsigned *near_reasons = nullptr;
     struct ReasonsFree { unsigned **p; ~ReasonsFree() { if (*p) (void)hipFree(*p); } } reasons_free{&near_reasons};
     if (use_near && getenv("HZ_NEAR_REASONS")) {
-        if (hipMalloc((void **)&near_reasons, 16 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); near_reasons = nullptr; }
-        else (void)hipMemsetAsync(near_reasons, 0, 16 * sizeof(unsigned), st);
+        if (hipMalloc((void **)&near_reasons, 20 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); near_reasons = nullptr; }
+        else (void)hipMemsetAsync(near_reasons, 0, 20 * sizeof(unsigned), st);
     }
     HostPinner pinner;          // declared after the events: destroyed (joined, unregistered) before them
     if (stream_out && !(opts && opts->no_host_pin)) {
@@ -614,6 +676,13 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             a.level_stack = (sc->level_stack.load(std::memory_order_relaxed) != 0 || (opts && opts->level_stack > 0)) ? 1
                             : ((opts && opts->level_stack < 0) ? opts->level_stack : 0);
             (void)hipEventRecord(e.a, st);
+            if (verify_n > 0 && !a.count_work && use_near) {
+                // monitor: the certificates of a sample of this launch's blocks, checked ray by ray by a counting launch
+                // (every shortened ray traced a second time over its full length) on a stream of its own, so that its few
+                // workgroups run NEXT TO the production launch instead of after it (a launch of its own costs one
+                // workgroup lifetime, ~0.1 s, however small the sample).  It writes the same output values.
+                if ((rc = mon.launch(sc, a, verify_n, rb, st))) return fail(rc);
+            }
             int safe = 0;
             rc = horizon_launch(sc, a, st, &safe);
             if (!rc && !safe) {
@@ -643,6 +712,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
                     }
                 }
             }
+            if (!rc && mon.active) rc = mon.collect(st, &n_verified, &n_mon_violations);
             (void)hipEventRecord(e.b, st);
             if (!rc && want_svf)
                 rc = svf_launch(d_azim.dev, hori_chunk, tilt0 + 3 * (size_t)rb * dim_in_1, re - rb, dim_in_1,
@@ -692,18 +762,18 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         stats->t_total_s += t_total.stop();
         stats->elev_num = tb.elev_num; stats->bvh_height = sc->hdr.height; stats->scene_bytes = sc->hdr.total_bytes;
         stats->stack_fallbacks += (uint64_t)fallbacks; stats->stack_redo_blocks += redo_blocks;
-        stats->rays_shortened += cnt[9]; stats->near_violations += cnt[10]; stats->t_near_s += (double)ms_near * 1e-3;
+        stats->rays_shortened += cnt[9]; stats->near_violations += cnt[10] + n_mon_violations; stats->t_near_s += (double)ms_near * 1e-3;
         stats->guard_cells += cnt[11]; stats->near_verified += n_verified;
         stats->height_field = height_field ? 1 : 0; stats->near_used = use_near ? 1 : 0;
     }
     if (near_reasons) {
-        unsigned h[16] = {0};
+        unsigned h[20] = {0};
         if (hipMemcpy(h, near_reasons, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
             static const char *nm[13] = {"frame", "vertex_on_axis", "edge_over_axis", "az_tolerance", "inplane_edge", "crossing_near_axis",
                                          "interval", "precision", "edge_on", "orientation", "origin_below", "axis_in_triangle", "window_or_mask"};
             fprintf(stderr, "hz near reasons: cells %u certified %u", h[0], h[1]);
             for (int b = 0; b < 13; b++) if (h[2 + b]) fprintf(stderr, " %s %u", nm[b], h[2 + b]);
-            fprintf(stderr, "\n");
+            fprintf(stderr, " | tasks %u bins %u\n", h[16], h[17]);
         }
     }
     if (opts && opts->verbose) {   // the reference's report, horizon_comp.cpp:673-700, 805-810 (same lines, same order)

@@ -57,10 +57,11 @@ struct HorizonParams {
 // LDS: [ per-lane stacks int[depth][256] | output staging float[4][256] | top-of-tree nodelet Node[top_nodes] ]
 // LEVELSTACK: the traversal's stack discipline (hz_common.h).  false = one LDS entry per pending sibling: fewest VALU
 // instructions, `stack_cap` entries, overflow flagged in counters[8]; true = one entry per tree level, cannot overflow.
-// VERIFY: the production kernel with the certificate check compiled in (opts.verify_near without count_work): a sample of the
-// shortened rays is traced a second time from parameter 0 and disagreeing decisions are counted (counters[10], [21]).
-template <int ALG, bool COUNT, bool STAGE, bool NODELET, bool LEVELSTACK, bool VERIFY = false>
-__global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
+// (the counting instantiation carries ~20 more live values: at 5 workgroups per CU it spilled 10 - 22 VGPRs, so it is built
+//  for 4.  Its tallies -- rays, node visits, triangle tests, wave iterations -- are functions of the lanes' states only, not
+//  of the schedule, so they are the production launch's numbers: the ray counts of the two instantiations are compared by the tests.)
+template <int ALG, bool COUNT, bool STAGE, bool NODELET, bool LEVELSTACK>
+__global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : 5) void k_horizon(HorizonParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *stack = reinterpret_cast<int *>(smem);
     const float4 *top = reinterpret_cast<const float4 *>(smem + p.stack_bytes + p.stage_bytes);
@@ -147,10 +148,9 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
     unsigned overflow = 0;   // !LEVELSTACK: a ray needed more stack entries than this launch has (see hz_trace)
     // near-field certificate of this cell (hz_near.hip): rays of azimuth k with a table index >= near_idx[k] clear
     // everything within near_r of the origin and start their box tests at parameter near_r
-    // verify_near (COUNT / VERIFY): a shortened ray that is selected (want_v) is traced a second time over its full length
+    // verify_near (COUNT): a shortened ray that is selected (want_v) is traced a second time over its full length
     // (verifying) and the two decisions are compared.  Lane state is kept in flags only (lane masks in scalar registers)
-    // and the tallies are wave-uniform popcounts: the VERIFY instantiation needs no vector register the production
-    // kernel does not have.
+    // and the tallies are wave-uniform popcounts.
     unsigned shortened = 0;                        // COUNT only
     unsigned w_verified = 0, w_violations = 0;     // wave-uniform
     bool verifying = false, first_result = false, want_v = false;
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
                 tn = 0.0f;
                 if (p.near_idx != nullptr && s.ind >= (int)p.near_idx[(size_t)cert * (size_t)t.azim_num + s.k]) tn = p.near_r[cert];
                 if (COUNT && tn > 0.0f) shortened++;
-                if (COUNT || VERIFY) want_v = p.verify_near && tn > 0.0f && (((rays + cert) & p.verify_mask) == 0u);
+                if (COUNT) want_v = p.verify_near && tn > 0.0f && (((rays + cert) & p.verify_mask) == 0u);
                 rb = hz_raybox(ocx + tn * dx, ocy + tn * dy, ocz + tn * dz, dx, dy, dz);
                 hz_trav_reset(ts);
                 // a ray below the previous azimuth's horizon is expected to be blocked near the same ridge
@@ -190,18 +190,18 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
                                                  dx, dy, dz, tfar, rb, ts, p.regroup, p.leaf_bias, tc, p.stack_cap, overflow);
             if (r == 0 && second) {                      // nothing in the cached subtree: full traversal
                 second = false; hz_trav_reset(ts);
-            } else if ((COUNT || VERIFY) && want_v && r != 2) {
+            } else if (COUNT && want_v && r != 2) {
                 // the shortened ray is done: trace it again over its full length and compare the decisions
                 want_v = false; verifying = true; first_result = (r == 1); start_v = true;
                 rb = hz_raybox(ocx, ocy, ocz, dx, dy, dz);
                 hz_trav_reset(ts);
             } else if (r != 2) {
-                if ((COUNT || VERIFY) && verifying) { viol = ((r == 1) != first_result); verifying = false; }
+                if (COUNT && verifying) { viol = ((r == 1) != first_result); verifying = false; }
                 ray_active = false; last_hit = (r == 1);
                 if (r == 1) cache = p.sv.anc[HZ_LEAF_ID(ts.lq0)];   // ts.lq0 is the leaf that blocked the ray
             }
         }
-        if (COUNT || VERIFY) {
+        if (COUNT) {
             w_verified += (unsigned)__popcll(__ballot(start_v));
             w_violations += (unsigned)__popcll(__ballot(viol));
         }
@@ -245,7 +245,7 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
             atomicMax(&p.counters[20], ~t_start);
         }
     }
-    if (COUNT || VERIFY) {
+    if (COUNT) {
         unsigned long long sh = shortened;
         for (int off = 32; off > 0; off >>= 1) sh += __shfl_xor(sh, off);
         if (lane == 0) {
@@ -256,11 +256,11 @@ __global__ __launch_bounds__(HZ_TPB, 5) void k_horizon(HorizonParams p) {
     }
 }
 
-template <int ALG, bool COUNT, bool STAGE, bool NODELET, bool LEVELSTACK, bool VERIFY = false>
+template <int ALG, bool COUNT, bool STAGE, bool NODELET, bool LEVELSTACK>
 static int launch_one(const HorizonParams &p, int grid, size_t lds, hipStream_t st) {
-    HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_horizon<ALG, COUNT, STAGE, NODELET, LEVELSTACK, VERIFY>),
+    HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_horizon<ALG, COUNT, STAGE, NODELET, LEVELSTACK>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_horizon<ALG, COUNT, STAGE, NODELET, LEVELSTACK, VERIFY>), dim3(grid), dim3(HZ_TPB), lds, st, p);
+    hipLaunchKernelGGL((k_horizon<ALG, COUNT, STAGE, NODELET, LEVELSTACK>), dim3(grid), dim3(HZ_TPB), lds, st, p);
     HZ_HIP(hipGetLastError());
     return HZ_OK;
 }
@@ -268,12 +268,11 @@ static int launch_one(const HorizonParams &p, int grid, size_t lds, hipStream_t 
 template <int ALG>
 static int launch_alg(const HorizonParams &p, int grid, size_t lds, bool count, bool level_stack, hipStream_t st) {
     const bool stage = p.stage_bytes != 0;
-    if (ALG == ALG_GUESS && !count && p.top_nodes > 0)      // opt-in LDS nodelet variant (opts.top_nodes > 0)
+    if (ALG == ALG_GUESS && !count && p.top_nodes > 0) {    // opt-in LDS nodelet variant (opts.top_nodes > 0)
+        if (!level_stack) return stage ? launch_one<ALG_GUESS, false, true, true, false>(p, grid, lds, st)
+                                       : launch_one<ALG_GUESS, false, false, true, false>(p, grid, lds, st);
         return stage ? launch_one<ALG_GUESS, false, true, true, true>(p, grid, lds, st)
                      : launch_one<ALG_GUESS, false, false, true, true>(p, grid, lds, st);
-    if (!count && p.verify_near) {                          // production kernel + sampled certificate check
-        if (level_stack) return stage ? launch_one<ALG, false, true, false, true, true>(p, grid, lds, st) : launch_one<ALG, false, false, false, true, true>(p, grid, lds, st);
-        return stage ? launch_one<ALG, false, true, false, false, true>(p, grid, lds, st) : launch_one<ALG, false, false, false, false, true>(p, grid, lds, st);
     }
     if (level_stack) {
         if (count) return stage ? launch_one<ALG, true, true, false, true>(p, grid, lds, st) : launch_one<ALG, true, false, false, true>(p, grid, lds, st);
@@ -281,6 +280,14 @@ static int launch_alg(const HorizonParams &p, int grid, size_t lds, bool count, 
     }
     if (count) return stage ? launch_one<ALG, true, true, false, false>(p, grid, lds, st) : launch_one<ALG, true, false, false, false>(p, grid, lds, st);
     return stage ? launch_one<ALG, false, true, false, false>(p, grid, lds, st) : launch_one<ALG, false, false, false, false>(p, grid, lds, st);
+}
+
+// 8 x 8 blocks (workgroup number * 4 + wave) a full launch over the rows of `a` numbers: the domain of HorizonArgs::tile_list
+int horizon_num_blocks(const HorizonArgs &a) {
+    const int rows = a.row_end - a.row_begin;
+    if (rows <= 0 || a.dim_in_1 <= 0) return 0;
+    const TileMap tm = make_tile_map((rows + 15) / 16, (a.dim_in_1 + 15) / 16);
+    return tm.per_xcd * 8 * 4;
 }
 
 int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *used_level_stack) {
@@ -309,8 +316,11 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
     const int stage = ((a.azim_num & 3) == 0 && (reinterpret_cast<size_t>(a.hori) & 15) == 0) ? 4 * HZ_TPB * 4 : 0;
     const int height = std::max(sc->hdr.height, 1);
     // (a.level_stack < 0: test hook, the fast discipline with that many entries)
-    const int fast_cap = a.level_stack < 0 ? std::max(-a.level_stack, 3) : std::max((31 * 1024 - stage) / (HZ_TPB * 4), 3);
-    const bool level_stack = a.level_stack > 0 || (a.top_nodes > 0 && a.alg == ALG_GUESS && !a.count_work);
+    // (with the opt-in LDS nodelet the fast stack gives up the entries the nodelet's bytes need, so that 5 workgroups stay resident)
+    const int want_top = (a.top_nodes > 0 && a.alg == ALG_GUESS && !a.count_work) ? std::min(a.top_nodes, sc->hdr.n_top) : 0;
+    const int fast_cap = a.level_stack < 0 ? std::max(-a.level_stack, 3)
+                                           : std::max((31 * 1024 - stage - want_top * (int)sizeof(Node)) / (HZ_TPB * 4), 3);
+    const bool level_stack = a.level_stack > 0;
     const int depth = level_stack ? height : std::min(fast_cap, 3 * height);
     if (used_level_stack) *used_level_stack = (level_stack || depth >= 3 * height) ? 1 : 0;   // 1: cannot overflow
     p.stack_cap = depth;
@@ -324,10 +334,10 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
     top = std::min(top, sc->hdr.n_top);
     p.top_nodes = top;
     // defaults from the sweep on the 3601^2 tile: refill when fewer than 40 lanes
-    // are traversing; leaf step when 20 n_leaf > 16 n_node.  opts.regroup = threshold | bias << 8.
+    // are traversing; leaf step when 24 n_leaf > 16 n_node.  opts.regroup = threshold | bias << 8.
     // (<= 0: the default -- a zeroed hz_opts must not switch the ray compaction off: 2.9 s instead of 2.15 s per tile)
     p.regroup = (a.regroup <= 0) ? 40 : std::min(a.regroup & 0xff, 64);
-    p.leaf_bias = (a.regroup >= 256) ? (a.regroup >> 8) : 20;
+    p.leaf_bias = (a.regroup >= 256) ? (a.regroup >> 8) : 24;      // (20 until round 4: re-swept after the node step lost 18 instructions, profiles/r04/regroup_sweep.log)
     p.hit_cache = (a.hit_cache != 0) ? 1 : 0;
     p.near_idx = a.near_idx; p.near_r = a.near_r;
     p.verify_near = (a.verify_near > 0 && a.near_idx != nullptr) ? 1 : 0;

@@ -127,8 +127,7 @@ struct HorizonArgs {
     int n_list;                          //   the full launch * 4 + wave) to compute: the blocks whose fast stack overflowed
     const unsigned short *near_idx;      // near-field certificates of rows [row_begin, row_end) (hz_near.hip) or null
     const float *near_r;
-    int verify_near;                     // N >= 1: re-trace one of every N shortened rays from parameter 0 (1: all; with count_work
-                                         //   the counting instantiation, else the production kernel with the check compiled in)
+    int verify_near;                     // counting instantiation: N >= 1 re-traces one of every N shortened rays from parameter 0 (1: all)
     unsigned long long *counters;        // device u64[24] + int[HZ_REDO_CAP] (tiles to redo, count in [8]): [0] rays, [1] guards, [2] nodes, [3] tris, [4] cells,
                                          // [5..7] wave iterations, [8] waves whose fast-discipline stack overflowed,
                                          // [9] rays shortened by a certificate, [10] certificate violations (verify), [11] cells with a guard event,
@@ -136,6 +135,7 @@ struct HorizonArgs {
 };
 #define HZ_REDO_CAP 16384                // 8 x 8 blocks of one launch that can be repeated one by one after a stack overflow
 int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *used_level_stack = nullptr);
+int horizon_num_blocks(const HorizonArgs &a);
 int topo_launch(int kind, const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
                 int len_2, float *out, hipStream_t st);
 int svf_launch(const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
@@ -150,7 +150,7 @@ struct NearArgs {
     float ray_org_elev, hori_acc, low, up;   // radians / metres
     unsigned short *near_idx;            // out [rows * dim_in_1][azim_num]
     float *near_r;                       // out [rows * dim_in_1]
-    unsigned *reasons = nullptr;         // debug: device u32[16] histogram of refusals (hz_near.hip), or null
+    unsigned *reasons = nullptr;         // debug: device u32[20] histogram of refusals (hz_near.hip), or null
 };
 int near_launch(const Scene *sc, const NearArgs &a, hipStream_t st);
 int near_max_azim();

@@ -51,7 +51,7 @@ struct NearParams {
     float ray_org_elev, low, step, up, pad;
     unsigned short *near_idx;          // [n_cells][azim_num]
     float *near_r;                     // [n_cells]
-    unsigned *reasons;                 // null, or 16 counters: [0] cells, [1] with a certificate, [2 + b] refused for reason bit b
+    unsigned *reasons;                 // null, or 20 counters: [0] cells, [1] with a certificate, [2 + b] refused for reason bit b, [16] tasks, [17] bins
 };
 
 // why a cell gets no certificate (bits of the per-wave flag word; HZ_NEAR_REASONS=1 prints the histogram of a call)
@@ -63,18 +63,26 @@ enum { HZ_NR_FRAME = 1, HZ_NR_VERTEX_ON_AXIS = 2, HZ_NR_EDGE_OVER_AXIS = 4, HZ_N
 __device__ __forceinline__ int f2o(float f) { const int i = __float_as_int(f); return i >= 0 ? i : (i ^ 0x7fffffff); }
 __device__ __forceinline__ float o2f(int i) { return __int_as_float(i >= 0 ? i : (i ^ 0x7fffffff)); }
 
+#define HZ_NEAR_MAXT 256      // tasks of the edge phase per cell (<= 255 edges, task numbers in bytes)
+template <int W>
+__host__ __device__ constexpr int near_per_wave_words(int A) {
+    constexpr int NV = 2 * W + 1, NVERT = NV * NV, NEDGE = 2 * NV * (NV - 1) + (NV - 1) * (NV - 1);
+    return NVERT * 5 + A + 4 + 2 * NEDGE + NEDGE + 1 + 10 * NEDGE + HZ_NEAR_MAXT / 4;
+}
+
 template <int W>
 __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
     constexpr int NV = 2 * W + 1, NVERT = NV * NV, CENTRE = W * NV + W;
     constexpr int NHOR = NV * (NV - 1), NDIAG = (NV - 1) * (NV - 1), NEDGE = 2 * NHOR + NDIAG;
     constexpr int NSEG = 8 * W;        // boundary segments of the window polygon
     static_assert(NVERT <= 64 && NSEG <= 64, "one lane per window vertex / boundary segment");
-    constexpr int CH = 16;             // azimuths per task of the edge phase
+    constexpr int NEC = 10;            // per-edge constants kept in LDS: a_e a_n a_z b_e b_n b_z r_a r_b x_a x_b
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_near[];
     const int A = p.azim_num;
     // LDS: [ sin phi_k, cos phi_k : 2 A floats, shared ] then per wave
-    //      [ q: NVERT x 5 | E: A | flags: 4 | first azimuth bin, bins per edge: 2 NEDGE | task prefix: NEDGE + 1 ]
-    const int per_wave = NVERT * 5 + A + 4 + 2 * NEDGE + NEDGE + 1;
+    //      [ q: NVERT x 5 | E: A | flags: 4 | first azimuth bin, bins per edge: 2 NEDGE | task prefix: NEDGE + 1 |
+    //        edge constants: NEC x NEDGE | task -> edge map: HZ_NEAR_MAXT bytes ]
+    const int per_wave = near_per_wave_words<W>(A);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float *tab = reinterpret_cast<float *>(smem_near);
     float *q = tab + 2 * A + (size_t)wave * per_wave;               // [NVERT][5]: e, n, z, world dx, dy
@@ -82,6 +90,8 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
     int *flags = E + A;                                             // [0]: certificate unusable
     int *ek = flags + 4;                                            // [NEDGE][2]
     int *pre = ek + 2 * NEDGE;                                      // [NEDGE + 1]
+    float *ec = reinterpret_cast<float *>(pre + NEDGE + 1);         // [NEDGE][NEC]
+    unsigned char *tmap = reinterpret_cast<unsigned char *>(ec + NEC * NEDGE);   // [HZ_NEAR_MAXT]
     for (int k = threadIdx.x; k < A; k += 256) { tab[k] = p.azim_sin[k]; tab[A + k] = p.azim_cos[k]; }
     const int cl = blockIdx.x * 4 + wave;                           // cell of this wave (launch local)
     const bool have = cl < p.n_cells;
@@ -126,17 +136,18 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
         else if (e < 2 * NHOR) { const int f = e - NHOR, r = f / NV, c = f % NV; ia = r * NV + c; ib = ia + NV; }
         else { const int f = e - 2 * NHOR, r = f / (NV - 1), c = f % (NV - 1); ia = r * NV + c + 1; ib = (r + 1) * NV + c; }   // (i, j+1) - (i+1, j)
     };
-    // ---- edges, phase 1: the azimuth bins each edge spans; tasks of CH bins, prefix-summed over the edges -----------
-    int carry = 0;
+    // ---- edges, phase 1: per edge the azimuth bins it spans and the constants phase 2 needs (once per edge, in LDS) ------
+    static_assert(NEDGE <= 255, "edge numbers travel in bytes");
+    int bins_total = 0;
     for (int e0 = 0; e0 < NEDGE; e0 += 64) {
         const int e = e0 + lane;
-        int tasks = 0;
+        int k_lo = 0, bins = 0;
         if (valid && e < NEDGE) {
             int ia, ib;
             edge_ends(e, ia, ib);
-            int k_lo = 0, bins = 0;
             if (ia != CENTRE && ib != CENTRE) {                      // spokes: see the header
-                const float ae = q[5 * ia], an = q[5 * ia + 1], be = q[5 * ib], bn = q[5 * ib + 1];
+                const float ae = q[5 * ia], an = q[5 * ia + 1], az = q[5 * ia + 2];
+                const float be = q[5 * ib], bn = q[5 * ib + 1], bz = q[5 * ib + 2];
                 const float ra = __builtin_sqrtf(ae * ae + an * an), rb = __builtin_sqrtf(be * be + bn * bn);
                 const float rmin = __builtin_fminf(ra, rb);
                 if (!(rmin > 1.0e-3f)) atomicOr(&flags[0], HZ_NR_VERTEX_ON_AXIS);                 // a vertex (almost) above / below the origin
@@ -152,37 +163,54 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
                         // (grids with centimetre spacing: the tolerance would span a large part of the circle and the
                         //  bins would leave the (-A, 2 A) range phase 2 wraps once -- no certificate for such a cell)
                         if (m_az > 0.25f) atomicOr(&flags[0], HZ_NR_AZ_TOLERANCE);
-                        k_lo = (int)__builtin_floorf((lo - m_az) / dphi);
-                        bins = (int)__builtin_ceilf((lo + span + m_az) / dphi) - k_lo + 1;
-                        if (m_az > 0.25f) bins = 0;
-                        tasks = (bins + CH - 1) / CH;
+                        else {
+                            k_lo = (int)__builtin_floorf((lo - m_az) / dphi);
+                            bins = (int)__builtin_ceilf((lo + span + m_az) / dphi) - k_lo + 1;
+                            // an end point that lies in the plane (|d| <= tol) is seen at r in [r sqrt(1 - (tol / r)^2), r]:
+                            // the larger of z / r over that range, once per edge (tol / r <= 0.126 because m_az <= 0.25)
+                            const float ta = (1.0e-3f * ra + 0.01f) / ra, tb = (1.0e-3f * rb + 0.01f) / rb;
+                            float *c = ec + NEC * e;
+                            c[0] = ae; c[1] = an; c[2] = az; c[3] = be; c[4] = bn; c[5] = bz; c[6] = ra; c[7] = rb;
+                            c[8] = az > 0.0f ? az / (ra * __builtin_sqrtf(1.0f - ta * ta)) : az / ra;
+                            c[9] = bz > 0.0f ? bz / (rb * __builtin_sqrtf(1.0f - tb * tb)) : bz / rb;
+                        }
                     }
                 }
             }
             ek[2 * e] = k_lo; ek[2 * e + 1] = bins;
         }
+        bins_total += bins;
+    }
+    for (int off = 32; off > 0; off >>= 1) bins_total += __shfl_xor(bins_total, off);
+    // Tasks of CH consecutive bins of one edge, one lane per task.  CH is chosen per cell so that the tasks fill two
+    // rounds of the wave (<= 128 + one ragged task per edge): with a fixed CH = 16 (rounds 2-3) most cells had 70 ... 150
+    // tasks, i.e. a nearly empty second or third round of 16 iterations each.
+    const int CH = max(4, (bins_total + 99) / 100);
+    int carry = 0;
+    for (int e0 = 0; e0 < NEDGE; e0 += 64) {
+        const int e = e0 + lane;
+        const int tasks = (valid && e < NEDGE) ? (ek[2 * e + 1] + CH - 1) / CH : 0;
         int inc = tasks;                                             // inclusive scan over the wave
         for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(inc, off); if (lane >= off) inc += v; }
-        if (e < NEDGE) pre[e] = carry + inc - tasks;
+        const int start = carry + inc - tasks;
+        if (e < NEDGE) pre[e] = start;
+        for (int t = 0; t < tasks; t++) if (start + t < HZ_NEAR_MAXT) tmap[start + t] = (unsigned char)e;   // task -> edge
         carry += __shfl(inc, 63);
     }
-    if (lane == 0) pre[NEDGE] = carry;
+    if (carry > HZ_NEAR_MAXT && lane == 0) atomicOr(&flags[0], HZ_NR_AZ_TOLERANCE);   // (cannot happen for A <= 2048: refusal, not an error)
+    if (p.reasons != nullptr && valid && lane == 0) { atomicAdd(&p.reasons[17], (unsigned)bins_total); atomicAdd(&p.reasons[16], (unsigned)carry); }
     // (everything below the azimuth table is private to the wave: its LDS instructions execute in program order, so a
     //  fence against compiler reordering is enough and the four cells of a workgroup need not wait for each other)
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
     // ---- edges, phase 2: one task = one edge x <= CH azimuths; where does the edge cross those vertical planes? ------
     if (valid) {
-        const int n_task = pre[NEDGE];
+        const int n_task = min(carry, HZ_NEAR_MAXT);
         for (int c = lane; c < n_task; c += 64) {
-            int lo_e = 0, hi_e = NEDGE;                              // last edge with pre[e] <= c
-            while (hi_e - lo_e > 1) { const int mid = (lo_e + hi_e) >> 1; if (pre[mid] <= c) lo_e = mid; else hi_e = mid; }
-            const int e = lo_e;
-            int ia, ib;
-            edge_ends(e, ia, ib);
-            const float ae = q[5 * ia], an = q[5 * ia + 1], az = q[5 * ia + 2];
-            const float be = q[5 * ib], bn = q[5 * ib + 1], bz = q[5 * ib + 2];
-            const float ra = __builtin_sqrtf(ae * ae + an * an), rb = __builtin_sqrtf(be * be + bn * bn);
+            const int e = (int)tmap[c];
+            const float *cc = ec + NEC * e;
+            const float ae = cc[0], an = cc[1], az = cc[2], be = cc[3], bn = cc[4], bz = cc[5], ra = cc[6], rb = cc[7];
+            const float xa = cc[8], xb = cc[9];
             const float rmin = __builtin_fminf(ra, rb);
             const float tol_a = 1.0e-3f * ra + 0.01f, tol_b = 1.0e-3f * rb + 0.01f;
             const int first = ek[2 * e] + (c - pre[e]) * CH, last = min(first + CH, ek[2 * e] + ek[2 * e + 1]);
@@ -190,11 +218,6 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
             // absolute error bounds of the interpolated (r, z) of a crossing: the window coordinates q carry ~3 roundings of
             // magnitude <= 2^-24 |q| each, the interpolation two more (term C)
             const float er = 6.0e-7f * (ra + rb), ez = 6.0e-7f * ((__builtin_fabsf(az) + __builtin_fabsf(bz)) + (ra + rb));
-            // an end point that lies in the plane (|d| <= tol) is seen at r in [ra sqrt(1 - (tol / ra)^2), ra]: the larger
-            // of z / r over that range, once per task instead of a division per azimuth (tol / ra <= 0.126: m_az <= 0.25)
-            const float ta = tol_a / ra, tb = tol_b / rb;
-            const float xa = az > 0.0f ? az / (ra * __builtin_sqrtf(1.0f - ta * ta)) : az / ra;
-            const float xb = bz > 0.0f ? bz / (rb * __builtin_sqrtf(1.0f - tb * tb)) : bz / rb;
             const float dz = bz - az;
             const float ninf = -__builtin_inff();
             for (int kk = first; kk < last; kk++) {
@@ -343,9 +366,8 @@ int near_launch(const Scene *sc, const NearArgs &a, hipStream_t st) {
     p.pad = sc->hdr.pad;
     p.near_idx = a.near_idx; p.near_r = a.near_r; p.reasons = a.reasons;
     if (p.n_cells <= 0) return HZ_OK;
-    constexpr int NVERT = (2 * HZ_NEAR_W + 1) * (2 * HZ_NEAR_W + 1);
-    constexpr int NV = 2 * HZ_NEAR_W + 1, NEDGE = 2 * NV * (NV - 1) + (NV - 1) * (NV - 1);
-    const size_t lds = ((size_t)2 * a.azim_num + (size_t)4 * (NVERT * 5 + a.azim_num + 4 + 3 * NEDGE + 1)) * sizeof(float);
+    const size_t lds = ((size_t)2 * a.azim_num + (size_t)4 * near_per_wave_words<HZ_NEAR_W>(a.azim_num)) * sizeof(float);
+    HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_near_cert<HZ_NEAR_W>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     const int grid = (p.n_cells + 3) / 4;
     hipLaunchKernelGGL(k_near_cert<HZ_NEAR_W>, dim3(grid), dim3(256), lds, st, p);
     HZ_HIP(hipGetLastError());

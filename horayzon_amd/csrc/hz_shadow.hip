@@ -13,7 +13,7 @@ namespace hz {
 
 #define HZ_TPB 256
 #ifndef HZ_SHADOW_LEAF_BIAS
-#define HZ_SHADOW_LEAF_BIAS 20   // node step when 16 * n_node >= bias * n_leaf (hz_trace)
+#define HZ_SHADOW_LEAF_BIAS 24   // node step when 16 * n_node >= bias * n_leaf (hz_trace); 20 until round 4 (profiles/r04/shadow_leaf_bias.log)
 #endif
 
 struct ShadowParams {

@@ -54,21 +54,23 @@ def sample_rows(n_rows, n_samples):
     return np.unique(np.clip(idx, 0, n_rows - 1))
 
 
-def estimate_row_cost(mask_or_rows, probe, *, samples=32, group=None):
+def estimate_row_cost(mask_or_rows, probe, *, samples=32, group=None, refine=3, refine_ratio=1.5, min_gap=16):
     """Per-row cost weights for ``row_slabs(..., cost=...)`` from a cheap sampled pre-pass.
 
     ``probe(row) -> float`` measures the cost of ONE inner-domain row (e.g. weighted node visits / triangle tests /
-    rays of a one-row ``count_work`` call with a reduced azimuth count; any unit).  The ``samples`` probe rows are
-    split over the ranks of ``group`` (rank r takes samples r, r + world, ...; one small all_gather joins them; no
+    rays of a ``count_work`` call on a sample of the row's tiles; any unit).  The ``samples`` probe rows are
+    split over the ranks of ``group`` (rank r takes samples r, r + world, ...; one small all_reduce joins them; no
     process group: this process probes all of them), converted to a cost per cell, interpolated linearly between the
-    sampled rows and multiplied by every row's cell count.  Deterministic on every rank: all ranks derive the same
-    slabs without exchanging them."""
+    sampled rows and multiplied by every row's cell count.  ``refine`` rounds of bisection follow: wherever two
+    neighbouring samples differ by more than ``refine_ratio`` in cost per cell (and are more than ``min_gap`` rows apart)
+    the row half way between them is probed as well -- a cliff between a plain and high relief is a band of rows that
+    costs ten times its surroundings, and evenly spaced samples step over it (bench.py --plain-fraction, round 4).
+    Deterministic on every rank: all ranks derive the same probe rows and the same slabs without exchanging them."""
     if np.ndim(mask_or_rows) == 0:
         cells = np.ones(int(mask_or_rows), np.float64)
     else:
         cells = (np.asarray(mask_or_rows) == 1).sum(axis=1).astype(np.float64)
     n = cells.shape[0]
-    rows = sample_rows(n, samples)
     rank, world, dist = 0, 1, None
     try:
         import torch.distributed as dist
@@ -76,17 +78,38 @@ def estimate_row_cost(mask_or_rows, probe, *, samples=32, group=None):
             rank, world = dist.get_rank(group), dist.get_world_size(group)
     except ImportError:
         dist = None
-    local = np.zeros(rows.shape[0], np.float64)
-    for k in range(rank, rows.shape[0], world):
-        local[k] = float(probe(int(rows[k])))
-    if world > 1:
-        import torch
-        t = torch.from_numpy(local)
-        if dist.get_backend(group) != "gloo":
-            t = t.cuda()
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)     # disjoint supports: the sum joins the shares
-        local = t.cpu().numpy()
-    per_cell = local / np.maximum(cells[rows], 1.0)
+
+    def measure(rows):
+        """cost of the given rows, the probes split over the ranks"""
+        local = np.zeros(rows.shape[0], np.float64)
+        for k in range(rank, rows.shape[0], world):
+            local[k] = float(probe(int(rows[k])))
+        if world > 1:
+            import torch
+            t = torch.from_numpy(local)
+            if dist.get_backend(group) != "gloo":
+                t = t.cuda()
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)     # disjoint supports: the sum joins the shares
+            local = t.cpu().numpy()
+        return local
+
+    rows = sample_rows(n, samples)
+    cost = measure(rows)
+    for _ in range(max(int(refine), 0)):
+        per_cell = cost / np.maximum(cells[rows], 1.0)
+        new = []
+        for a in range(rows.shape[0] - 1):
+            lo, hi = sorted((per_cell[a], per_cell[a + 1]))
+            if rows[a + 1] - rows[a] > min_gap and hi > 0 and (lo <= 0 or hi / lo > refine_ratio):
+                new.append((int(rows[a]) + int(rows[a + 1])) // 2)
+        new = np.array(sorted(set(new) - set(rows.tolist())), np.int64)
+        if new.size == 0:
+            break
+        c_new = measure(new)
+        order = np.argsort(np.concatenate([rows, new]), kind="stable")
+        rows = np.concatenate([rows, new])[order]
+        cost = np.concatenate([cost, c_new])[order]
+    per_cell = cost / np.maximum(cells[rows], 1.0)
     ok = cells[rows] > 0
     if not ok.any() or not (per_cell[ok] > 0).any():
         return cells                                              # nothing measured: fall back to the cell count

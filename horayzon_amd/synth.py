@@ -73,10 +73,21 @@ def fractal_elevation(n0, n1, hurst=0.8, seed=20220621, z_min=200.0, z_max=4000.
     return np.rint(z_min + (z_max - z_min) * f).astype(np.float32)
 
 
-def fractal_tile(n=3601, offset=16, seed=20220621, dy=30.87, dx=21.44):
+def fractal_tile(n=3601, offset=16, seed=20220621, dy=30.87, dx=21.44, plain_fraction=0.0):
     """Config 3 input (planar variant): n x n 1-arc-second tile at 46 deg N,
-    rows run north -> south (y decreasing), like a DEM raster."""
+    rows run north -> south (y decreasing), like a DEM raster.  ``plain_fraction`` > 0 scales the relief of that share
+    of the rows (the northern ones) down to 3 % -- rolling lowland next to high relief, with a smooth ramp over a tenth of
+    the rows between them (a vertical step instead would put a 3 km wall next to the plain: the cells at its foot then
+    need hundreds of rays per azimuth and their one workgroup, not the slab split, decides the run time of a small job,
+    profiles/r04/half_plain_dem_slab_costs.jsonl) -- a deliberately inhomogeneous DEM for the load-balance experiments
+    of bench.py."""
     z = fractal_elevation(n, n, seed=seed)
+    if plain_fraction > 0.0:
+        r = np.arange(n, dtype=np.float64) / max(n - 1, 1)
+        t = np.clip((r - (min(plain_fraction, 1.0) - 0.05)) / 0.1, 0.0, 1.0)
+        w = 0.03 + 0.97 * (3.0 * t * t - 2.0 * t * t * t)              # smoothstep from the lowland to the mountains
+        zmin = float(z.min())
+        z = np.rint(zmin + (z - zmin) * w[:, None]).astype(np.float32)
     x = (np.arange(n, dtype=np.float64) * dx - 0.5 * (n - 1) * dx).astype(np.float32)
     y = (0.5 * (n - 1) * dy - np.arange(n, dtype=np.float64) * dy).astype(np.float32)
     xx, yy = np.meshgrid(x, y)

@@ -67,11 +67,13 @@ typedef struct hz_opts {
                            /*   parameter 0.  Results are the same either way; the default (0) is faster and is only   */
                            /*   active for a DEM mesh that IS a height field over the world (x, y) plane (checked by   */
                            /*   the scene build, hz_stats.height_field); -1 (tests): certificates even if it is not    */
-    int32_t verify_near;   /* N >= 1: re-trace one of every N shortened rays (N rounded up to a power of two; 1: every  */
-                           /*   one) over its full length and count disagreeing hit decisions in                        */
-                           /*   hz_stats.near_violations (must stay 0; near_verified = rays checked).  With count_work   */
-                           /*   the counting instantiation does it; without, the production kernel with the check       */
-                           /*   compiled in -- N = 256 monitors real inputs at < 0.5 % of the run time                   */
+    int32_t verify_near;   /* N >= 1: check the near-field certificates while computing; disagreeing hit decisions are   */
+                           /*   counted in hz_stats.near_violations (must stay 0), the rays checked in near_verified.    */
+                           /*   With count_work: the counting instantiation traces one of every N shortened rays (N       */
+                           /*   rounded up to a power of two; 1: every one) a second time over its full length.  Without: */
+                           /*   the production launch is untouched and a second, counting launch re-traces EVERY          */
+                           /*   shortened ray of one of every N 8 x 8 blocks of cells, next to it on a stream of its own --  */
+                           /*   N = 256 monitors real inputs for 2 - 3 % of the run time (profiles/r04/)                  */
     int32_t inputs_are_slab; /* 0: vec_norm, vec_north, mask (and opts.vec_tilt) address inner-domain row 0 (reference   */
                            /*   layout; only the slab's rows are read or uploaded); 1: they address row_begin, i.e. the */
                            /*   caller holds only its slab [row_end - row_begin][dim_in_1] of each -- the form for a    */

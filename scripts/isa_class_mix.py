@@ -8,8 +8,8 @@ min / max / min3 / max3, compares, v_lshl_add_*, 64-bit integer, FP64) every ~4.
 prices the kernel against the time its instructions need at those rates; this script counts, from the compiler's
 assembly, how many instructions of each class one node step / leaf step / refill contains.
 
-Sections are found from the hand-written load blocks: the node step starts at the asm block with four
-global_load_dwordx4 (hz_load_node) and ends at the one with three (hz_load_prim), the leaf step runs from there to the
+Sections are found from the hand-written load blocks: the node step starts at the first asm block with three
+global_load_dwordx4 (hz_load_node) and ends at the second one (hz_load_prim), the leaf step runs from there to the
 end of the kernel's main loop, the refill section is what precedes the node step inside that loop.
 usage: python scripts/isa_class_mix.py   (needs hipcc; writes profiles/valu_class_mix.json)"""
 import json
@@ -26,7 +26,7 @@ FAST = ("v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_add_f32", "v_sub_f32", "v_sub
         "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_add_co_u32",
         "v_addc_co_u32", "v_sub_co_u32", "v_subb_co_u32", "v_cndmask_b32", "v_lshlrev_b32", "v_lshrrev_b32",
         "v_ashrrev_i32", "v_bfe_u32", "v_bfe_i32", "v_and_or_b32", "v_or3_b32", "v_mul_u32_u24", "v_mad_u32_u24")
-KERNEL = "_ZN2hz9k_horizonILi2ELb0ELb1ELb0ELb0ELb0EEEvNS_13HorizonParamsE"
+KERNEL = "_ZN2hz9k_horizonILi2ELb0ELb1ELb0ELb0EEEvNS_13HorizonParamsE"
 
 
 def classify(lines):
@@ -94,8 +94,8 @@ def main():
             blocks.append((i, j, sum("global_load_dwordx4" in x for x in k[i:j])))
             i = j
         i += 1
-    node = next(x for x in blocks if x[2] == 4)
-    leaf = next(x for x in blocks if x[2] == 3 and x[0] > node[0])
+    node = next(x for x in blocks if x[2] == 3)                      # 48 B node: three 16 B loads (round 4; four before)
+    leaf = next(x for x in blocks if x[2] == 3 and x[0] > node[0])   # 48 B leaf record
     # main loop: the innermost loop header before the node block ... the last backward branch after the leaf block
     hdr = max(i for i in range(node[0]) if "=>This Inner Loop Header" in k[i] or "Inner Loop Header" in k[i])
     outer = max(i for i in range(hdr) if "Loop Header" in k[i] and i != hdr) if any("Loop Header" in k[i] for i in range(hdr)) else hdr

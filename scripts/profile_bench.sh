@@ -10,19 +10,20 @@ mkdir -p $R/gpurun_out
 cd /tmp
 # kernel trace + stats of the timed launches (whole tile per launch).  --no-e2e: the untimed drop-in call at the end of
 # the default command launches the same kernel on 5 chunks of rows, which would mix into the per-kernel average; the
-# default command (with it) is traced as well, into ${P}_kte
+# default command (with it and with the untimed extras except config 5: binary_search, discrete_sampling, the curved tile, c4)
+# is traced as well, into ${P}_kte -- its per-kernel table is the rocprofv3 evidence for the ALG 0 / 1 instantiations
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${P}_kt -- \
-    python $R/bench.py --no-cpu-baseline --no-e2e > $R/gpurun_out/${P}_kt_bench.json 2> $R/gpurun_out/${P}_kt.err
+    python $R/bench.py --no-cpu-baseline --no-e2e --no-extras > $R/gpurun_out/${P}_kt_bench.json 2> $R/gpurun_out/${P}_kt.err
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${P}_kte -- \
-    python $R/bench.py --no-cpu-baseline > $R/gpurun_out/${P}_kte_bench.json 2> $R/gpurun_out/${P}_kte.err
+    python $R/bench.py --no-cpu-baseline --no-c5-extra > $R/gpurun_out/${P}_kte_bench.json 2> $R/gpurun_out/${P}_kte.err
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/${P}_fetch -- \
-    python $R/bench.py --steps 2 --no-cpu-baseline --no-count --no-peaks --no-e2e > /dev/null 2> $R/gpurun_out/${P}_fetch.err
+    python $R/bench.py --steps 2 --no-cpu-baseline --no-count --no-peaks --no-e2e --no-extras > /dev/null 2> $R/gpurun_out/${P}_fetch.err
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${P}_write -- \
-    python $R/bench.py --steps 2 --no-cpu-baseline --no-count --no-peaks --no-e2e > /dev/null 2> $R/gpurun_out/${P}_write.err
+    python $R/bench.py --steps 2 --no-cpu-baseline --no-count --no-peaks --no-e2e --no-extras > /dev/null 2> $R/gpurun_out/${P}_write.err
 timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_LDS --output-format csv -d $R/gpurun_out/${P}_sq -- \
-    python $R/bench.py --steps 2 --no-cpu-baseline --no-peaks --no-e2e > $R/gpurun_out/${P}_sq_bench.json 2> $R/gpurun_out/${P}_sq.err
+    python $R/bench.py --steps 2 --no-cpu-baseline --no-peaks --no-e2e --no-extras > $R/gpurun_out/${P}_sq_bench.json 2> $R/gpurun_out/${P}_sq.err
 timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/${P}_grbm -- \
-    python $R/bench.py --steps 2 --no-cpu-baseline --no-count --no-peaks --no-e2e > /dev/null 2> $R/gpurun_out/${P}_grbm.err
+    python $R/bench.py --steps 2 --no-cpu-baseline --no-count --no-peaks --no-e2e --no-extras > /dev/null 2> $R/gpurun_out/${P}_grbm.err
 # config 4 (shadow, 144 sun positions in one launch): kernel trace + stats, and the SQ counters of k_shadow_refill
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${P}_c4kt -- \
     python $R/bench.py --workload c4 > $R/gpurun_out/${P}_c4kt_bench.json 2> $R/gpurun_out/${P}_c4kt.err

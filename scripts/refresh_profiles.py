@@ -45,6 +45,7 @@ cal_r = out["FETCH_SIZE"]["hz::k_bounds"]["mean_KiB"] * 1024 / (12 * 3601 * 3601
 cal_w = out["WRITE_SIZE"]["hz::k_morton"]["mean_KiB"] * 1024 / (8 * 3600 * 3600)     # key + primitive id per quad
 b = json.loads(open("gpurun_out/%s_kt_bench.json" % pre).read().strip().splitlines()[-1])
 t = {"tile": 3601, "azim": 360, "rows_per_step": b["config"]["rows_per_step"], "kernel_source_sha": sha,
+     "device": b["config"].get("device"), "rocm": b["config"].get("rocm"),
      "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024, "fetch_bytes": 2 * f * 1024, "write_bytes": w * 1024,
      "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (profiles/%s/pmc_fetch_write_summary.json), mean "
              "over the launches of 2 steps; KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2); calibration "
@@ -61,7 +62,8 @@ if kk:
     model_winst = bs["roofline"].get("valu_winst_per_launch")
     d = bs["roofline"].get("valu_model_constants") or dict(bench.VALU_MODEL_DEFAULT)   # the constants that run used
     fac = m["SQ_INSTS_VALU"] / model_winst if model_winst else None
-    vm = {"kernel_source_sha": sha, "sq_counters_per_launch": m, "model_winst_before": model_winst,
+    vm = {"kernel_source_sha": sha, "device": bs["config"].get("device"), "rocm": bs["config"].get("rocm"),
+          "sq_counters_per_launch": m, "model_winst_before": model_winst,
           "scale": fac, "lane_utilisation_valu": m["SQ_THREAD_CYCLES_VALU"] / (64.0 * m["SQ_INSTS_VALU"]) if m.get("SQ_INSTS_VALU") else None,
           "note": "per-iteration constants of that bench run scaled by SQ_INSTS_VALU / (its model) on the launches of 2 bench steps "
                   "(the counter pass of the same run supplies the wave-iteration counts)"}
@@ -100,7 +102,13 @@ try:
             "note": "1024 SIMDs x engine cycles / SQ_INSTS_VALU: below 4 means the instructions cannot all have taken the 4 cycles "
                     "of the round-2 model -- the fast class issues every ~2.4 cycles (profiles/%s/inst_rates.json)" % rnd}
     if rf.get("wave_node_iters"):
-        rest = m["SQ_INSTS_VALU"] - 147.0 * rf["wave_node_iters"] - 218.0 * rf["wave_leaf_iters"]
+        try:
+            vmj = json.load(open("profiles/valu_model.json"))
+            ni, li = vmj.get("node_iter", 147.0), vmj.get("leaf_iter", 218.0)
+        except Exception:
+            ni, li = 147.0, 218.0
+        out4["node_iter_leaf_iter_used"] = [ni, li]
+        rest = m["SQ_INSTS_VALU"] - ni * rf["wave_node_iters"] - li * rf["wave_leaf_iters"]
         out4["setup_winst_per_64_cells"] = rest / (144 * 3569 * 3569 / 64.0)
     json.dump(out4, open("profiles/%s/pmc_shadow_refill.json" % rnd, "w"), indent=1)
     print(json.dumps(out4))

@@ -113,3 +113,29 @@ def test_row_slabs_edge_cases():
     assert sl[0][0] == 0 and sl[-1][1] == 12 and all(sl[i][1] == sl[i + 1][0] for i in range(3))
     work = [int(m[b:e].sum()) for b, e in sl]
     assert max(work) - min(work) <= 5                    # balanced to within one row of cells
+
+
+def test_cost_estimate_refines_across_a_narrow_expensive_band():
+    """estimate_row_cost bisects where neighbouring samples differ strongly: a band of rows that costs 20 times its
+    surroundings (a cliff between a plain and high relief) is resolved with a few more probes instead of being stepped over."""
+    import numpy as np
+    from horayzon_amd.dist import estimate_row_cost, row_slabs, predicted_imbalance
+    n = 2000
+    true = np.ones(n)
+    true[700:790] = 20.0
+    true[790:] = 2.0
+    calls = []
+
+    def probe(row):
+        calls.append(row)
+        return float(true[row])
+
+    coarse = estimate_row_cost(n, probe, samples=32, refine=0)
+    n_coarse = len(calls)
+    fine = estimate_row_cost(n, probe, samples=32, refine=3)
+    n_fine = len(calls) - n_coarse
+    assert n_coarse == 32 and 32 < n_fine <= 32 + 24
+    imb_coarse = predicted_imbalance(row_slabs(n, 4, coarse), true)
+    imb_fine = predicted_imbalance(row_slabs(n, 4, fine), true)
+    imb_cells = predicted_imbalance(row_slabs(n, 4), true)
+    assert imb_fine < 1.12 and imb_fine < imb_coarse - 0.03 and imb_fine < imb_cells - 0.2, (imb_cells, imb_coarse, imb_fine)

@@ -151,3 +151,21 @@ def test_config4_bench_line():
     r = d["roofline"]
     assert r["bound"] == "valu_issue" and 0.0 < r["frac"] <= 1.0 and r["kernel_ms_per_step"] > 0
     assert r["nodes_per_ray"] > 1 and 0.0 < r["lane_utilisation_node_leaf_steps"] <= 1.0
+
+
+def test_cost_balanced_slabs_pay_on_an_inhomogeneous_dem():
+    """`--balance cost` on a DEM that is half rolling lowland (3 % of the relief), half high relief (--plain-fraction 0.5).  The two
+    slabs of an emulated 2-rank partition are timed one after the other on the one GPU: split by cell count, one slab
+    takes far longer than the other; split by the sampled cost pre-pass (probe rows bisected where neighbouring samples
+    differ strongly, dist.estimate_row_cost) the two slabs take about the same."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29627")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5", "--tile", "3073", "--azim", "120",
+           "--plain-fraction", "0.5", "--emulate-ranks", "2", "--cost-samples", "48"]
+    p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-2000:]
+    e = json.loads(p.stdout.strip().splitlines()[-1])["config"]
+    print(json.dumps({k: e[k] for k in ("cost", "cells")}))
+    assert e["cells"]["imbalance_measured"] > 1.12                       # count-balanced: the high-relief slab dominates
+    assert e["cost"]["imbalance_measured"] < e["cells"]["imbalance_measured"] - 0.05
+    assert e["cost"]["imbalance_measured"] < 1.12 and e["cost"]["job_s_if_parallel"] < e["cells"]["job_s_if_parallel"]
+    assert e["cost"]["slabs"][0][1] > e["cells"]["slabs"][0][1]          # the lowland's slab is longer

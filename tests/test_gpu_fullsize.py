@@ -163,8 +163,9 @@ def _log_r04(name, rec):
 def test_c3_whole_tile_certificates_retraced(hip, tile):
     """EVERY ray of the whole config-3 tile that a near-field certificate shortened (79 % of 9.9e9
     rays) is traced a second time over its full length (counting instantiation, opts.verify_near = 1): no decision may
-    differ.  Then the production kernel with the sampled check compiled in (verify_near = 256): same output bit for bit,
-    no violation, and what the monitoring costs."""
+    differ.  Then the monitor for production inputs (verify_near = 256 without count_work: the production launch untouched,
+    plus a counting launch that re-traces every shortened ray of one of every 256 blocks): same output bit for bit, no
+    violation, and what the monitoring costs."""
     torch = pytest.importorskip("torch")
     import ctypes as C
     from horayzon_amd import _lib
@@ -202,7 +203,7 @@ def test_c3_whole_tile_certificates_retraced(hip, tile):
                                           violations=int(sv.near_violations), kernel_s_plain=s0.t_kernel_s,
                                           kernel_s_sampled_1_of_256=ss.t_kernel_s, sampled_retraced=int(ss.near_verified),
                                           sampled_overhead=ss.t_kernel_s / s0.t_kernel_s - 1.0))
-    assert ss.t_kernel_s <= 1.03 * s0.t_kernel_s          # the monitor is meant to cost < 0.5 % (logged); 3 % is the alarm
+    assert ss.t_kernel_s <= 1.05 * s0.t_kernel_s          # about 1 - 2 % (logged): a small second launch with its own tail
 
 
 def test_c3_curved_tile_certificates_retraced(hip, tile):
