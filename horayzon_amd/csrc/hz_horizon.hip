@@ -401,8 +401,11 @@ __device__ __forceinline__ void hz_sincos_halfpi(double x, double &s, double &c)
 }
 
 #define HZ_TOPO_CH 32      // azimuths per LDS block
+#ifndef HZ_TOPO_WG
+#define HZ_TOPO_WG 3      // workgroups per CU the register allocation is held to (3: 155 VGPRs; 4: see DESIGN.md section 5)
+#endif
 template <int KIND>
-__global__ __launch_bounds__(256) void k_topo(const float *__restrict__ azim, const float *__restrict__ hori,
+__global__ __launch_bounds__(256, HZ_TOPO_WG) void k_topo(const float *__restrict__ azim, const float *__restrict__ hori,
                                              const float *__restrict__ vec_tilt, size_t ncell, int A,
                                              float *__restrict__ out) {
     extern __shared__ float topo_lds[];                 // [2 A] sin / cos of the azimuths, then 4 x [64][33] blocks
