@@ -72,11 +72,29 @@ def test_plain_bench_gpus_2_starts_two_ranks_and_shards_the_tile(tmp_path):
     a, b = np.load(dump2), np.load(dump1)
     assert a.shape == (569, 569) and np.isfinite(a).all() and np.array_equal(a, b)
     # ... and the plain N = 1 line (one launch over the whole tile, no process group)
-    r, dump0 = _plain(tmp_path, "plain", "--no-count", "--no-peaks", gpus=1)
+    r, dump0 = _plain(tmp_path, "plain", "--no-count", "--no-peaks", "--no-c5-extra", gpus=1)
     assert r.returncode == 0, r.stderr[-3000:]
     d0 = json.loads(r.stdout.strip().splitlines()[-1])
     assert d0["n_gpus"] == 1 and d0["scaling"] == "strong" and d0["config"]["cells_per_step"] == cells
     assert np.array_equal(a, np.load(dump0))
+
+
+def test_plain_bench_gpus_8_world_of_eight_on_one_gpu(tmp_path):
+    """The world size the driver's scaling run ends with: `python bench.py --gpus 8` (eight ranks sharing the one GPU over
+    gloo) -- eight disjoint slabs that cover the tile, every rank's time reported, the gathered SVF equal to the N = 1 SVF."""
+    np = pytest.importorskip("numpy")
+    p, dump8 = _plain(tmp_path, "eight", "--no-count", "--no-peaks", gpus=8)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    c = d["config"]
+    sl = c["slabs"]
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and len(sl) == 8 and len(c["t_ranks_s"]) == 8
+    assert sl[0][0] == 0 and sl[-1][1] == 569 and all(sl[i][1] == sl[i + 1][0] for i in range(7))
+    assert all(71 <= b - a <= 72 for a, b in sl) and c["gathered_svf_finite"] is True
+    assert c["cells_per_step"] == 569 * 569 and c["load_imbalance_max_over_mean"] >= 1.0
+    r, dump1 = _plain(tmp_path, "one", "--no-count", "--no-peaks", "--no-extras", gpus=1)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert np.array_equal(np.load(dump8), np.load(dump1))
 
 
 def test_plain_bench_gpus_2_broadcasting_vertices_only(tmp_path):
