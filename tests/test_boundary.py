@@ -26,6 +26,21 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), name
 
 
+def test_abi_revision_and_struct_mirrors():
+    """hz_abi_version() names the revision of the structs / option semantics (include/horayzon_hip.h lists what changed);
+    the ctypes mirrors have the compiled sizes, and the Cython declaration in INTEGRATION.md lists every hz_opts field."""
+    import ctypes as C
+    L = _lib.lib()
+    assert L.hz_abi_version() == 4
+    a, b = C.c_int(0), C.c_int(0)
+    assert L.hz_abi_struct_sizes(C.byref(a), C.byref(b)) == 0
+    assert a.value == C.sizeof(_lib.hz_opts) and b.value == C.sizeof(_lib.hz_stats)
+    assert _lib.hz_stats._fields_[-1][0] == "near_verified"
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for name, _ in _lib.hz_opts._fields_:
+        assert re.search(r"\b%s\b" % name, doc), name
+
+
 def test_no_torch_types_in_abi():
     hdr = open(os.path.join(ROOT, "include", "horayzon_hip.h")).read()
     assert "torch" not in hdr.lower() and "at::" not in hdr
