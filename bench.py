@@ -377,7 +377,9 @@ def run_c3(ctx):
     for s in range(steps):
         rb, re = step(base + warmup + s, stats)
     if ctx["use_dist"] and steps > 0:    # final gather of the SVF rows of every rank's last step (4 B / cell)
-        gather_rows(d_svf[rb:re], [(0, rps)] * world, dst=0)
+        last = torch.zeros((rps, in1), dtype=torch.float32, device=dev)      # (ranks may sit on slabs of different length)
+        last[:re - rb] = d_svf[rb:re]
+        gather_rows(last, [(0, rps)] * world, dst=0)
     barrier(ctx)
     elapsed = time.perf_counter() - t0
     if ctx["use_dist"]:

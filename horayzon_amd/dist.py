@@ -226,31 +226,35 @@ def _host_staged(t, group):
 
 
 def gather_rows(local, slabs, dst=0, group=None):
-    """Gather per-rank row slabs (torch tensors, leading axis = rows of the slab; ``None`` for an
+    """Gather per-rank row slabs (torch tensors, leading axis = rows of the slab; a 0-row tensor for an
     empty slab) into the full array on ``dst``.  CUDA tensors (RCCL) and CPU tensors (gloo).
-    Meant for small per-cell outputs (SVF): every rank sends max-slab-rows rows."""
+    Every rank sends exactly its own rows to ``dst`` (point-to-point; rounds 2-3 padded every slab to the
+    largest one for a `gather` collective -- with cost-balanced slabs the sizes differ by design)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
-    max_rows = max(max(e - b for b, e in slabs), 1)
     if local is None:
         raise ValueError("gather_rows needs a (possibly 0-row) tensor on every rank")
     tail = tuple(local.shape[1:])
     dev = local.device
-    local = _host_staged(local, group)
-    padded = torch.zeros((max_rows,) + tail, dtype=local.dtype, device=local.device)
-    padded[:local.shape[0]] = local
-    out = [torch.empty_like(padded) for _ in range(world)] if rank == dst else None
-    try:
-        dist.gather(padded, out, dst=dst, group=group)
-    except (RuntimeError, NotImplementedError):      # a backend without gather: all_gather, keep dst's copy
-        allv = [torch.empty_like(padded) for _ in range(world)]
-        dist.all_gather(allv, padded, group=group)
-        out = allv if rank == dst else None
+    local = _host_staged(local, group).contiguous()
+    if local.shape[0] != slabs[rank][1] - slabs[rank][0]:
+        raise ValueError("rank %d holds %d rows, its slab has %d" % (rank, local.shape[0], slabs[rank][1] - slabs[rank][0]))
     if rank != dst:
+        if local.shape[0] > 0:
+            dist.send(local, dst=dst, group=group)
         return None
-    return torch.cat([out[r][:slabs[r][1] - slabs[r][0]] for r in range(world)], dim=0).to(dev)
+    parts = []
+    for r in range(world):
+        rows = slabs[r][1] - slabs[r][0]
+        if r == dst:
+            parts.append(local)
+        elif rows > 0:
+            buf = torch.empty((rows,) + tail, dtype=local.dtype, device=local.device)
+            dist.recv(buf, src=r, group=group)
+            parts.append(buf)
+    return torch.cat(parts, dim=0).to(dev)
 
 
 def sharded_rows(mask, compute, *, sync=None, dst=0, group=None, gather=True, cost=None):
