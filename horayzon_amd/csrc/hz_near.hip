@@ -23,8 +23,10 @@
 //    and T /\ H_k is a segment along which z / r (the tangent of the elevation seen from o) is monotone, so its
 //    maximum sits at an end point, and the end points are crossings of H_k with EDGES of T.  Hence
 //        tanE[k] = max over window edges crossing H_k of z / r at the crossing point
-//    bounds the elevation of everything in W along azimuth k.  (The six spokes from the cell's own vertex cross H_k
-//    only at the vertex itself, directly below o, and contribute nothing.)
+//    bounds the elevation of everything in W along azimuth k.  (The six spokes from the cell's own vertex are not
+//    evaluated: the origin lies above the planes of the six triangles around that vertex -- checked per cell -- so
+//    z / r = slope + gamma / r with gamma < 0 increases with r on each of them and their maximum is taken on the inner
+//    ring's outer edges.  DESIGN.md section 4.3 lists every statement of this argument with the check that backs it.)
 //  * That bound needs the window's surface to be a graph over the cell's LOCAL horizontal plane (one curve z(r) per
 //    azimuth, starting directly below o): checked per cell (orientation of every window triangle in the local (east,
 //    north) projection); a cell whose frame is tilted against terrain steeper than the tilt allows gets no certificate.
