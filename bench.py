@@ -850,6 +850,11 @@ def run_sharded(ctx, kind):
         run_slab(slab0[0], slab0[1] if c3 else min(slab0[0] + 64, slab0[1]), _lib.hz_stats())
     if args.emulate_ranks > 1:
         return emulate_ranks(ctx, in0, in1, run_slab, probe, n_samples, blob_bytes)
+    # the collectives of a step once before the clock starts (RCCL sets its point-to-point channels up on first use)
+    _slabs_w = row_slabs(in0, world, cost)
+    _dist_mod.gather_rows(torch.zeros((_slabs_w[rank][1] - _slabs_w[rank][0], 1), dtype=torch.float32, device=dev), _slabs_w, dst=0)
+    _tw = _dist_mod._host_staged(torch.zeros(1, dtype=torch.float64, device=dev), None)
+    dist.all_gather([torch.empty_like(_tw) for _ in range(world)], _tw)
     barrier(ctx)
     t0 = time.perf_counter()
     res = None
