@@ -441,11 +441,30 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
             const int slot_ = __builtin_ctz((unsigned)pm | 16u); \
             node = (pm != 0) ? pf + slot_ : HZ_EMPTY; pm &= pm - 1; \
         } else { \
-            const bool ne = sp > 0; sp = ne ? sp - 1 : 0; const int pv = stack[sp * TPB + tid]; \
+            const bool ne = sa != sa0; sa = ne ? sa - (unsigned)(TPB * 4) : sa; const int pv = HZ_STACK_AT(sa); \
             node = ne ? pv : HZ_EMPTY; \
         } } while (0)
-#define HZ_SAVE() do { t.node = node; t.sp = sp; t.pf = pf; t.pm = pm; t.lq0 = lq0; t.lq1 = lq1; } while (0)
+// the fast discipline keeps its stack pointer as the BYTE offset of this lane's next free entry (sa = sa0 + sp * TPB * 4):
+// a push is a ds_write at `sa` and an add, no shift-and-add per access
+#define HZ_STACK_AT(off) (*reinterpret_cast<int *>(reinterpret_cast<char *>(stack) + (off)))
+#define HZ_SAVE() do { if (!LEVELSTACK) sp = (int)((sa - sa0) / (unsigned)(TPB * 4)); \
+                       t.node = node; t.sp = sp; t.pf = pf; t.pm = pm; t.lq0 = lq0; t.lq1 = lq1; } while (0)
+    const unsigned sa0 = (unsigned)tid * 4u;
+    unsigned sa = sa0 + (unsigned)sp * (unsigned)(TPB * 4);
+    const unsigned sa_cap = sa0 + (unsigned)(stack_cap - 3) * (unsigned)(TPB * 4);
     int res = -1;                 // single exit: lanes leave the loop through `res`, state is saved once
+#ifdef HZ_PREFETCH
+    // Probe (scripts/build_variant.sh pf -DHZ_PREFETCH): touch the cache line of the link a node step has just chosen with
+    // a fire-and-forget 4 B load, so that the three 16 B loads of the next visit hit L1.  The destination register is
+    // carried through the loop (loads return in order; the wait in the next load block covers it) and waited for at the exit.
+    unsigned pf_sink = 0u;
+#define HZ_PF(link) do { if ((link) != HZ_EMPTY) { \
+        const char *pa_ = HZ_IS_NODE(link) ? reinterpret_cast<const char *>(nodes + (link)) \
+                                           : reinterpret_cast<const char *>(prims + HZ_LEAF_ID(link)); \
+        asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(pa_) : "memory"); } } while (0)
+#else
+#define HZ_PF(link) do { } while (0)
+#endif
     while (res < 0) {
         // set leaves aside while the leaf queue (QLEN entries, filled front to back; a queued leaf is negative, an empty
         // place HZ_EMPTY) has room
@@ -489,16 +508,19 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
                     }
                     HZ_POP();                        // ... and the first of them (or of a level above) is entered
                 } else {
-                    if (sp > stack_cap - 3) { overflow = 1u; sp = stack_cap - 3; }
-                    int next = HZ_EMPTY;
-                    // branch-free pushes: the candidate is always stored at the stack top and only kept (sp advanced)
-                    // when it was a real link
-                    if (h3) next = first + 3;
-                    if (h2) { stack[sp * TPB + tid] = next; sp += (next != HZ_EMPTY) ? 1 : 0; next = first + 2; }
-                    if (h1) { stack[sp * TPB + tid] = next; sp += (next != HZ_EMPTY) ? 1 : 0; next = first + 1; }
-                    if (h0) { stack[sp * TPB + tid] = next; sp += (next != HZ_EMPTY) ? 1 : 0; next = first; }
-                    if (next != HZ_EMPTY) node = next; else HZ_POP();
+                    if (sa > sa_cap) { overflow = 1u; sa = sa_cap; }
+                    // branch-free pushes: the candidate is always stored at the stack top and only kept (pointer advanced)
+                    // when it was a real link.  "It was a real link" = a higher slot was hit: known from the hit flags, which
+                    // are lane masks in scalar registers -- no vector compare per push (round 4: the node step waits for its
+                    // slow-class instructions, and v_cmp / v_lshl_add are slow class)
+                    const bool p2 = h3, p1 = h3 || h2, p0 = p1 || h1;
+                    int next = h3 ? first + 3 : HZ_EMPTY;
+                    if (h2) { HZ_STACK_AT(sa) = next; sa += p2 ? (unsigned)(TPB * 4) : 0u; next = first + 2; }
+                    if (h1) { HZ_STACK_AT(sa) = next; sa += p1 ? (unsigned)(TPB * 4) : 0u; next = first + 1; }
+                    if (h0) { HZ_STACK_AT(sa) = next; sa += p0 ? (unsigned)(TPB * 4) : 0u; next = first; }
+                    if (p0 || h0) node = next; else HZ_POP();
                 }
+                HZ_PF(node);
             }
         } else {
             // ---------------- leaf step: the two triangles of a DEM quad (or one TIN triangle) ---
@@ -514,10 +536,15 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
             }
         }
     }
+#ifdef HZ_PREFETCH
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) : : "memory");
+#endif
     HZ_SAVE();
     return res;
+#undef HZ_PF
 #undef HZ_POP
 #undef HZ_SAVE
+#undef HZ_STACK_AT
 }
 
 // ---------------------------------------------------------------------------

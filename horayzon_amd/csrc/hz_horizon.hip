@@ -61,7 +61,10 @@ struct HorizonParams {
 //  for 4.  Its tallies -- rays, node visits, triangle tests, wave iterations -- are functions of the lanes' states only, not
 //  of the schedule, so they are the production launch's numbers: the ray counts of the two instantiations are compared by the tests.)
 template <int ALG, bool COUNT, bool STAGE, bool NODELET, bool LEVELSTACK>
-__global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : 5) void k_horizon(HorizonParams p) {
+#ifndef HZ_WG_PER_CU
+#define HZ_WG_PER_CU 5     // resident workgroups per CU the register allocation is held to (6: 80 VGPRs, measured slower)
+#endif
+__global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : HZ_WG_PER_CU) void k_horizon(HorizonParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int *stack = reinterpret_cast<int *>(smem);
     const float4 *top = reinterpret_cast<const float4 *>(smem + p.stack_bytes + p.stage_bytes);
@@ -318,8 +321,10 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
     // (a.level_stack < 0: test hook, the fast discipline with that many entries)
     // (with the opt-in LDS nodelet the fast stack gives up the entries the nodelet's bytes need, so that 5 workgroups stay resident)
     const int want_top = (a.top_nodes > 0 && a.alg == ALG_GUESS && !a.count_work) ? std::min(a.top_nodes, sc->hdr.n_top) : 0;
+    // (HZ_LDS_BUDGET: bytes of LDS per workgroup the fast stack may use with staging and nodelet -- experiments with the residency)
+    static const int lds_budget = []() { const char *e = getenv("HZ_LDS_BUDGET"); return e && atoi(e) > 8192 ? atoi(e) : 31 * 1024; }();
     const int fast_cap = a.level_stack < 0 ? std::max(-a.level_stack, 3)
-                                           : std::max((31 * 1024 - stage - want_top * (int)sizeof(Node)) / (HZ_TPB * 4), 3);
+                                           : std::max((lds_budget - stage - want_top * (int)sizeof(Node)) / (HZ_TPB * 4), 3);
     const bool level_stack = a.level_stack > 0;
     const int depth = level_stack ? height : std::min(fast_cap, 3 * height);
     if (used_level_stack) *used_level_stack = (level_stack || depth >= 3 * height) ? 1 : 0;   // 1: cannot overflow

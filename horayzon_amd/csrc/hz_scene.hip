@@ -321,6 +321,12 @@ __device__ __forceinline__ uint32_t step_exponent(float extent, float qmax) {
 // of the two ray constants (b = fma(o', rd, -oc rd): |o'| grows by <= 1024 s, so its rounding by <= 1024 s 2^-24 =
 // s 2^-14 in space units; the origin's own rounding is below that) -- everything else is the error
 // structure the leaf padding has covered since round 1.
+// z bounds: integers 0 .. HZ_QZ_MAX stored as half floats (exact)
+#ifdef HZ_PROBE_NODE32_BOUNDS
+#define HZ_QZ_MAX 255.0f
+#else
+#define HZ_QZ_MAX 2047.0f
+#endif
 struct AxisQ { uint32_t e; float s, o, m; };
 __device__ __forceinline__ double axis_plane(const AxisQ &a, float q) { return (double)a.o + (double)(1024.0f + q) * (double)a.s; }
 // The step exponents travel in the low 9 mantissa bits of the node's x and z origins (bit 8 zero, bits 7..0 the biased
@@ -369,11 +375,11 @@ __device__ __forceinline__ void axes_setup(float xl, float xh, float yl, float y
 }
 // z: origin with the exponent bits at or below the node's lower bound, step such that code 2047 reaches its upper bound
 __device__ __forceinline__ void z_setup(float zl, float zh, float &oz, float &sz) {
-    uint32_t e = step_exponent(zh - zl, 2040.0f);
+    uint32_t e = step_exponent(zh - zl, HZ_QZ_MAX - 7.0f);
     for (;;) {
         sz = __uint_as_float(e << 23);
         oz = embed_down(zl, e);
-        if (__builtin_fmaf(2047.0f, sz, oz) >= zh || e >= 254u) break;
+        if (__builtin_fmaf(HZ_QZ_MAX, sz, oz) >= zh || e >= 254u) break;
         e++;
     }
 }
@@ -392,7 +398,7 @@ __device__ __forceinline__ uint32_t axis_hi(const AxisQ &a, float hi) {
     return (uint32_t)q;
 }
 // z bounds: integers 0 .. 2047 stored as half floats (exact), decoded as o + q s with the node's own lower corner
-#define HZ_QZ_MAX 2047.0f
+
 __device__ __forceinline__ uint32_t half_bits(uint32_t q) {
     const _Float16 h = (_Float16)(float)q;
     return (uint32_t)__builtin_bit_cast(unsigned short, h);
@@ -437,6 +443,26 @@ __global__ __launch_bounds__(256) void k_emit4(Emit4 e, NodeTmp *__restrict__ no
             if (k == slot) { link[k] = lk; lo[k][0] = bl.x; lo[k][1] = bl.y; lo[k][2] = bl.z;
                              hi[k][0] = bh.x; hi[k][1] = bh.y; hi[k][2] = bh.z; }
     }
+#ifdef HZ_PROBE_NODE32_BOUNDS
+    // Probe: the bounds a 32 B node (two 16 B loads per visit) could hold -- per axis ONE range for the two children of
+    // each half of the quadrant split (x: same column bit, y: same row bit), z in 8 bits, children in quadrant order.
+    // How many more node visits do the looser boxes cost?  (scripts/build_variant.sh n32 -DHZ_PROBE_NODE32_BOUNDS)
+    {
+        float hl[2][2], hh[2][2];      // [axis][half]
+        for (int a = 0; a < 2; a++) for (int h = 0; h < 2; h++) { hl[a][h] = INFINITY; hh[a][h] = -INFINITY; }
+        for (int k = 0; k < 4; k++) {
+            if (link[k] == HZ_TMP_EMPTY) continue;
+            const int hx = k & 1, hy = k >> 1;
+            hl[0][hx] = fminf(hl[0][hx], lo[k][0]); hh[0][hx] = fmaxf(hh[0][hx], hi[k][0]);
+            hl[1][hy] = fminf(hl[1][hy], lo[k][1]); hh[1][hy] = fmaxf(hh[1][hy], hi[k][1]);
+        }
+        for (int k = 0; k < 4; k++) {
+            if (link[k] == HZ_TMP_EMPTY) continue;
+            lo[k][0] = hl[0][k & 1]; hi[k][0] = hh[0][k & 1];
+            lo[k][1] = hl[1][k >> 1]; hi[k][1] = hh[1][k >> 1];
+        }
+    }
+#else
     // the traversal visits slot 0 first: put the tallest child there (a blocked ray is most likely
     // blocked by the child that reaches highest), empty slots last
     {
@@ -453,6 +479,7 @@ __global__ __launch_bounds__(256) void k_emit4(Emit4 e, NodeTmp *__restrict__ no
         };
         cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
     }
+#endif
     const float4 nl = e.node_lo[i], nh = e.node_hi[i];
     AxisQ ax, ay;
     axes_setup(nl.x, nh.x, nl.y, nh.y, ax, ay);
