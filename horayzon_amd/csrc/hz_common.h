@@ -7,8 +7,9 @@
 // vertices : the caller's vert_grid, untouched (ray origins read them;
 //            reference: shared vertex buffer, horizon_comp.cpp:126-127).
 // nodes    : flat LBVH collapsed to 4-wide nodes along the 2-bit digits of the Morton key (= a quadtree over the
-//            (x, y) centroids).  One node is 48 B and holds the conservatively quantised AABBs (8 bit x/y, 11 bit z as half floats,
-//            relative to the node's own box) of up to 4 children, stored tallest (largest z-max) first.  ALL nodes
+//            (x, y) centroids).  One node is 32 B and holds the conservatively quantised bounds of its children (8 bit,
+//            relative to the node's own box) of up to 4 children in quadrant order: one x range per column half, one y
+//            range per row half, one z range per child.  ALL nodes
 //            are numbered breadth first and the children of a node are CONTIGUOUS: one index (`first`) addresses
 //            the block of 4 child slots -- 4 consecutive nodes, or 4 consecutive leaf records (a node whose children
 //            were mixed got its leaves wrapped into single-child nodes, so a block is of one kind).  A traversal
@@ -29,7 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #define HZ_BLOB_MAGIC 0x485a4c42u /* "HZLB" */
-#define HZ_BLOB_VERSION 8u
+#define HZ_BLOB_VERSION 9u
 #define HZ_WAVE 64
 
 struct BlobHeader {
@@ -65,18 +66,21 @@ static_assert(sizeof(BlobHeader) == 256, "BlobHeader must be 256 bytes");
 #define HZ_LEAF_BIT 0x80000000u
 #define HZ_LEAF_ID(link) ((int)((unsigned)(link) & 0x7fffffffu))
 struct __attribute__((aligned(16))) Node {
-    float org[3];        // origin of the node's quantisation frame (centred scene frame): a child's x bound is
-                         // org[0] + (1024 + q) * step_xy, its z bound org[2] + q * step_z (the forms hz_qbox_hit decodes).
-                         // The quantisation steps are powers of two and live IN these floats: the low 9 mantissa bits of
-                         // org[0] hold the biased exponent of step_xy (x and y share one step), those of org[2] that of
-                         // step_z (bit 8 is zero, so `bits << 23` IS the step).  The build chooses the origins as floats
-                         // with those low bits and quantises against exactly these values (hz_scene.hip: axis_setup).
+    float org[3];        // origin of the node's quantisation frame (centred scene frame): a bound with code q lies at
+                         // org[axis] + (1024 + q) * step (the form hz_node_hits decodes: the byte q becomes the half float
+                         // 0x64qq = 1024 + q).  The steps are powers of two and live IN these floats: the low 9 mantissa bits
+                         // of org[0] hold the biased exponent of the x / y step (one step for both), those of org[2] that of
+                         // the z step (bit 8 is zero, so `bits << 23` IS the step).  The build chooses the origins as floats
+                         // with those low bits and quantises against exactly these values (hz_scene.hip: axis_try).
     int32_t first;       // link of child slot 0; slots 1..3 are first + 1 .. first + 3: 4 consecutive nodes or 4
-                         // consecutive leaf records (blocks are 4-aligned).  An unused slot has an empty box (lo > hi).
-    uint32_t qxy[4];     // per child slot: xlo | xhi<<8 | ylo<<16 | yhi<<24   (8 bit, 0..255)
-    uint32_t qz[4];      // per child slot: zlo | zhi<<16     (two half floats holding integers 0..2047)
+                         // consecutive leaf records (blocks are 4-aligned).  Slot k is the quadrant 2 * row bit + column bit
+                         // of the Morton digit this node splits.
+    uint32_t qx;         // x ranges, 8 bit each: (lo, hi) of the two children with column bit 0, (lo, hi) of those with bit 1
+    uint32_t qy;         // y ranges: (lo, hi) of the children with row bit 0, (lo, hi) of those with row bit 1
+    uint32_t qz[2];      // z ranges per child slot: qz[0] = (lo0, hi0, lo1, hi1), qz[1] = (lo2, hi2, lo3, hi3);
+                         // an unused slot has lo = 255 > hi = 0
 };
-static_assert(sizeof(Node) == 48, "Node must be 48 bytes");
+static_assert(sizeof(Node) == 32, "Node must be 32 bytes");
 
 struct __attribute__((aligned(16))) Prim {
     float a[3], b[3], c[3], d[3];
@@ -254,9 +258,11 @@ __device__ __forceinline__ bool hz_tri_hit_t(float ox, float oy, float oz, float
 struct RayBox {
     float rdx, rdy, rdz;     // 1 / d (clamped away from inf)
     float ordx, ordy, ordz;  // (o - center) * rd
-    uint32_t sel_x, sel_y, sel_z;   // v_perm selectors that put the NEAR bound into the low half word and the FAR bound
-                                    // into the high one (near = lo when 1/d > 0, hi otherwise); see hz_qbox_hit
+    uint32_t sel_x, sel_y, sel_z;   // v_perm selectors that turn the byte pair (lo, hi) in bytes 0 / 1 of a bounds word into
+                                    // two half floats, the NEAR bound in the low half word and the FAR bound in the high one
+                                    // (near = lo when 1/d > 0, hi otherwise); + HZ_SEL_PAIR1 addresses the pair in bytes 2 / 3
 };
+#define HZ_SEL_PAIR1 0x00020002u
 
 __device__ __forceinline__ float hz_safe_rcp(float d) {
     // v_rcp_f32 (1 ulp) is enough: these constants only feed the conservative box test
@@ -269,10 +275,10 @@ __device__ __forceinline__ RayBox hz_raybox(float ocx, float ocy, float ocz,
     r.rdx = hz_safe_rcp(dx); r.rdy = hz_safe_rcp(dy); r.rdz = hz_safe_rcp(dz);
     r.ordx = ocx * r.rdx; r.ordy = ocy * r.rdy; r.ordz = ocz * r.rdz;
     // selector bytes 0..3 pick bytes 0..3 of the second v_perm operand (the packed bounds), 4 picks byte 0 of the
-    // first one (HZ_HALF_MAGIC): x and y bounds are single bytes that become the mantissa of a half float
+    // first one (HZ_HALF_MAGIC): every bound is a single byte that becomes the mantissa of a half float
     r.sel_x = (r.rdx < 0.0f) ? 0x04000401u : 0x04010400u;
-    r.sel_y = (r.rdy < 0.0f) ? 0x04020403u : 0x04030402u;
-    r.sel_z = (r.rdz < 0.0f) ? 0x01000302u : 0x03020100u;
+    r.sel_y = (r.rdy < 0.0f) ? 0x04000401u : 0x04010400u;
+    r.sel_z = (r.rdz < 0.0f) ? 0x04000401u : 0x04010400u;
     return r;
 }
 
@@ -289,14 +295,14 @@ __device__ __forceinline__ NodeRay hz_node_ray(const RayBox &r, float ox, float 
     return n;
 }
 
-// Child bounds are decoded WITHOUT integer -> float conversions (24 v_cvt + 24 v_fma per node step in rounds 1-3: the
-// conversions are slow-class VALU instructions and the three-source FMAs collided in the VGPR banks):
-//   x, y : 8-bit integers q.  One v_perm_b32 per axis builds the two half floats 0x64qq = 1024 + q (near bound in the low
-//          half word, far bound in the high one; the byte 0x64 comes from the constant operand), and v_fma_mix_f32 reads a
-//          half-float source directly: t = (1024 + q) * a + b.  The node stores its x / y origin shifted by -1024 steps
-//          (Node::org), so a and b are formed exactly as before.
-//   z    : stored as half floats (integers 0 .. 2047, exact in binary16); one v_perm_b32 orders (near, far).
-// 3 v_perm + 6 v_fma_mix per child instead of 2 v_perm + 6 v_cvt + 6 v_fma.
+// Bounds are decoded WITHOUT integer -> float conversions (24 v_cvt + 24 v_fma per node step in rounds 1-3: the conversions
+// are slow-class VALU instructions and the three-source FMAs collided in the VGPR banks): every bound is an 8-bit integer q;
+// one v_perm_b32 turns a (lo, hi) byte pair into the two half floats 0x64qq = 1024 + q (near bound in the low half word,
+// far bound in the high one; the byte 0x64 comes from the constant operand), and v_fma_mix_f32 reads a half-float source
+// directly: t = (1024 + q) * a + b.  The node stores its origins shifted by -1024 steps (Node::org).
+// Round 4, 32 B nodes: the four children are the quadrants of one split, so x has ONE range per column half and y one per
+// row half (2 v_perm + 4 v_fma_mix per axis and node), z one range per child (4 + 8): 8 v_perm + 16 v_fma_mix per node
+// instead of 12 + 24, and two 16 B loads per visit instead of three.
 #define HZ_HALF_MAGIC 0x64646464u
 typedef _Float16 hz_half2 __attribute__((ext_vector_type(2)));
 
@@ -309,60 +315,58 @@ __device__ __forceinline__ float hz_fma_mix_hi(uint32_t h2, float a, float b) {
     return __builtin_fmaf((float)__builtin_bit_cast(hz_half2, h2).y, a, b);
 }
 
-// does [0, tfar] overlap the quantised child box (qxy, qz)?  The ray's direction signs say which
-// bound of each slab is entered first, so the bounds are byte-permuted once (v_perm_b32) instead
-// of being sorted with min / max per axis.
-__device__ __forceinline__ bool hz_qbox_hit(const NodeRay &n, const RayBox &r, float tfar, uint32_t qxy, uint32_t qz) {
-    const uint32_t px = __builtin_amdgcn_perm(HZ_HALF_MAGIC, qxy, r.sel_x);
-    const uint32_t py = __builtin_amdgcn_perm(HZ_HALF_MAGIC, qxy, r.sel_y);
-    const uint32_t pz = __builtin_amdgcn_perm(0u, qz, r.sel_z);
-    const float tnx = hz_fma_mix_lo(px, n.ax, n.bx), tfx = hz_fma_mix_hi(px, n.ax, n.bx);
-    const float tny = hz_fma_mix_lo(py, n.ay, n.by), tfy = hz_fma_mix_hi(py, n.ay, n.by);
-    const float tnz = hz_fma_mix_lo(pz, n.az, n.bz), tfz = hz_fma_mix_hi(pz, n.az, n.bz);
-    const float tmin = __builtin_fmaxf(__builtin_fmaxf(tnx, tny), __builtin_fmaxf(tnz, 0.0f));
-    const float tmax = __builtin_fminf(__builtin_fminf(tfx, tfy), __builtin_fminf(tfz, tfar));
+// which of the four child boxes of a node does [0, tfar] overlap?  `q` = the node's second 16 bytes (qx, qy, qz[0], qz[1]).
+// The ray's direction signs say which bound of each slab is entered first, so every (lo, hi) pair is byte-permuted into
+// (near, far) once (v_perm_b32) instead of being sorted with min / max.
+__device__ __forceinline__ void hz_node_hits(const NodeRay &n, const RayBox &r, float tfar, const uint4 &q,
+                                             bool &h0, bool &h1, bool &h2, bool &h3) {
+    const uint32_t px0 = __builtin_amdgcn_perm(HZ_HALF_MAGIC, q.x, r.sel_x), px1 = __builtin_amdgcn_perm(HZ_HALF_MAGIC, q.x, r.sel_x + HZ_SEL_PAIR1);
+    const uint32_t py0 = __builtin_amdgcn_perm(HZ_HALF_MAGIC, q.y, r.sel_y), py1 = __builtin_amdgcn_perm(HZ_HALF_MAGIC, q.y, r.sel_y + HZ_SEL_PAIR1);
+    const uint32_t pz0 = __builtin_amdgcn_perm(HZ_HALF_MAGIC, q.z, r.sel_z), pz1 = __builtin_amdgcn_perm(HZ_HALF_MAGIC, q.z, r.sel_z + HZ_SEL_PAIR1);
+    const uint32_t pz2 = __builtin_amdgcn_perm(HZ_HALF_MAGIC, q.w, r.sel_z), pz3 = __builtin_amdgcn_perm(HZ_HALF_MAGIC, q.w, r.sel_z + HZ_SEL_PAIR1);
+    const float nx0 = hz_fma_mix_lo(px0, n.ax, n.bx), fx0 = hz_fma_mix_hi(px0, n.ax, n.bx);
+    const float nx1 = hz_fma_mix_lo(px1, n.ax, n.bx), fx1 = hz_fma_mix_hi(px1, n.ax, n.bx);
+    const float ny0 = hz_fma_mix_lo(py0, n.ay, n.by), fy0 = hz_fma_mix_hi(py0, n.ay, n.by);
+    const float ny1 = hz_fma_mix_lo(py1, n.ay, n.by), fy1 = hz_fma_mix_hi(py1, n.ay, n.by);
 #ifdef HZ_PROBE_NO_SLACK      // measurement probe: how much does the relative slack cost?
-    return tmin <= tmax;
+#define HZ_SLACK(x) (x)
 #else
-    return tmin <= tmax * 1.000001f;
+#define HZ_SLACK(x) ((x) * 1.000001f)
 #endif
+#define HZ_CHILD(pz, nx, fx, ny, fy, out) do { \
+        const float nz_ = hz_fma_mix_lo(pz, n.az, n.bz), fz_ = hz_fma_mix_hi(pz, n.az, n.bz); \
+        const float tmin_ = __builtin_fmaxf(__builtin_fmaxf(nx, ny), __builtin_fmaxf(nz_, 0.0f)); \
+        const float tmax_ = __builtin_fminf(__builtin_fminf(fx, fy), __builtin_fminf(fz_, tfar)); \
+        out = tmin_ <= HZ_SLACK(tmax_); } while (0)
+    HZ_CHILD(pz0, nx0, fx0, ny0, fy0, h0);      // slot k: column half k & 1, row half k >> 1
+    HZ_CHILD(pz1, nx1, fx1, ny0, fy0, h1);
+    HZ_CHILD(pz2, nx0, fx0, ny1, fy1, h2);
+    HZ_CHILD(pz3, nx1, fx1, ny1, fy1, h3);
+#undef HZ_CHILD
+#undef HZ_SLACK
 }
 
-// One 48 B node = 3 x 16 B global loads issued back to back and waited for once.
-// (hipcc was seen to put an s_waitcnt between the halves of the plain C++ form.)  Rounds 1-3 had 64 B nodes (a fourth load
-// for the three quantisation steps and a valid mask): the vector-memory pipe is the kernel's second limit (+1 load per
-// visit cost 3 %, +2 loads 10 - 12 %, round 3), so the steps moved into the low mantissa bits of the origin.
-__device__ __forceinline__ void hz_load_node(const Node *n, float4 &n0, uint4 &n1, uint4 &n2) {
-#ifdef HZ_PROBE_EXTRA_LOADS   // measurement probe (scripts/build_variant.sh): more 16 B loads of the same cache line per visit
-    float4 x0, x1;
-    const Node *n_other = reinterpret_cast<const Node *>(reinterpret_cast<size_t>(n) ^ (size_t)64);
-#if HZ_PROBE_EXTRA_LOADS >= 2
+// One 32 B node = 2 x 16 B global loads issued back to back and waited for once.
+// (hipcc was seen to put an s_waitcnt between the halves of the plain C++ form.)  Rounds 1-3 had 64 B nodes (four loads),
+// the first half of round 4 48 B ones (three): the vector-memory pipe is the kernel's co-limit -- every load instruction
+// per visit is worth ~4 % (+1 load: -3 %, round 3; 4 -> 3 loads: +4.2 %; a fire-and-forget prefetch load: -6 %).
+__device__ __forceinline__ void hz_load_node(const Node *n, float4 &n0, uint4 &n1) {
     asm volatile("global_load_dwordx4 %0, %2, off\n\t"
-                 "global_load_dwordx4 %1, %2, off offset:16"
-                 : "=&v"(x0), "=&v"(x1) : "v"(n_other) : "memory");
-#else
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(x0) : "v"(n_other) : "memory");
-    (void)x1;
-#endif
-#endif
-    asm volatile("global_load_dwordx4 %0, %3, off\n\t"
-                 "global_load_dwordx4 %1, %3, off offset:16\n\t"
-                 "global_load_dwordx4 %2, %3, off offset:32\n\t"
+                 "global_load_dwordx4 %1, %2, off offset:16\n\t"
                  "s_waitcnt vmcnt(0)"
-                 : "=&v"(n0), "=&v"(n1), "=&v"(n2)
+                 : "=&v"(n0), "=&v"(n1)
                  : "v"(n)
                  : "memory");
 }
 
-// The same node from the LDS nodelet (3 x ds_read_b128, one wait).
-__device__ __forceinline__ void hz_load_node_lds(const float4 *q, float4 &n0, uint4 &n1, uint4 &n2) {
+// The same node from the LDS nodelet (2 x ds_read_b128, one wait).
+__device__ __forceinline__ void hz_load_node_lds(const float4 *q, float4 &n0, uint4 &n1) {
     const unsigned addr = (unsigned)(size_t)reinterpret_cast<const __attribute__((address_space(3))) char *>(
         (const __attribute__((address_space(3))) float4 *)q);
-    asm volatile("ds_read_b128 %0, %3\n\t"
-                 "ds_read_b128 %1, %3 offset:16\n\t"
-                 "ds_read_b128 %2, %3 offset:32\n\t"
+    asm volatile("ds_read_b128 %0, %2\n\t"
+                 "ds_read_b128 %1, %2 offset:16\n\t"
                  "s_waitcnt lgkmcnt(0)"
-                 : "=&v"(n0), "=&v"(n1), "=&v"(n2)
+                 : "=&v"(n0), "=&v"(n1)
                  : "v"(addr)
                  : "memory");
 }
@@ -485,20 +489,21 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
         if (n_node * 16 >= n_leaf * leaf_bias) {
             // ---------------- node step ------------------------------------------------------
             if (can_node) {
-                float4 n0; uint4 n1, n2;
+                float4 n0; uint4 n1;
                 // NODELET: top-of-tree nodes from LDS, the rest from global memory (two separate asm paths:
                 // a per-lane pointer select would be compiled into slow flat loads).  Measured 2 % slower
                 // than plain global loads -- the top of the tree is L1 resident -- so it is opt-in.
-                if (NODELET && node < ntop) hz_load_node_lds(top + 3 * node, n0, n1, n2);
-                else hz_load_node(nodes + node, n0, n1, n2);
+                if (NODELET && node < ntop) hz_load_node_lds(top + 2 * node, n0, n1);
+                else hz_load_node(nodes + node, n0, n1);
                 if (COUNT) { cnt.nodes++; HZ_WAVE_TICK(cnt.w_nodes, lane); }
                 const NodeRay nr = hz_node_ray(rb, n0.x, n0.y, n0.z);
-                // children are visited in slot order (tallest first).  A front-to-back order (slot r ^ direction
+                // children are visited in slot order (quadrant order).  A front-to-back order (slot r ^ direction
                 // signs, ~45 VALU per step) was measured to be a net loss: these are any-hit rays, a blocked ray
                 // is blocked over a long stretch behind the first ridge, and near-horizon rays that only
-                // nick a crest are served by the hit cache.
-                const bool h0 = hz_qbox_hit(nr, rb, tfar, n1.x, n2.x), h1 = hz_qbox_hit(nr, rb, tfar, n1.y, n2.y);
-                const bool h2 = hz_qbox_hit(nr, rb, tfar, n1.z, n2.z), h3 = hz_qbox_hit(nr, rb, tfar, n1.w, n2.w);
+                // nick a crest are served by the hit cache.  (Rounds 2-3 stored the tallest child first: +1 %; the
+                // quadrant order is what lets x and y share one range per half, i.e. the 32 B node.)
+                bool h0, h1, h2, h3;
+                hz_node_hits(nr, rb, tfar, n1, h0, h1, h2, h3);
                 const int first = __float_as_int(n0.w);
                 if (LEVELSTACK) {
                     const int h = (h0 ? 1 : 0) | (h1 ? 2 : 0) | (h2 ? 4 : 0) | (h3 ? 8 : 0);
@@ -563,12 +568,12 @@ __device__ __forceinline__ bool hz_closest(const Node *__restrict__ nodes, const
     bool any = false;
     while (node != HZ_EMPTY) {
         if (node >= 0) {
-            float4 n0; uint4 n1, n2;
-            hz_load_node(nodes + node, n0, n1, n2);
+            float4 n0; uint4 n1;
+            hz_load_node(nodes + node, n0, n1);
             const float tf = any ? __builtin_fminf(tfar, best * 1.0001f) : tfar;
             const NodeRay nr = hz_node_ray(rb, n0.x, n0.y, n0.z);
-            const bool h0 = hz_qbox_hit(nr, rb, tf, n1.x, n2.x), h1 = hz_qbox_hit(nr, rb, tf, n1.y, n2.y);
-            const bool h2 = hz_qbox_hit(nr, rb, tf, n1.z, n2.z), h3 = hz_qbox_hit(nr, rb, tf, n1.w, n2.w);
+            bool h0, h1, h2, h3;
+            hz_node_hits(nr, rb, tf, n1, h0, h1, h2, h3);
             const int first = __float_as_int(n0.w);
             const int c0 = first, c1 = first + 1, c2 = first + 2, c3 = first + 3;
             int next = HZ_EMPTY;

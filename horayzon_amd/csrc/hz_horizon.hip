@@ -73,7 +73,7 @@ __global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : HZ_WG_PER_CU) void k_horizon(Ho
     if (NODELET && ntop > 0) {   // stage the breadth-first top of the tree in LDS (coalesced 16 B per lane)
         float4 *dst = reinterpret_cast<float4 *>(smem + p.stack_bytes + p.stage_bytes);
         const float4 *src = reinterpret_cast<const float4 *>(p.sv.nodes);
-        for (int i = tid; i < ntop * 3; i += HZ_TPB) dst[i] = src[i];
+        for (int i = tid; i < ntop * 2; i += HZ_TPB) dst[i] = src[i];
         __syncthreads();
     }
 
@@ -133,7 +133,10 @@ __global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : HZ_WG_PER_CU) void k_horizon(Ho
             r20 = east_z; r21 = north_z; r22 = norm_z;
         }
     }
-    const float ocx = ox - p.sv.cx, ocy = oy - p.sv.cy, ocz = oz - p.sv.cz;
+    // (the origin in the scene-centred frame is formed from (ox, oy, oz) where it is needed -- three subtractions per ray
+    //  instead of three more registers that live through the traversal; the empty asm stops the compiler from hoisting them)
+#define HZ_OC(ocx, ocy, ocz) float ocx, ocy, ocz; { float ax_ = ox, ay_ = oy, az_ = oz; asm volatile("" : "+v"(ax_), "+v"(ay_), "+v"(az_)); \
+        ocx = ax_ - p.sv.cx; ocy = ay_ - p.sv.cy; ocz = az_ - p.sv.cz; }
     const float tfar = p.dist;
 
     Search s;
@@ -163,7 +166,12 @@ __global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : HZ_WG_PER_CU) void k_horizon(Ho
         // ---- refill: lanes without a ray take the next sample of their search -----------------
         if (!done && !ray_active) {
             if (COUNT) HZ_WAVE_TICK(w_adv, lane);
-            out.hori = hori0 + (size_t)cert * (size_t)t.azim_num;
+            // (the per-cell addresses are rebuilt from `cert` HERE, at every refill: the empty asm keeps the compiler from
+            //  hoisting the 64-bit products out of the loop -- it then spilled them, and every refill paid three scratch
+            //  reloads with a full memory wait each: vector-memory instructions are what this kernel is short of)
+            unsigned cert_r = cert;
+            asm volatile("" : "+v"(cert_r));
+            out.hori = hori0 + (size_t)cert_r * (size_t)t.azim_num;
             if (advance<ALG, STAGE>(s, last_hit, t, out, guards)) {
                 // local direction (east, north, up) and rotation: horizon_comp.cpp:357-361, :55-62
                 const float ec = t.elev_cos[s.ind], es = t.elev_sin[s.ind];
@@ -172,9 +180,10 @@ __global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : HZ_WG_PER_CU) void k_horizon(Ho
                 dy = (r10 * rx + r11 * ry) + r12 * rz;
                 dz = (r20 * rx + r21 * ry) + r22 * rz;
                 tn = 0.0f;
-                if (p.near_idx != nullptr && s.ind >= (int)p.near_idx[(size_t)cert * (size_t)t.azim_num + s.k]) tn = p.near_r[cert];
+                if (p.near_idx != nullptr && s.ind >= (int)p.near_idx[(size_t)cert_r * (size_t)t.azim_num + s.k]) tn = p.near_r[cert_r];
                 if (COUNT && tn > 0.0f) shortened++;
                 if (COUNT) want_v = p.verify_near && tn > 0.0f && (((rays + cert) & p.verify_mask) == 0u);
+                HZ_OC(ocx, ocy, ocz)
                 rb = hz_raybox(ocx + tn * dx, ocy + tn * dy, ocz + tn * dz, dx, dy, dz);
                 hz_trav_reset(ts);
                 // a ray below the previous azimuth's horizon is expected to be blocked near the same ridge
@@ -196,6 +205,7 @@ __global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : HZ_WG_PER_CU) void k_horizon(Ho
             } else if (COUNT && want_v && r != 2) {
                 // the shortened ray is done: trace it again over its full length and compare the decisions
                 want_v = false; verifying = true; first_result = (r == 1); start_v = true;
+                HZ_OC(ocx, ocy, ocz)
                 rb = hz_raybox(ocx, ocy, ocz, dx, dy, dz);
                 hz_trav_reset(ts);
             } else if (r != 2) {

@@ -12,7 +12,7 @@
 //   5. k_leaf_boxes / k_refit_pass  leaf AABBs; bottom-up union, level synchronous with work lists
 //   6. k_roots/scan  collapse along the 2-bit Morton digits: a binary node starts a 4-wide
 //                    node when its common-prefix length enters a new digit (quadtree level)
-//   7. k_emit4       temp 4-wide nodes with conservatively quantised child AABBs (8 bit x/y, 11 bit z as half floats),
+//   7. k_emit4       temp 4-wide nodes with conservatively quantised child bounds (8 bit; one x range per column half, one y range per row half, one z range per child),
 //                    children sorted tallest first
 //   8. k_bfs_*       breadth-first numbering of ALL nodes, level by level, with the children of every node in one
 //                    contiguous block of 4 slots (nodes or 48 B leaf records); emits the final nodes and leaves
@@ -276,8 +276,8 @@ __global__ __launch_bounds__(256) void k_roots(int n_nodes, const int *__restric
 struct NodeTmp {
     float org[3];        // quantisation origins with the step exponents in their low mantissa bits (hz_common.h: Node)
     uint32_t pad_;
-    uint32_t qxy[4], qz[4];
-    int32_t link[4];     // >= 0 temp node, < 0 leaf (~sorted position), HZ_TMP_EMPTY none
+    uint32_t qx, qy, qz[2];   // as in Node
+    int32_t link[4];     // per quadrant slot: >= 0 temp node, < 0 leaf (~sorted position), HZ_TMP_EMPTY none
 };
 
 struct Emit4 {
@@ -314,19 +314,13 @@ __device__ __forceinline__ uint32_t step_exponent(float extent, float qmax) {
     return (uint32_t)biased;
 }
 
-// x / y bounds (hz_common.h: hz_qbox_hit).  The traversal decodes code q in [0, 255] as the half float 1024 + q and
+// Bounds (hz_common.h: hz_node_hits).  The traversal decodes code q in [0, 255] as the half float 1024 + q and
 // evaluates t = (1024 + q) * (s rd) + (o' rd - oc rd) with the STORED origin o' ~ lo_node - 1024 s.  In exact
 // arithmetic that is the plane X(q) = o' + (1024 + q) s; the build guarantees X(q_lo) <= lo - m and X(q_hi) >= hi + m,
 // checked in float64 (exact for these operands).  m = s 2^-12 pays for what the 1024 s offset adds to the rounding
 // of the two ray constants (b = fma(o', rd, -oc rd): |o'| grows by <= 1024 s, so its rounding by <= 1024 s 2^-24 =
 // s 2^-14 in space units; the origin's own rounding is below that) -- everything else is the error
 // structure the leaf padding has covered since round 1.
-// z bounds: integers 0 .. HZ_QZ_MAX stored as half floats (exact)
-#ifdef HZ_PROBE_NODE32_BOUNDS
-#define HZ_QZ_MAX 255.0f
-#else
-#define HZ_QZ_MAX 2047.0f
-#endif
 struct AxisQ { uint32_t e; float s, o, m; };
 __device__ __forceinline__ double axis_plane(const AxisQ &a, float q) { return (double)a.o + (double)(1024.0f + q) * (double)a.s; }
 // The step exponents travel in the low 9 mantissa bits of the node's x and z origins (bit 8 zero, bits 7..0 the biased
@@ -373,13 +367,11 @@ __device__ __forceinline__ void axes_setup(float xl, float xh, float yl, float y
         e++;
     }
 }
-// z: origin with the exponent bits at or below the node's lower bound, step such that code 2047 reaches its upper bound
-__device__ __forceinline__ void z_setup(float zl, float zh, float &oz, float &sz) {
-    uint32_t e = step_exponent(zh - zl, HZ_QZ_MAX - 7.0f);
+// z: a step of its own, the exponent bits in the origin
+__device__ __forceinline__ void axis_setup_z(float zl, float zh, AxisQ &az) {
+    uint32_t e = step_exponent(zh - zl, 250.0f);
     for (;;) {
-        sz = __uint_as_float(e << 23);
-        oz = embed_down(zl, e);
-        if (__builtin_fmaf(HZ_QZ_MAX, sz, oz) >= zh || e >= 254u) break;
+        if (axis_try(az, zl, zh, e, true) || e >= 254u) break;
         e++;
     }
 }
@@ -397,14 +389,11 @@ __device__ __forceinline__ uint32_t axis_hi(const AxisQ &a, float hi) {
     while (q > 0.0f && axis_plane(a, q - 1.0f) >= want) q -= 1.0f;
     return (uint32_t)q;
 }
-// z bounds: integers 0 .. 2047 stored as half floats (exact), decoded as o + q s with the node's own lower corner
-
-__device__ __forceinline__ uint32_t half_bits(uint32_t q) {
-    const _Float16 h = (_Float16)(float)q;
-    return (uint32_t)__builtin_bit_cast(unsigned short, h);
+#define HZ_PAIR_EMPTY 0x00ffu         // (lo = 255, hi = 0): a range nothing can hit
+// one (lo, hi) byte pair
+__device__ __forceinline__ uint32_t axis_pair(const AxisQ &a, float lo, float hi) {
+    return (lo <= hi) ? (axis_lo(a, lo) | (axis_hi(a, hi) << 8)) : HZ_PAIR_EMPTY;
 }
-#define HZ_QXY_EMPTY 0x00ff00ffu      // lo > hi on every axis: never hit
-#define HZ_QZ_EMPTY 0x000067ffu       // half(2047) | half(0) << 16
 
 __global__ __launch_bounds__(256) void k_emit4(Emit4 e, NodeTmp *__restrict__ nodes) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -443,61 +432,40 @@ __global__ __launch_bounds__(256) void k_emit4(Emit4 e, NodeTmp *__restrict__ no
             if (k == slot) { link[k] = lk; lo[k][0] = bl.x; lo[k][1] = bl.y; lo[k][2] = bl.z;
                              hi[k][0] = bh.x; hi[k][1] = bh.y; hi[k][2] = bh.z; }
     }
-#ifdef HZ_PROBE_NODE32_BOUNDS
-    // Probe: the bounds a 32 B node (two 16 B loads per visit) could hold -- per axis ONE range for the two children of
-    // each half of the quadrant split (x: same column bit, y: same row bit), z in 8 bits, children in quadrant order.
-    // How many more node visits do the looser boxes cost?  (scripts/build_variant.sh n32 -DHZ_PROBE_NODE32_BOUNDS)
-    {
-        float hl[2][2], hh[2][2];      // [axis][half]
-        for (int a = 0; a < 2; a++) for (int h = 0; h < 2; h++) { hl[a][h] = INFINITY; hh[a][h] = -INFINITY; }
-        for (int k = 0; k < 4; k++) {
-            if (link[k] == HZ_TMP_EMPTY) continue;
-            const int hx = k & 1, hy = k >> 1;
-            hl[0][hx] = fminf(hl[0][hx], lo[k][0]); hh[0][hx] = fmaxf(hh[0][hx], hi[k][0]);
-            hl[1][hy] = fminf(hl[1][hy], lo[k][1]); hh[1][hy] = fmaxf(hh[1][hy], hi[k][1]);
-        }
-        for (int k = 0; k < 4; k++) {
-            if (link[k] == HZ_TMP_EMPTY) continue;
-            lo[k][0] = hl[0][k & 1]; hi[k][0] = hh[0][k & 1];
-            lo[k][1] = hl[1][k >> 1]; hi[k][1] = hh[1][k >> 1];
-        }
-    }
-#else
-    // the traversal visits slot 0 first: put the tallest child there (a blocked ray is most likely
-    // blocked by the child that reaches highest), empty slots last
-    {
-        auto key = [&](int k) { return link[k] == HZ_TMP_EMPTY ? -INFINITY : hi[k][2]; };
-        auto cswap = [&](int x, int y) {
-            if (key(x) < key(y)) {
-                const int t = link[x]; link[x] = link[y]; link[y] = t;
+    // The children stay in quadrant order (slot = 2 * row bit + column bit of this node's Morton digit): the two children
+    // of a column half share ONE x range, the two of a row half ONE y range -- what the 32 B node holds (hz_common.h).  For
+    // a DEM whose grid is aligned with the axes these are the children's own ranges; for rotated / curved grids the union
+    // over the half.  Measured against per-child ranges + 11-bit z + tallest-first order (48 B nodes): +0.9 % node visits,
+    // +1.8 % leaf visits (profiles/r04/probe_node32_bounds_and_wg6.log), for one 16 B load less per visit.
+    float hl[2][2], hh[2][2];      // [axis][half]
 #pragma unroll
-                for (int q = 0; q < 3; q++) {
-                    float f = lo[x][q]; lo[x][q] = lo[y][q]; lo[y][q] = f;
-                    f = hi[x][q]; hi[x][q] = hi[y][q]; hi[y][q] = f;
-                }
-            }
-        };
-        cswap(0, 1); cswap(2, 3); cswap(0, 2); cswap(1, 3); cswap(1, 2);
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) { hl[a][h] = INFINITY; hh[a][h] = -INFINITY; }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (link[k] == HZ_TMP_EMPTY) continue;
+        const int hx = k & 1, hy = k >> 1;
+        hl[0][hx] = fminf(hl[0][hx], lo[k][0]); hh[0][hx] = fmaxf(hh[0][hx], hi[k][0]);
+        hl[1][hy] = fminf(hl[1][hy], lo[k][1]); hh[1][hy] = fmaxf(hh[1][hy], hi[k][1]);
     }
-#endif
     const float4 nl = e.node_lo[i], nh = e.node_hi[i];
-    AxisQ ax, ay;
+    AxisQ ax, ay, az;
     axes_setup(nl.x, nh.x, nl.y, nh.y, ax, ay);
-    float oz, sz;
-    z_setup(nl.z, nh.z, oz, sz);
+    axis_setup_z(nl.z, nh.z, az);
     NodeTmp n;
-    n.org[0] = ax.o; n.org[1] = ay.o; n.org[2] = oz;
+    n.org[0] = ax.o; n.org[1] = ay.o; n.org[2] = az.o;
     n.pad_ = 0u;
+    n.qx = axis_pair(ax, hl[0][0], hh[0][0]) | (axis_pair(ax, hl[0][1], hh[0][1]) << 16);
+    n.qy = axis_pair(ay, hl[1][0], hh[1][0]) | (axis_pair(ay, hl[1][1], hh[1][1]) << 16);
+    uint32_t zq[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         n.link[k] = link[k];
-        if (link[k] == HZ_TMP_EMPTY) { n.qxy[k] = HZ_QXY_EMPTY; n.qz[k] = HZ_QZ_EMPTY; continue; }   // lo > hi: never hit
-        const uint32_t xl = axis_lo(ax, lo[k][0]), xh = axis_hi(ax, hi[k][0]);
-        const uint32_t yl = axis_lo(ay, lo[k][1]), yh = axis_hi(ay, hi[k][1]);
-        const uint32_t zl = quant_lo(lo[k][2], oz, sz, HZ_QZ_MAX), zh = quant_hi(hi[k][2], oz, sz, HZ_QZ_MAX);
-        n.qxy[k] = xl | (xh << 8) | (yl << 16) | (yh << 24);
-        n.qz[k] = half_bits(zl) | (half_bits(zh) << 16);
+        zq[k] = (link[k] == HZ_TMP_EMPTY) ? HZ_PAIR_EMPTY : axis_pair(az, lo[k][2], hi[k][2]);
     }
+    n.qz[0] = zq[0] | (zq[1] << 16);
+    n.qz[1] = zq[2] | (zq[3] << 16);
     nodes[e.idx[i]] = n;
 }
 
@@ -580,8 +548,7 @@ __global__ __launch_bounds__(256) void k_bfs_emit(BfsEmit e, BuildParams b) {
     bfs_kinds(t, ni, nl);
     Node n;
     n.org[0] = t.org[0]; n.org[1] = t.org[1]; n.org[2] = t.org[2];
-#pragma unroll
-    for (int k = 0; k < 4; k++) { n.qxy[k] = t.qxy[k]; n.qz[k] = t.qz[k]; }
+    n.qx = t.qx; n.qy = t.qy; n.qz[0] = t.qz[0]; n.qz[1] = t.qz[1];
     if (ni == 0) {                                        // all children are leaves: one leaf block
         const int lb = e.leaf_blocks_before + (int)e.scan_leaf[pos];
         n.first = (int)(HZ_LEAF_BIT | (unsigned)(4 * lb));
@@ -598,11 +565,13 @@ __global__ __launch_bounds__(256) void k_bfs_emit(BfsEmit e, BuildParams b) {
             if (t.link[k] >= 0) f = t.link[k];
             else if (t.link[k] != HZ_TMP_EMPTY) {
                 f = -2 - (~t.link[k]);
-                Node w;                                    // single-child node: this slot's box in this node's frame
-                w.org[0] = n.org[0]; w.org[1] = n.org[1]; w.org[2] = n.org[2];
+                Node w;                                    // single-child node: this slot's box in this node's frame,
+                w.org[0] = n.org[0]; w.org[1] = n.org[1]; w.org[2] = n.org[2];     // moved to slot 0 of the wrapper
                 w.first = 0;
-                for (int q = 0; q < 4; q++) { w.qxy[q] = HZ_QXY_EMPTY; w.qz[q] = HZ_QZ_EMPTY; }
-                w.qxy[0] = t.qxy[k]; w.qz[0] = t.qz[k];
+                w.qx = ((n.qx >> (16 * (k & 1))) & 0xffffu) | (HZ_PAIR_EMPTY << 16);
+                w.qy = ((n.qy >> (16 * (k >> 1))) & 0xffffu) | (HZ_PAIR_EMPTY << 16);
+                w.qz[0] = ((n.qz[k >> 1] >> (16 * (k & 1))) & 0xffffu) | (HZ_PAIR_EMPTY << 16);
+                w.qz[1] = HZ_PAIR_EMPTY | (HZ_PAIR_EMPTY << 16);
                 e.nodes[first + k] = w;
             }
             e.next_frontier[4 * rel + k] = f;
@@ -629,17 +598,18 @@ __global__ __launch_bounds__(256) void k_anc_bfs(int n_leaf_blocks, int levels, 
 // single primitive: a temp root whose slot 0 is the leaf, quantised against its own box
 __global__ void k_single_tmp(const float4 *leaf_lo, const float4 *leaf_hi, NodeTmp *nodes) {
     const float4 l = leaf_lo[0], h = leaf_hi[0];
-    AxisQ ax, ay;
+    AxisQ ax, ay, az;
     axes_setup(l.x, h.x, l.y, h.y, ax, ay);
-    float oz, sz;
-    z_setup(l.z, h.z, oz, sz);
+    axis_setup_z(l.z, h.z, az);
     NodeTmp n;
-    n.org[0] = ax.o; n.org[1] = ay.o; n.org[2] = oz;
+    n.org[0] = ax.o; n.org[1] = ay.o; n.org[2] = az.o;
     n.pad_ = 0u;
-    for (int k = 0; k < 4; k++) { n.link[k] = HZ_TMP_EMPTY; n.qxy[k] = HZ_QXY_EMPTY; n.qz[k] = HZ_QZ_EMPTY; }
+    for (int k = 0; k < 4; k++) n.link[k] = HZ_TMP_EMPTY;
     n.link[0] = ~0;
-    n.qxy[0] = axis_lo(ax, l.x) | (axis_hi(ax, h.x) << 8) | (axis_lo(ay, l.y) << 16) | (axis_hi(ay, h.y) << 24);
-    n.qz[0] = half_bits(quant_lo(l.z, oz, sz, HZ_QZ_MAX)) | (half_bits(quant_hi(h.z, oz, sz, HZ_QZ_MAX)) << 16);
+    n.qx = axis_pair(ax, l.x, h.x) | (HZ_PAIR_EMPTY << 16);
+    n.qy = axis_pair(ay, l.y, h.y) | (HZ_PAIR_EMPTY << 16);
+    n.qz[0] = axis_pair(az, l.z, h.z) | (HZ_PAIR_EMPTY << 16);
+    n.qz[1] = HZ_PAIR_EMPTY | (HZ_PAIR_EMPTY << 16);
     nodes[0] = n;
 }
 

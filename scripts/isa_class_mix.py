@@ -94,7 +94,7 @@ def main():
             blocks.append((i, j, sum("global_load_dwordx4" in x for x in k[i:j])))
             i = j
         i += 1
-    node = next(x for x in blocks if x[2] == 3)                      # 48 B node: three 16 B loads (round 4; four before)
+    node = next(x for x in blocks if x[2] == 2)                      # 32 B node: two 16 B loads (three for the 48 B node of early round 4, four before)
     leaf = next(x for x in blocks if x[2] == 3 and x[0] > node[0])   # 48 B leaf record
     # main loop: the innermost loop header before the node block ... the last backward branch after the leaf block
     hdr = max(i for i in range(node[0]) if "=>This Inner Loop Header" in k[i] or "Inner Loop Header" in k[i])
