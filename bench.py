@@ -53,7 +53,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-NODE_BYTES = 48.0       # one 4-wide LBVH node (hz_common.h: Node; 64 B until round 3): the bytes a node visit reads
+NODE_BYTES = 32.0       # one 4-wide LBVH node (hz_common.h: Node; 64 B until round 3, 48 B early in round 4): the bytes a node visit reads
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable
 KERNEL_SOURCES = ("hz_common.h", "hz_search.h", "hz_horizon.hip")   # what the traffic figure was measured for
 
@@ -1023,7 +1023,7 @@ def run_c4(ctx):
     V = n * n
     out_b = 1 if shadow else 4
     # SURVEY 8(d) "shadow bytes": 12 V + 33 C once at initialise, 1 C (shadow) / 4 C (sw_dir_cor) per sun position;
-    # B_trav = rays x (node visits x 48 B + triangle tests x 24 B) from the counting pass -- served by the caches
+    # B_trav = rays x (node visits x 32 B + triangle tests x 24 B) from the counting pass -- served by the caches
     b_io = S * out_b * cells + (12.0 * V + 33.0 * cells)
     b_trav = (cw["nodes_visited"] * NODE_BYTES + cw["tris_tested"] * 24.0) if cw else 0.0
     alg = (b_io + b_trav) / k_step / 1e9 if k_step else None
