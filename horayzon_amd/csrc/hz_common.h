@@ -305,6 +305,7 @@ __device__ __forceinline__ NodeRay hz_node_ray(const RayBox &r, float ox, float 
 // instead of 12 + 24, and two 16 B loads per visit instead of three.
 #define HZ_HALF_MAGIC 0x64646464u
 typedef _Float16 hz_half2 __attribute__((ext_vector_type(2)));
+typedef int hz_int2 __attribute__((ext_vector_type(2)));
 
 // (float)half * a + b as ONE v_fma_mix_f32 (the compiler folds the conversion into the FMA's operand modifier; written in
 // C++ rather than inline asm so that it knows the results are arithmetic values: no canonicalising v_max_f32 before min / max)
@@ -333,15 +334,28 @@ __device__ __forceinline__ void hz_node_hits(const NodeRay &n, const RayBox &r, 
 #else
 #define HZ_SLACK(x) ((x) * 1.000001f)
 #endif
+    // the ray's own interval [0, tfar] is folded into the two x terms, which every child shares with one other child:
+    // 2 + 2 instead of 4 + 4 clamps, and one max3 / min3 per child
+#ifdef HZ_V_NO_XCLAMP
+    const float cx0 = nx0, cx1 = nx1, gx0 = fx0, gx1 = fx1;
 #define HZ_CHILD(pz, nx, fx, ny, fy, out) do { \
         const float nz_ = hz_fma_mix_lo(pz, n.az, n.bz), fz_ = hz_fma_mix_hi(pz, n.az, n.bz); \
         const float tmin_ = __builtin_fmaxf(__builtin_fmaxf(nx, ny), __builtin_fmaxf(nz_, 0.0f)); \
         const float tmax_ = __builtin_fminf(__builtin_fminf(fx, fy), __builtin_fminf(fz_, tfar)); \
         out = tmin_ <= HZ_SLACK(tmax_); } while (0)
-    HZ_CHILD(pz0, nx0, fx0, ny0, fy0, h0);      // slot k: column half k & 1, row half k >> 1
-    HZ_CHILD(pz1, nx1, fx1, ny0, fy0, h1);
-    HZ_CHILD(pz2, nx0, fx0, ny1, fy1, h2);
-    HZ_CHILD(pz3, nx1, fx1, ny1, fy1, h3);
+#else
+    const float cx0 = __builtin_fmaxf(nx0, 0.0f), cx1 = __builtin_fmaxf(nx1, 0.0f);
+    const float gx0 = __builtin_fminf(fx0, tfar), gx1 = __builtin_fminf(fx1, tfar);
+#define HZ_CHILD(pz, nx, fx, ny, fy, out) do { \
+        const float nz_ = hz_fma_mix_lo(pz, n.az, n.bz), fz_ = hz_fma_mix_hi(pz, n.az, n.bz); \
+        const float tmin_ = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz_); \
+        const float tmax_ = __builtin_fminf(__builtin_fminf(fx, fy), fz_); \
+        out = tmin_ <= HZ_SLACK(tmax_); } while (0)
+#endif
+    HZ_CHILD(pz0, cx0, gx0, ny0, fy0, h0);      // slot k: column half k & 1, row half k >> 1
+    HZ_CHILD(pz1, cx1, gx1, ny0, fy0, h1);
+    HZ_CHILD(pz2, cx0, gx0, ny1, fy1, h2);
+    HZ_CHILD(pz3, cx1, gx1, ny1, fy1, h3);
 #undef HZ_CHILD
 #undef HZ_SLACK
 }
@@ -351,6 +365,10 @@ __device__ __forceinline__ void hz_node_hits(const NodeRay &n, const RayBox &r, 
 // the first half of round 4 48 B ones (three): the vector-memory pipe is the kernel's co-limit -- every load instruction
 // per visit is worth ~4 % (+1 load: -3 %, round 3; 4 -> 3 loads: +4.2 %; a fire-and-forget prefetch load: -6 %).
 __device__ __forceinline__ void hz_load_node(const Node *n, float4 &n0, uint4 &n1) {
+#ifdef HZ_PROBE_PAD_VMEM   // sensitivity probe: one more (4 B, same cache line) vector-memory instruction per node visit
+    unsigned pad_;
+    asm volatile("global_load_dword %0, %1, off offset:4" : "=&v"(pad_) : "v"(n) : "memory");
+#endif
     asm volatile("global_load_dwordx4 %0, %2, off\n\t"
                  "global_load_dwordx4 %1, %2, off offset:16\n\t"
                  "s_waitcnt vmcnt(0)"
@@ -427,17 +445,46 @@ __device__ __forceinline__ void hz_entry_unpack(int e, int &pf, int &pm) {
 //          host repeats that launch with the other discipline.
 //   true:  one entry per level as described above: `height` entries, no overflow case (+10 % VALU instructions on
 //          the 3601^2 tile).
+// Sensitivity probes (scripts/build_variant.sh <name> -DHZ_PROBE_PAD_SLOW=8 ...; results unchanged): n dead instructions of one
+// kind per node step -- what does the node step wait for?  slow / fast: the two VALU issue classes; LDS: ds_write to the
+// lane's own free stack entry; SALU: scalar moves.
+#if defined(HZ_PROBE_PAD_SLOW) || defined(HZ_PROBE_PAD_FAST) || defined(HZ_PROBE_PAD_LDS) || defined(HZ_PROBE_PAD_SALU)   // (HZ_PROBE_PAD_VMEM: see hz_load_node)
+#ifndef HZ_PROBE_PAD_SLOW
+#define HZ_PROBE_PAD_SLOW 0
+#endif
+#ifndef HZ_PROBE_PAD_FAST
+#define HZ_PROBE_PAD_FAST 0
+#endif
+#ifndef HZ_PROBE_PAD_LDS
+#define HZ_PROBE_PAD_LDS 0
+#endif
+#ifndef HZ_PROBE_PAD_SALU
+#define HZ_PROBE_PAD_SALU 0
+#endif
+#define HZ_PROBE_PADS(seed) do { \
+        float pad_a_ = (seed), pad_b_ = (seed); unsigned pad_s_; \
+        _Pragma("unroll") for (int q_ = 0; q_ < HZ_PROBE_PAD_SLOW; q_ += 2) { \
+            asm volatile("v_max_f32 %0, %0, %0" : "+v"(pad_a_)); asm volatile("v_max_f32 %0, %0, %0" : "+v"(pad_b_)); } \
+        _Pragma("unroll") for (int q_ = 0; q_ < HZ_PROBE_PAD_FAST; q_ += 2) { \
+            asm volatile("v_xor_b32 %0, 1, %0" : "+v"(pad_a_)); asm volatile("v_xor_b32 %0, 1, %0" : "+v"(pad_b_)); } \
+        _Pragma("unroll") for (int q_ = 0; q_ < HZ_PROBE_PAD_SALU; q_++) asm volatile("s_mov_b32 %0, 0" : "=s"(pad_s_)); \
+        if (!LEVELSTACK) { _Pragma("unroll") for (int q_ = 0; q_ < HZ_PROBE_PAD_LDS; q_++) \
+            asm volatile("ds_write_b32 %0, %1 offset:2048" : : "v"(sa), "v"(pad_a_) : "memory"); } \
+    } while (0)
+#else
+#define HZ_PROBE_PADS(seed) do { } while (0)
+#endif
 template <int TPB, bool COUNT, int QLEN = 2, bool NODELET = false, bool LEVELSTACK = true>
 __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Prim *__restrict__ prims,
                                         const float4 *top, int ntop, int *stack, int tid,
                                         float ox, float oy, float oz, float dx, float dy, float dz, float tfar,
                                         const RayBox &rb, TravState &t, int regroup, int leaf_bias,
-                                        TravCounters &cnt, int stack_cap, unsigned &overflow) {
+                                        TravCounters &cnt, int stack_cap, bool &overflow) {
     const int lane = tid & 63;
     int node = t.node, sp = t.sp, pf = t.pf, pm = t.pm, lq0 = t.lq0, lq1 = t.lq1;
     const int n_entry = __popcll(__ballot(1));   // lanes that entered with a ray
 // next link.  LEVELSTACK: a pending sibling of the current level, else of the closest level above that has one (LDS);
-// else: the top LDS entry (branch-free: read the clamped top, keep it only if the stack was not empty)
+// else: the top LDS entry -- entry 0 of every lane holds HZ_EMPTY, so a pop needs no "is the stack empty" test
 #define HZ_POP() do { \
         if (LEVELSTACK) { \
             if (pm == 0) { const bool ne = sp > 0; sp = ne ? sp - 1 : 0; const int pv = stack[sp * TPB + tid]; \
@@ -445,17 +492,32 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
             const int slot_ = __builtin_ctz((unsigned)pm | 16u); \
             node = (pm != 0) ? pf + slot_ : HZ_EMPTY; pm &= pm - 1; \
         } else { \
-            const bool ne = sa != sa0; sa = ne ? sa - (unsigned)(TPB * 4) : sa; const int pv = HZ_STACK_AT(sa); \
-            node = ne ? pv : HZ_EMPTY; \
+            node = HZ_STACK_AT(sa + (unsigned)(TPB * 4)); sa -= (unsigned)(TPB * 4); \
         } } while (0)
-// the fast discipline keeps its stack pointer as the BYTE offset of this lane's next free entry (sa = sa0 + sp * TPB * 4):
-// a push is a ds_write at `sa` and an add, no shift-and-add per access
-#define HZ_STACK_AT(off) (*reinterpret_cast<int *>(reinterpret_cast<char *>(stack) + (off)))
-#define HZ_SAVE() do { if (!LEVELSTACK) sp = (int)((sa - sa0) / (unsigned)(TPB * 4)); \
+// The fast discipline (round 4: the wave's instruction count is what the node step pays for -- any instruction, scalar ones
+// included, profiles/r04/sensitivity_pads.log -- so everything below is written for the fewest instructions):
+//   * `sa` is the LDS BYTE ADDRESS of the entry BELOW this lane's top entry (sa = sa0 + (sp - 1) * TPB * 4 with the LDS base
+//     folded into sa0): the top two entries, the pop value of a node step and its three push slots are all `sa` + an
+//     immediate offset -- a stack access is one ds instruction, no address arithmetic.  Entry 0 is a sentinel holding
+//     HZ_EMPTY (sp = 0: only the sentinel, sa one row below the stack -- that row is read with the top, never used).
+//     A finished ray pops the sentinel (sp = -1); its lane then holds HZ_EMPTY and never pops or pushes again, but it
+//     keeps reading "the top two entries" while its queued leaves are tested: the caller keeps two rows (2 x TPB x 4
+//     bytes) of LDS in front of the stack.
+//   * the two top entries are read once per iteration (one ds_read2st64_b32); the two queue fills below are selects;
+//   * a node step stores its three push candidates unconditionally above the top and advances `sa` by a select per
+//     candidate (garbage above the top is harmless: `sa_cap` keeps three entries free) -- no exec-mask branch per push;
+//   * `overflow` is a lane mask in scalar registers (what the caller needs is "any lane of the wave").
+typedef __attribute__((address_space(3))) int hz_lds_int;
+#define HZ_STACK_AT(addr) (*reinterpret_cast<hz_lds_int *>((size_t)(addr)))
+#define HZ_SAVE() do { if (!LEVELSTACK) sp = (int)(sa - sa0) / (TPB * 4) + 1; \
                        t.node = node; t.sp = sp; t.pf = pf; t.pm = pm; t.lq0 = lq0; t.lq1 = lq1; } while (0)
-    const unsigned sa0 = (unsigned)tid * 4u;
-    unsigned sa = sa0 + (unsigned)sp * (unsigned)(TPB * 4);
-    const unsigned sa_cap = sa0 + (unsigned)(stack_cap - 3) * (unsigned)(TPB * 4);
+    const unsigned sa0 = (unsigned)(size_t)reinterpret_cast<hz_lds_int *>(
+                             (__attribute__((address_space(3))) char *)reinterpret_cast<char *>(stack)) + (unsigned)tid * 4u;
+    unsigned sa = sa0 + (unsigned)(sp - 1) * (unsigned)(TPB * 4);
+    const unsigned sa_cap = sa0 + (unsigned)(stack_cap - 5) * (unsigned)(TPB * 4);
+    if (!LEVELSTACK) HZ_STACK_AT(sa0) = HZ_EMPTY;
+    unsigned sa_hi = sa;          // highest stack pointer of this call (overflow is decided once, at the exit)
+    const int n_leave = min(regroup, n_entry);   // suspend below this many traversing lanes (see `regroup`)
     int res = -1;                 // single exit: lanes leave the loop through `res`, state is saved once
 #ifdef HZ_PREFETCH
     // Probe (scripts/build_variant.sh pf -DHZ_PREFETCH): touch the cache line of the link a node step has just chosen with
@@ -472,8 +534,33 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
     while (res < 0) {
         // set leaves aside while the leaf queue (QLEN entries, filled front to back; a queued leaf is negative, an empty
         // place HZ_EMPTY) has room
-        if (node < 0 && lq0 >= 0) { lq0 = node; HZ_POP(); }
-        if (node < 0 && lq1 >= 0) { lq1 = node; HZ_POP(); }
+        if (LEVELSTACK) {
+            if (node < 0 && lq0 >= 0) { lq0 = node; HZ_POP(); }
+            if (node < 0 && lq1 >= 0) { lq1 = node; HZ_POP(); }
+        } else {
+            // top entry and the one below it (the row below the sentinel belongs to the caller's staging buffer or padding:
+            // read with the sentinel, never used)
+#ifdef HZ_V_NO_READ2ASM
+            int t0 = HZ_STACK_AT(sa + (unsigned)(TPB * 4));
+            const int t1 = HZ_STACK_AT(sa);
+#else
+            hz_int2 t10;
+            asm volatile("ds_read2st64_b32 %0, %1 offset1:4\n\ts_waitcnt lgkmcnt(0)" : "=v"(t10) : "v"(sa) : "memory");
+            int t0 = t10.y;
+            const int t1 = t10.x;
+#endif
+            // "node is a leaf link (negative) and the place is free (HZ_EMPTY: positive)" as ONE vector compare of
+            // node & ~place: scalar logic on two compare results waits for both (round 4: a scalar instruction that
+            // consumes a vector compare costs about 1 % of the kernel, profiles/r04/ab_scalar_mask_logic.log)
+            int m1 = node & ~lq0;
+            asm volatile("" : "+v"(m1));
+            const bool c1 = m1 < 0;
+            lq0 = c1 ? node : lq0; node = c1 ? t0 : node; t0 = c1 ? t1 : t0; sa -= c1 ? (unsigned)(TPB * 4) : 0u;
+            int m2 = node & ~lq1;
+            asm volatile("" : "+v"(m2));
+            const bool c2 = m2 < 0;
+            lq1 = c2 ? node : lq1; node = c2 ? t0 : node; sa -= c2 ? (unsigned)(TPB * 4) : 0u;
+        }
         const bool can_node = HZ_IS_NODE(node);
         const bool can_leaf = lq0 < 0;
         // votes taken before any lane leaves: a lane that is finished contributes to neither mask, so the
@@ -483,7 +570,7 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
         if (!can_node && !can_leaf) { res = 0; continue; }                    // nothing left: miss
         // ray compaction: suspend only if some lane finished its ray in this call (it can refill,
         // so the caller always makes progress)
-        if (n_all < regroup && n_all < n_entry) { res = 2; continue; }
+        if (n_all < n_leave) { res = 2; continue; }
         const int n_node = __popcll(m_node);
         const int n_leaf = __popcll(m_leaf);
         if (n_node * 16 >= n_leaf * leaf_bias) {
@@ -505,6 +592,7 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
                 bool h0, h1, h2, h3;
                 hz_node_hits(nr, rb, tfar, n1, h0, h1, h2, h3);
                 const int first = __float_as_int(n0.w);
+                HZ_PROBE_PADS(n0.x);
                 if (LEVELSTACK) {
                     const int h = (h0 ? 1 : 0) | (h1 ? 2 : 0) | (h2 ? 4 : 0) | (h3 ? 8 : 0);
                     if (h != 0) {                    // the hit children become the pending set of this level ...
@@ -513,17 +601,23 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
                     }
                     HZ_POP();                        // ... and the first of them (or of a level above) is entered
                 } else {
-                    if (sa > sa_cap) { overflow = 1u; sa = sa_cap; }
-                    // branch-free pushes: the candidate is always stored at the stack top and only kept (pointer advanced)
-                    // when it was a real link.  "It was a real link" = a higher slot was hit: known from the hit flags, which
-                    // are lane masks in scalar registers -- no vector compare per push (round 4: the node step waits for its
-                    // slow-class instructions, and v_cmp / v_lshl_add are slow class)
-                    const bool p2 = h3, p1 = h3 || h2, p0 = p1 || h1;
-                    int next = h3 ? first + 3 : HZ_EMPTY;
-                    if (h2) { HZ_STACK_AT(sa) = next; sa += p2 ? (unsigned)(TPB * 4) : 0u; next = first + 2; }
-                    if (h1) { HZ_STACK_AT(sa) = next; sa += p1 ? (unsigned)(TPB * 4) : 0u; next = first + 1; }
-                    if (h0) { HZ_STACK_AT(sa) = next; sa += p0 ? (unsigned)(TPB * 4) : 0u; next = first; }
-                    if (p0 || h0) node = next; else HZ_POP();
+                    // out of entries: remember the highest pointer (checked once, at the exit) and clamp
+                    sa_hi = max(sa_hi, sa);
+                    sa = min(sa, sa_cap);
+                    // Pushes without a branch and without scalar logic: the three candidates are always stored above the top
+                    // and only kept (pointer advanced) when they were real links, i.e. when a higher slot was hit too.  The
+                    // hit flags become 0 / one-entry steps in vector registers once (a_k), "a higher slot was hit" is an OR of
+                    // those, "advance" an AND; the lane without a hit child continues with the top entry pv and steps down.
+                    const unsigned S = (unsigned)(TPB * 4);
+                    const int pv = HZ_STACK_AT(sa + S);
+                    unsigned a0 = h0 ? S : 0u, a1 = h1 ? S : 0u, a2 = h2 ? S : 0u, a3 = h3 ? S : 0u;
+                    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));    // (keeps them out of the compiler's mask algebra)
+                    const unsigned o32 = a3 | a2, o321 = o32 | a1, o3210 = o321 | a0;
+                    int next = h3 ? first + 3 : pv;
+                    HZ_STACK_AT(sa + 2u * S) = next; sa += a2 & a3;   next = h2 ? first + 2 : next;
+                    HZ_STACK_AT(sa + 2u * S) = next; sa += a1 & o32;  next = h1 ? first + 1 : next;
+                    HZ_STACK_AT(sa + 2u * S) = next; sa += a0 & o321; next = h0 ? first : next;
+                    node = next; sa = sa + o3210 - S;
                 }
                 HZ_PF(node);
             }
@@ -544,6 +638,7 @@ __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Pr
 #ifdef HZ_PREFETCH
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) : : "memory");
 #endif
+    if (!LEVELSTACK && sa_hi > sa_cap) overflow = true;
     HZ_SAVE();
     return res;
 #undef HZ_PF

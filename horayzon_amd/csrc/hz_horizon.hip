@@ -44,6 +44,8 @@ struct HorizonParams {
     TileMap tm;                    // tile grid of the slab -> workgroups (XCD aware)
     float dist, hori_fill, ray_org_elev;
     int top_nodes, regroup, stack_bytes, leaf_bias, stage_bytes, hit_cache, stack_cap;
+    int pre_bytes;                 // LDS in front of the stack: the output staging buffer, or (no staging) two padding rows --
+                                   // the fast stack reads the rows below its sentinel together with the top (hz_trace)
     const unsigned short *near_idx;   // near-field certificates of this launch's rows (hz_near.hip) or null
     const float *near_r;
     int verify_near;               // 0: off; else re-trace the shortened rays selected by verify_mask over their full length
@@ -66,12 +68,12 @@ template <int ALG, bool COUNT, bool STAGE, bool NODELET, bool LEVELSTACK>
 #endif
 __global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : HZ_WG_PER_CU) void k_horizon(HorizonParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int *stack = reinterpret_cast<int *>(smem);
-    const float4 *top = reinterpret_cast<const float4 *>(smem + p.stack_bytes + p.stage_bytes);
+    int *stack = reinterpret_cast<int *>(smem + p.pre_bytes);
+    const float4 *top = reinterpret_cast<const float4 *>(smem + p.pre_bytes + p.stack_bytes);
     const int tid = threadIdx.x;
     const int ntop = p.top_nodes;
     if (NODELET && ntop > 0) {   // stage the breadth-first top of the tree in LDS (coalesced 16 B per lane)
-        float4 *dst = reinterpret_cast<float4 *>(smem + p.stack_bytes + p.stage_bytes);
+        float4 *dst = reinterpret_cast<float4 *>(smem + p.pre_bytes + p.stack_bytes);
         const float4 *src = reinterpret_cast<const float4 *>(p.sv.nodes);
         for (int i = tid; i < ntop * 2; i += HZ_TPB) dst[i] = src[i];
         __syncthreads();
@@ -99,10 +101,13 @@ __global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : HZ_WG_PER_CU) void k_horizon(Ho
     Sink out;
     out.hori = hori0 + (size_t)cert * (size_t)t.azim_num;
     out.dist = nullptr; out.dist_hit = 0.0f;
-    out.stage = reinterpret_cast<float *>(smem + p.stack_bytes) + tid;   // only touched when STAGE
+    out.stage = reinterpret_cast<float *>(smem) + tid;   // only touched when STAGE
     out.stride = HZ_TPB;
     float ox = 0, oy = 0, oz = 0;
-    float r00 = 0, r01 = 0, r02 = 0, r10 = 0, r11 = 0, r12 = 0, r20 = 0, r21 = 0, r22 = 0;
+    float r01 = 0, r02 = 0, r11 = 0, r12 = 0, r21 = 0, r22 = 0;
+#ifdef HZ_V_EAST_REG
+    float e00 = 0, e10 = 0, e20 = 0;
+#endif
     const bool masked = in_dom && p.mask[cell] != 1;
     {   // masked cells get hori_fill for every azimuth (horizon_comp.cpp:789-794).  The wave fills them together, one
         // cell after the other with consecutive lanes on consecutive azimuths: 256 B per store instruction instead of
@@ -125,12 +130,16 @@ __global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : HZ_WG_PER_CU) void k_horizon(Ho
             ox = v[0] + norm_x * p.ray_org_elev;
             oy = v[1] + norm_y * p.ray_org_elev;
             oz = v[2] + norm_z * p.ray_org_elev;
-            const float east_x = north_y * norm_z - north_z * norm_y;
-            const float east_y = north_z * norm_x - north_x * norm_z;
-            const float east_z = north_x * norm_y - north_y * norm_x;
-            r00 = east_x; r01 = north_x; r02 = norm_x;
-            r10 = east_y; r11 = north_y; r12 = norm_y;
-            r20 = east_z; r21 = north_z; r22 = norm_z;
+            // (east = north x norm is formed again at every refill: 9 instructions there against 3 registers that would
+            //  live through the traversal -- the kernel sits exactly at the 96 VGPRs of 5 workgroups per CU)
+            r01 = north_x; r02 = norm_x;
+            r11 = north_y; r12 = norm_y;
+            r21 = north_z; r22 = norm_z;
+#ifdef HZ_V_EAST_REG
+            e00 = north_y * norm_z - north_z * norm_y;
+            e10 = north_z * norm_x - north_x * norm_z;
+            e20 = north_x * norm_y - north_y * norm_x;
+#endif
         }
     }
     // (the origin in the scene-centred frame is formed from (ox, oy, oz) where it is needed -- three subtractions per ray
@@ -151,7 +160,7 @@ __global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : HZ_WG_PER_CU) void k_horizon(Ho
     TravState ts; hz_trav_reset(ts);
     int cache = 0;           // hit cache: subtree above the leaf that blocked this cell's last blocked ray
     bool second = false;     // the cache walk found nothing: the root traversal is still due
-    unsigned overflow = 0;   // !LEVELSTACK: a ray needed more stack entries than this launch has (see hz_trace)
+    bool overflow = false;   // !LEVELSTACK: a ray needed more stack entries than this launch has (see hz_trace)
     // near-field certificate of this cell (hz_near.hip): rays of azimuth k with a table index >= near_idx[k] clear
     // everything within near_r of the origin and start their box tests at parameter near_r
     // verify_near (COUNT): a shortened ray that is selected (want_v) is traced a second time over its full length
@@ -174,13 +183,31 @@ __global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : HZ_WG_PER_CU) void k_horizon(Ho
             out.hori = hori0 + (size_t)cert_r * (size_t)t.azim_num;
             if (advance<ALG, STAGE>(s, last_hit, t, out, guards)) {
                 // local direction (east, north, up) and rotation: horizon_comp.cpp:357-361, :55-62
+                // every load of the new ray is issued before the first one is used: the table entries, and the certificate of
+                // (cell, azimuth) with the cell's radius -- read unconditionally: a load that waits for the comparison of
+                // another load is one more memory round trip per refill (three in a row cost 3.5 %)
                 const float ec = t.elev_cos[s.ind], es = t.elev_sin[s.ind];
-                const float rx = ec * t.azim_sin[s.k], ry = ec * t.azim_cos[s.k], rz = es;
+                const float asn = t.azim_sin[s.k], acs = t.azim_cos[s.k];
+                int near_i = 0x7fffffff;
+                float near_rad = 0.0f;
+                if (p.near_idx != nullptr) {
+                    near_i = (int)p.near_idx[(size_t)cert_r * (size_t)t.azim_num + s.k];
+                    near_rad = p.near_r[cert_r];
+                }
+                const float rx = ec * asn, ry = ec * acs, rz = es;
+#ifdef HZ_V_EAST_REG
+                const float r00 = e00, r10 = e10, r20 = e20;
+#else
+                float nx_ = r01, ny_ = r11, nz_ = r21;        // (the empty asm keeps the products inside the loop)
+                asm volatile("" : "+v"(nx_), "+v"(ny_), "+v"(nz_));
+                const float r00 = ny_ * r22 - nz_ * r12;      // east = north x norm (horizon_comp.cpp:763-766)
+                const float r10 = nz_ * r02 - nx_ * r22;
+                const float r20 = nx_ * r12 - ny_ * r02;
+#endif
                 dx = (r00 * rx + r01 * ry) + r02 * rz;
                 dy = (r10 * rx + r11 * ry) + r12 * rz;
                 dz = (r20 * rx + r21 * ry) + r22 * rz;
-                tn = 0.0f;
-                if (p.near_idx != nullptr && s.ind >= (int)p.near_idx[(size_t)cert_r * (size_t)t.azim_num + s.k]) tn = p.near_r[cert_r];
+                tn = (s.ind >= near_i) ? near_rad : 0.0f;
                 if (COUNT && tn > 0.0f) shortened++;
                 if (COUNT) want_v = p.verify_near && tn > 0.0f && (((rays + cert) & p.verify_mask) == 0u);
                 HZ_OC(ocx, ocy, ocz)
@@ -232,7 +259,7 @@ __global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : HZ_WG_PER_CU) void k_horizon(Ho
     }
     // !LEVELSTACK: a wave in which a ray ran out of stack entries does not count; its block is computed again by the
     // one-entry-per-level kernel (horizon_run), which overwrites everything this wave wrote
-    if (!LEVELSTACK && __ballot(overflow != 0u) != 0ull) {
+    if (!LEVELSTACK && __ballot(overflow) != 0ull) {
         if (lane == 0) {
             const unsigned long long slot = atomicAdd(&p.counters[8], 1ull);
             if (slot < (unsigned long long)HZ_REDO_CAP) p.redo_list[slot] = (int)blockIdx.x * 4 + wave;
@@ -327,25 +354,29 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
     // repeats that launch with the one-entry-per-level discipline (`height` entries, cannot overflow, +10 % VALU) and
     // keeps it for the scene.  Shallow trees whose worst case fits never need the second kernel.
     const int stage = ((a.azim_num & 3) == 0 && (reinterpret_cast<size_t>(a.hori) & 15) == 0) ? 4 * HZ_TPB * 4 : 0;
+    // (two rows: a lane that has popped its sentinel but still has queued leaves reads the two rows below the stack)
+    const int pre = stage ? stage : 2 * HZ_TPB * 4;
     const int height = std::max(sc->hdr.height, 1);
     // (a.level_stack < 0: test hook, the fast discipline with that many entries)
     // (with the opt-in LDS nodelet the fast stack gives up the entries the nodelet's bytes need, so that 5 workgroups stay resident)
     const int want_top = (a.top_nodes > 0 && a.alg == ALG_GUESS && !a.count_work) ? std::min(a.top_nodes, sc->hdr.n_top) : 0;
     // (HZ_LDS_BUDGET: bytes of LDS per workgroup the fast stack may use with staging and nodelet -- experiments with the residency)
     static const int lds_budget = []() { const char *e = getenv("HZ_LDS_BUDGET"); return e && atoi(e) > 8192 ? atoi(e) : 31 * 1024; }();
-    const int fast_cap = a.level_stack < 0 ? std::max(-a.level_stack, 3)
-                                           : std::max((lds_budget - stage - want_top * (int)sizeof(Node)) / (HZ_TPB * 4), 3);
+    // (entry 0 of the fast stack is the sentinel, and a node step wants three free entries above the top: at least 4)
+    const int fast_cap = a.level_stack < 0 ? std::max(-a.level_stack, 4)
+                                           : std::max((lds_budget - pre - want_top * (int)sizeof(Node)) / (HZ_TPB * 4), 4);
     const bool level_stack = a.level_stack > 0;
-    const int depth = level_stack ? height : std::min(fast_cap, 3 * height);
-    if (used_level_stack) *used_level_stack = (level_stack || depth >= 3 * height) ? 1 : 0;   // 1: cannot overflow
+    const int depth = level_stack ? height : std::min(fast_cap, 3 * height + 1);
+    if (used_level_stack) *used_level_stack = (level_stack || depth >= 3 * height + 1) ? 1 : 0;   // 1: cannot overflow
     p.stack_cap = depth;
     p.stack_bytes = depth * HZ_TPB * 4;
     // output staging (4 azimuths per lane) when the 16 B stores are aligned: azim_num % 4 == 0
     p.stage_bytes = stage;
+    p.pre_bytes = pre;
     // LDS nodelet (opt-in, guess_constant only): opts.top_nodes > 0 stages that many top-of-tree nodes;
     // the default reads every node through L1 (measured 2 % faster)
     int top = (a.top_nodes > 0 && a.alg == ALG_GUESS && !a.count_work) ? a.top_nodes : 0;
-    top = std::min(top, std::max(0, (80 * 1024 - (p.stack_bytes + p.stage_bytes)) / (int)sizeof(Node)));
+    top = std::min(top, std::max(0, (80 * 1024 - (p.stack_bytes + p.pre_bytes)) / (int)sizeof(Node)));
     top = std::min(top, sc->hdr.n_top);
     p.top_nodes = top;
     // defaults from the sweep on the 3601^2 tile: refill when fewer than 40 lanes
@@ -364,7 +395,7 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
     p.counters = a.counters;
     p.tile_list = a.tile_list; p.n_list = a.n_list;
     p.redo_list = reinterpret_cast<int *>(a.counters + 24);
-    const size_t lds = (size_t)p.stack_bytes + (size_t)p.stage_bytes + (size_t)top * sizeof(Node);
+    const size_t lds = (size_t)p.pre_bytes + (size_t)p.stack_bytes + (size_t)top * sizeof(Node);
     const int grid = a.tile_list ? (a.n_list + 3) / 4 : p.tm.per_xcd * 8;
     if (grid <= 0) return HZ_OK;
     const bool count = a.count_work != 0;

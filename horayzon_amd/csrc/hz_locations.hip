@@ -99,7 +99,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_locations(LocParams p) {
                 if (last_hit) out.dist_hit = d;                     // :545-547 / :589-591
             } else {                                                // castRay_occluded1, :241-262
                 TravState ts; hz_trav_reset(ts);
-                unsigned overflow = 0;       // unused: the one-entry-per-level stack cannot overflow
+                bool overflow = false;       // unused: the one-entry-per-level stack cannot overflow
                 last_hit = hz_trace<HZ_TPB, false>(p.sv.nodes, p.sv.prims, nullptr, 0, stack, tid, ox, oy, oz, dx, dy,
                                                    dz, p.tfar, rb, ts, 0, 16, tc, 0, overflow) == 1;
             }

@@ -74,7 +74,7 @@ __device__ __forceinline__ bool occluded(const SceneView &sv, int *stack, int ti
     const RayBox rb = hz_raybox(ox - sv.cx, oy - sv.cy, oz - sv.cz, dx, dy, dz);
 #endif
     TravState ts; hz_trav_reset(ts);
-    unsigned overflow = 0;      // unused: the one-entry-per-level stack cannot overflow
+    bool overflow = false;      // unused: the one-entry-per-level stack cannot overflow
     return hz_trace<HZ_TPB, COUNT>(sv.nodes, sv.prims, nullptr, 0, stack, tid, ox, oy, oz, dx, dy, dz, tfar, rb,
                                    ts, 0, HZ_SHADOW_LEAF_BIAS, tc, 0, overflow) == 1;
 }
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_shadow_refill(ShadowParams p) {
     size_t cell = 0;
     RayBox rb = hz_raybox(0, 0, 0, 0, 0, 1);
     TravState ts; hz_trav_reset(ts);
-    unsigned overflow = 0;
+    bool overflow = false;
     for (;;) {
         if (next < total) {
             const unsigned long long need = __ballot(!ray_active);

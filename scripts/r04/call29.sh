@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 4, GPU call 29: which of the refinements on top of the first rewrite (fs1) lost 3 %?
+export TMPDIR=/tmp
+O=gpurun_out/r04_29; mkdir -p $O
+for round in 1 2; do
+for v in fs1 new va vb vc; do
+  if [ $v = new ]; then unset HORAYZON_HIP_LIB; else export HORAYZON_HIP_LIB=$PWD/horayzon_amd/libhorayzon_hip_$v.so; fi
+  ( timeout 300 python scripts/quick_perf.py --win 1024 --reps 3 > $O/q.tmp 2>&1 ); echo "$v $(grep 'rep 1\|rep 2' $O/q.tmp | awk '{print $6}' | tr '\n' ' ')" >> $O/bisect.log
+done
+done
+cat $O/bisect.log
