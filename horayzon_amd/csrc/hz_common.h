@@ -194,20 +194,21 @@ __device__ __forceinline__ bool hz_quad_hit(float ox, float oy, float oz, float 
     const float U = ((e0y * s0z - e0z * s0y) * dx + (e0z * s0x - e0x * s0z) * dy) + (e0x * s0y - e0y * s0x) * dz;
     const float V = ((e1y * s1z - e1z * s1y) * dx + (e1z * s1x - e1x * s1z) * dy) + (e1x * s1y - e1y * s1x) * dz;
     const float W = ((e2y * s2z - e2z * s2y) * dx + (e2z * s2x - e2x * s2z) * dy) + (e2x * s2y - e2y * s2x) * dz;
+    // No early outs (round 4): with ~25 rays of a wave in a leaf step some lane passes every partial test, so the skipped
+    // blocks ran anyway and every `if` was an exec-mask save / branch / restore on top.  The decisions are the same
+    // comparisons on the same values, combined with non-short-circuit & and |.
+    bool hit0;
     {
         const float UVW = (U + V) + W;
         const float eps = 1.1920928955078125e-7f * __builtin_fabsf(UVW);
         const float mn = __builtin_fminf(U, __builtin_fminf(V, W));
         const float mx = __builtin_fmaxf(U, __builtin_fmaxf(V, W));
-        if ((mn >= -eps) || (mx <= eps)) {
-            const float nx = e1y * e0z - e1z * e0y, ny = e1z * e0x - e1x * e0z, nz = e1x * e0y - e1y * e0x;
-            const float den = (nx * dx + ny * dy) + nz * dz;
-            const float T = (v0x * nx + v0y * ny) + v0z * nz;
-            const float Ts = (den < 0.0f) ? -T : T;
-            if (den != 0.0f && Ts >= 0.0f && Ts <= tfar * __builtin_fabsf(den)) return true;
-        }
+        const float nx = e1y * e0z - e1z * e0y, ny = e1z * e0x - e1x * e0z, nz = e1x * e0y - e1y * e0x;
+        const float den = (nx * dx + ny * dy) + nz * dz;
+        const float T = (v0x * nx + v0y * ny) + v0z * nz;
+        const float Ts = (den < 0.0f) ? -T : T;
+        hit0 = ((mn >= -eps) | (mx <= eps)) & (den != 0.0f) & (Ts >= 0.0f) & (Ts <= tfar * __builtin_fabsf(den));
     }
-    if (!second) return false;
     // triangle (b, d, c): v0' = b, v1' = d, v2' = c
     const float w1x = qx - ox, w1y = qy - oy, w1z = qz - oz;      // d
     const float f0x = -e2x, f0y = -e2y, f0z = -e2z;               // e0' = c - b
@@ -222,15 +223,13 @@ __device__ __forceinline__ bool hz_quad_hit(float ox, float oy, float oz, float 
     const float eps = 1.1920928955078125e-7f * __builtin_fabsf(UVW);
     const float mn = __builtin_fminf(U1, __builtin_fminf(V1, W1));
     const float mx = __builtin_fmaxf(U1, __builtin_fmaxf(V1, W1));
-    if (!((mn >= -eps) || (mx <= eps))) return false;
     const float nx = f1y * f0z - f1z * f0y, ny = f1z * f0x - f1x * f0z, nz = f1x * f0y - f1y * f0x;
     const float den = (nx * dx + ny * dy) + nz * dz;
     const float T = (v1x * nx + v1y * ny) + v1z * nz;
-    if (den == 0.0f) return false;
     const float Ts = (den < 0.0f) ? -T : T;
-    if (!(Ts >= 0.0f)) return false;
-    if (!(Ts <= tfar * __builtin_fabsf(den))) return false;
-    return true;
+    // (a TIN triangle's record holds NaNs in d: every comparison below is false for it, `second` only states it)
+    const bool hit1 = second & ((mn >= -eps) | (mx <= eps)) & (den != 0.0f) & (Ts >= 0.0f) & (Ts <= tfar * __builtin_fabsf(den));
+    return hit0 | hit1;
 }
 
 // closest-hit variant (rtcIntersect1): same acceptance test; t = T / den as one IEEE division
@@ -517,8 +516,11 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
     const unsigned sa_cap = sa0 + (unsigned)(stack_cap - 5) * (unsigned)(TPB * 4);
     if (!LEVELSTACK) HZ_STACK_AT(sa0) = HZ_EMPTY;
     unsigned sa_hi = sa;          // highest stack pointer of this call (overflow is decided once, at the exit)
-    const int n_leave = min(regroup, n_entry);   // suspend below this many traversing lanes (see `regroup`)
-    int res = -1;                 // single exit: lanes leave the loop through `res`, state is saved once
+    // The loop is left by the WAVE: when fewer than n_leave lanes are still traversing (`regroup`, and only if some lane
+    // finished its ray in this call -- it can refill, so the caller always makes progress) or when none is.  A lane whose
+    // ray is decided idles until then: a miss holds HZ_EMPTY and an empty queue; a hit holds HZ_EMPTY and the NUMBER of
+    // the blocking leaf instead of its link in lq0 (non-negative: "no leaf queued"; never HZ_EMPTY).  No per-lane exit, no result register in the loop.
+    const int n_leave = max(min(regroup, n_entry), 1);
 #ifdef HZ_PREFETCH
     // Probe (scripts/build_variant.sh pf -DHZ_PREFETCH): touch the cache line of the link a node step has just chosen with
     // a fire-and-forget 4 B load, so that the three 16 B loads of the next visit hit L1.  The destination register is
@@ -531,7 +533,7 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
 #else
 #define HZ_PF(link) do { } while (0)
 #endif
-    while (res < 0) {
+    for (;;) {
         // set leaves aside while the leaf queue (QLEN entries, filled front to back; a queued leaf is negative, an empty
         // place HZ_EMPTY) has room
         if (LEVELSTACK) {
@@ -567,10 +569,7 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
         // masks equal those of the lanes that stay (and stay plain scalar compares)
         const unsigned long long m_node = __ballot(can_node), m_leaf = __ballot(can_leaf);
         const int n_all = __popcll(m_node | m_leaf);
-        if (!can_node && !can_leaf) { res = 0; continue; }                    // nothing left: miss
-        // ray compaction: suspend only if some lane finished its ray in this call (it can refill,
-        // so the caller always makes progress)
-        if (n_all < n_leave) { res = 2; continue; }
+        if (n_all < n_leave) break;
         const int n_node = __popcll(m_node);
         const int n_leaf = __popcll(m_leaf);
         if (n_node * 16 >= n_leaf * leaf_bias) {
@@ -630,7 +629,7 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
                 if (COUNT) { cnt.tris += (q2.y == q2.y) ? 2 : 1; HZ_WAVE_TICK(cnt.w_leaves, lane); }
                 const bool hit = hz_quad_hit(ox, oy, oz, dx, dy, dz, tfar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
                                              q2.x, q2.y, q2.z, q2.w, q2.y == q2.y);
-                if (hit) res = 1;                       // lq0 stays: the caller reads the blocking leaf
+                if (hit) { lq0 = HZ_LEAF_ID(lq0); node = HZ_EMPTY; }     // decided: blocked by this leaf
                 else { lq0 = lq1; lq1 = HZ_EMPTY; }
             }
         }
@@ -639,6 +638,9 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) : : "memory");
 #endif
     if (!LEVELSTACK && sa_hi > sa_cap) overflow = true;
+    const bool blocked = lq0 >= 0 && lq0 != HZ_EMPTY;
+    const int res = blocked ? 1 : ((HZ_IS_NODE(node) || lq0 < 0) ? 2 : 0);
+    if (blocked) lq0 = (int)((unsigned)lq0 | 0x80000000u);      // the caller reads the blocking leaf (as a link) from the state
     HZ_SAVE();
     return res;
 #undef HZ_PF
