@@ -533,7 +533,12 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
 #else
 #define HZ_PF(link) do { } while (0)
 #endif
-    for (;;) {
+    // The loop is rotated by hand: [queue fills + votes] once in front of it and again at the end of its body, so that the
+    // wave's exit test is the loop condition itself.
+    bool can_node, can_leaf;
+    unsigned long long m_node, m_leaf;
+    int n_all;
+    auto top_of_iteration = [&]() __attribute__((always_inline)) {
         // set leaves aside while the leaf queue (QLEN entries, filled front to back; a queued leaf is negative, an empty
         // place HZ_EMPTY) has room
         if (LEVELSTACK) {
@@ -563,13 +568,15 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
             const bool c2 = m2 < 0;
             lq1 = c2 ? node : lq1; node = c2 ? t0 : node; sa -= c2 ? (unsigned)(TPB * 4) : 0u;
         }
-        const bool can_node = HZ_IS_NODE(node);
-        const bool can_leaf = lq0 < 0;
+        can_node = HZ_IS_NODE(node);
+        can_leaf = lq0 < 0;
         // votes taken before any lane leaves: a lane that is finished contributes to neither mask, so the
         // masks equal those of the lanes that stay (and stay plain scalar compares)
-        const unsigned long long m_node = __ballot(can_node), m_leaf = __ballot(can_leaf);
-        const int n_all = __popcll(m_node | m_leaf);
-        if (n_all < n_leave) break;
+        m_node = __ballot(can_node); m_leaf = __ballot(can_leaf);
+        n_all = __popcll(m_node | m_leaf);
+    };
+    top_of_iteration();
+    while (n_all >= n_leave) {
         const int n_node = __popcll(m_node);
         const int n_leaf = __popcll(m_leaf);
         if (n_node * 16 >= n_leaf * leaf_bias) {
@@ -633,6 +640,7 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
                 else { lq0 = lq1; lq1 = HZ_EMPTY; }
             }
         }
+        top_of_iteration();
     }
 #ifdef HZ_PREFETCH
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) : : "memory");
