@@ -91,7 +91,7 @@ static inline float deg2rad_f(float ang) { return (float)(((double)ang / 180.0) 
 
 struct HostTables {
     std::vector<float> azim_sin, azim_cos, elev_ang, elev_sin, elev_cos;
-    std::vector<int> mid_idx;   // index nearest to the midpoint of entries i and i + 10 (horizon_comp.cpp:462-464)
+    std::vector<int> mid_idx;   // (index nearest to the midpoint of entries i and i + 10, bits of elev_ang[that index]) (horizon_comp.cpp:462-464)
     int elev_num = 0;
     float hori_acc = 0, low = 0, up = 0;
 };
@@ -120,10 +120,15 @@ static void build_tables(int azim_num, float hori_acc_deg, float low_deg, HostTa
         t.elev_cos[(size_t)(t.elev_num - i - 1)] = cosf(ang);
     }
     // elev_samp = (elev_ang[prev] + elev_ang[ind]) / 2.0; ind = (int)roundf((elev_samp - low) / (hori_acc / 5.0))
-    t.mid_idx.assign(n > 0 ? n : 1, 0);
+    // (stored as pairs: the index and the bits of elev_ang[index], the value the search emits -- one 8 B load instead of
+    //  two dependent 4 B loads at the end of every azimuth)
+    t.mid_idx.assign(2 * (n > 0 ? n : 1), 0);
     for (int i = 0; i + 10 < t.elev_num; i++) {
         const float es = (float)((double)(t.elev_ang[(size_t)i] + t.elev_ang[(size_t)i + 10]) / 2.0);
-        t.mid_idx[(size_t)i] = (int)roundf((float)((double)(es - t.low) / step));
+        const int mid = (int)roundf((float)((double)(es - t.low) / step));
+        t.mid_idx[2 * (size_t)i] = mid;
+        const float ev = t.elev_ang[(size_t)std::min(std::max(mid, 0), t.elev_num - 1)];
+        memcpy(&t.mid_idx[2 * (size_t)i + 1], &ev, sizeof(float));
     }
 }
 

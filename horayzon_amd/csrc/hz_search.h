@@ -13,7 +13,7 @@ enum { PH_NEWAZ = 0, PH_BIN = 1, PH_UP = 2, PH_DOWN = 3, PH_EMIT = 4 };
 
 struct Tables {
     const float *azim_sin, *azim_cos, *elev_ang, *elev_sin, *elev_cos;
-    const int *mid_idx;   // mid_idx[i] = ind_of(half_sum(elev_ang[i], elev_ang[i + 10])), built on the host
+    const int *mid_idx;   // pairs: mid_idx[2 i] = ind_of(half_sum(elev_ang[i], elev_ang[i + 10])), [2 i + 1] = bits of elev_ang[that], built on the host
     int azim_num, elev_num;
     float hori_acc, low, up;
     double step;   // (double)hori_acc / 5.0
@@ -37,10 +37,17 @@ __device__ __forceinline__ float half_sum(float a, float b) {
 // index of the table entry nearest to the midpoint of entries `a` and `b` (horizon_comp.cpp:462-464,
 // :490-492).  The search steps by 10 entries, so the midpoint index comes from a host-built table
 // (same float/double expressions, hz_api.hip); clamped steps at the table ends take the general path.
-__device__ __forceinline__ int mid_index(const Tables &t, int a, int b) {
+// *ev = elev_ang[that index], the value the search emits: the table holds (index, value bits) pairs -- one 8 B load.
+__device__ __forceinline__ int mid_index(const Tables &t, int a, int b, float *ev) {
     const int lo = min(a, b);
-    if (max(a, b) - lo == 10) return t.mid_idx[lo];
-    return ind_of(t, half_sum(t.elev_ang[a], t.elev_ang[b]));
+    if (max(a, b) - lo == 10) {
+        const int2 v = reinterpret_cast<const int2 *>(t.mid_idx)[lo];
+        *ev = __int_as_float(v.y);
+        return v.x;
+    }
+    const int ind = ind_of(t, half_sum(t.elev_ang[a], t.elev_ang[b]));
+    *ev = t.elev_ang[ind];
+    return ind;
 }
 
 // per-cell output sink
@@ -128,8 +135,8 @@ __device__ __forceinline__ bool advance(Search &s, bool hit, const Tables &t, Si
                 continue;
             }
             if (s.count > 1) {                               // :460-467
-                s.ind = mid_index(t, s.prev, s.ind);
-                s.ev = t.elev_ang[s.ind]; s.pazim = s.ind; s.phase = PH_EMIT;
+                s.ind = mid_index(t, s.prev, s.ind, &s.ev);
+                s.pazim = s.ind; s.phase = PH_EMIT;
                 continue;
             }
             // move downwards: :472-477
@@ -148,8 +155,8 @@ __device__ __forceinline__ bool advance(Search &s, bool hit, const Tables &t, Si
                 return true;
             }
             if (guard) guards++;
-            s.ind = mid_index(t, s.prev, s.ind);                              // :490-494
-            s.ev = t.elev_ang[s.ind]; s.pazim = s.ind; s.phase = PH_EMIT;
+            s.ind = mid_index(t, s.prev, s.ind, &s.ev);                       // :490-494
+            s.pazim = s.ind; s.phase = PH_EMIT;
             continue;
         }
     }
