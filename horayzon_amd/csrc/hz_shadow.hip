@@ -28,6 +28,7 @@ struct ShadowParams {
     int refrac, which;
     uint8_t *out_u8; float *out_f32;
     int top_nodes, stack_bytes;
+    int stack_cap;                 // FAST: entries of the fast stack (hz_trace, !LEVELSTACK), sentinel included
     int nb;                  // k_shadow_refill: 8 x 8 blocks per wave
     unsigned long long *counters;
 };
@@ -194,13 +195,25 @@ __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
 // instruction, profiles/r02/pmc_shadow_summary.json); here a lane whose ray is finished takes the next cell once
 // fewer than `regroup` lanes are still traversing (the ray compaction of the horizon kernel).  Cells are handed out
 // in block order, so the rays in flight stay neighbours.  Results are those of k_shadow bit for bit.
+#ifndef HZ_SHADOW_FAST_CAP_DEFAULT
+#define HZ_SHADOW_FAST_CAP_DEFAULT 19   // 21 KiB of LDS per workgroup: 7 resident; round 4: level stack 1.074 -> fast stack 0.964 ms per position at 5 workgroups (profiles/r04/ab_shadow_fast_stack.log)
+#endif
 #ifndef HZ_SHADOW_REGROUP
 #define HZ_SHADOW_REGROUP 40      // refill when fewer lanes than this are still traversing
 #endif
-template <bool COUNT>
-__global__ __launch_bounds__(HZ_TPB) void k_shadow_refill(ShadowParams p) {
+// FAST: the fast stack discipline of hz_trace (every pending sibling its own entry, written for the fewest instructions;
+// `stack_cap` entries behind two padding rows).  A ray that runs out of entries is traced again, to completion, with the
+// one-entry-per-level discipline in the same LDS column of its lane (the launcher makes sure the tree's height fits).
+// resident workgroups per CU the register allocation is held to (profiles/r04/ab_shadow_fast_stack.log, ms per sun position:
+// unconstrained = 86 VGPRs = 5 workgroups 0.955; 6 (80 VGPRs, no spills) 0.884; 7 (72 VGPRs, 6 spilled) 0.857; 8 (64 VGPRs, 21
+// spilled) 0.957).  The counting instantiation carries ~10 more live values and is left at 5.
+#ifndef HZ_SHADOW_WG
+#define HZ_SHADOW_WG 7
+#endif
+template <bool COUNT, bool FAST>
+__global__ __launch_bounds__(HZ_TPB, COUNT ? 5 : HZ_SHADOW_WG) void k_shadow_refill(ShadowParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int *stack = reinterpret_cast<int *>(smem);
+    int *stack = reinterpret_cast<int *>(smem + (FAST ? 2 * HZ_TPB * 4 : 0));
     const int tid = threadIdx.x;
     int ti = 0, tj = 0;
     const bool has_tile = hz_tile_of_block(p.tm, blockIdx.x, &ti, &tj);      // tile map over super tiles (16 x 16 nb cells)
@@ -233,6 +246,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_shadow_refill(ShadowParams p) {
                         cell = (size_t)i * p.dim_in_1 + j;
                         rb = hz_raybox(r.ox - p.sv.cx, r.oy - p.sv.cy, r.oz - p.sv.cz, r.dx, r.dy, r.dz);
                         hz_trav_reset(ts);
+                        overflow = false;
                         ray_active = true;
                         rays++;
                     }
@@ -245,8 +259,15 @@ __global__ __launch_bounds__(HZ_TPB) void k_shadow_refill(ShadowParams p) {
         }
         if (ray_active) {
             // while cells are left the traversal returns when fewer than 40 lanes are busy (and one finished)
-            const int res = hz_trace<HZ_TPB, COUNT>(p.sv.nodes, p.sv.prims, nullptr, 0, stack, tid, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz,
-                                                    __builtin_inff(), rb, ts, (next < total) ? HZ_SHADOW_REGROUP : 0, HZ_SHADOW_LEAF_BIAS, tc, 0, overflow);
+            int res = hz_trace<HZ_TPB, COUNT, 2, false, !FAST>(p.sv.nodes, p.sv.prims, nullptr, 0, stack, tid, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz,
+                                                    __builtin_inff(), rb, ts, (next < total) ? HZ_SHADOW_REGROUP : 0, HZ_SHADOW_LEAF_BIAS, tc, p.stack_cap, overflow);
+            if (FAST && res != 2 && overflow) {
+                bool unused = false;
+                hz_trav_reset(ts);
+                res = hz_trace<HZ_TPB, COUNT, 2, false, true>(p.sv.nodes, p.sv.prims, nullptr, 0, stack, tid, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz,
+                                                                    __builtin_inff(), rb, ts, 0, HZ_SHADOW_LEAF_BIAS, tc, 0, unused);
+                if (COUNT && p.counters) atomicAdd(&p.counters[8], 1ull);     // rays traced twice
+            }
             if (res != 2) {
                 shadow_result(p, cell, res == 1, r, out_u8, out_f32);
                 ray_active = false;
@@ -274,7 +295,14 @@ int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st) {
     p.stack_bytes = std::max(sc->hdr.height, 1) * HZ_TPB * 4;
     p.top_nodes = 0;
     p.counters = a.counters;
-    const size_t lds = (size_t)p.stack_bytes;
+    // fast stack (k_shadow_refill<.., true>): HZ_SHADOW_FAST_CAP entries (0: off) behind two padding rows, if the level
+    // stack of the in-kernel retry fits into them
+    static const int fast_cap_env = []() { const char *e = getenv("HZ_SHADOW_FAST_CAP"); return e ? atoi(e) : HZ_SHADOW_FAST_CAP_DEFAULT; }();
+    const int height = std::max(sc->hdr.height, 1);
+    const int fast_cap = std::min(fast_cap_env, 3 * height + 1);
+    const bool fast = fast_cap >= 5 && fast_cap >= height;
+    p.stack_cap = fast ? fast_cap : 0;
+    const size_t lds = fast ? (size_t)(fast_cap + 2) * HZ_TPB * 4 : (size_t)p.stack_bytes;
     static const bool refill = []() { const char *e = getenv("HZ_SHADOW_REFILL"); return !(e && e[0] == '0'); }();
     // blocks per wave: as many as leave >= ~48 workgroups per CU over the whole launch (measured on the 3601^2 tile, 144
     // positions per launch: 2 / 4 / 8 / 16 / 32 / 64 blocks -> 1.64 / 1.49 / 1.42 / 1.36 / 1.29 / 1.51 ms per position; a single
@@ -299,7 +327,8 @@ int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st) {
 #define HZ_LAUNCH_SHADOW(K) do { \
         HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(K, grid, dim3(HZ_TPB), lds, st, p); } while (0)
-    if (refill) { if (a.count_work) HZ_LAUNCH_SHADOW(k_shadow_refill<true>); else HZ_LAUNCH_SHADOW(k_shadow_refill<false>); }
+    if (refill && fast) { if (a.count_work) HZ_LAUNCH_SHADOW((k_shadow_refill<true, true>)); else HZ_LAUNCH_SHADOW((k_shadow_refill<false, true>)); }
+    else if (refill) { if (a.count_work) HZ_LAUNCH_SHADOW((k_shadow_refill<true, false>)); else HZ_LAUNCH_SHADOW((k_shadow_refill<false, false>)); }
     else { if (a.count_work) HZ_LAUNCH_SHADOW(k_shadow<true>); else HZ_LAUNCH_SHADOW(k_shadow<false>); }
 #undef HZ_LAUNCH_SHADOW
     HZ_HIP(hipGetLastError());
