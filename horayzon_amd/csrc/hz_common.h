@@ -515,7 +515,8 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
     unsigned sa = sa0 + (unsigned)(sp - 1) * (unsigned)(TPB * 4);
     const unsigned sa_cap = sa0 + (unsigned)(stack_cap - 5) * (unsigned)(TPB * 4);
     if (!LEVELSTACK) HZ_STACK_AT(sa0) = HZ_EMPTY;
-    unsigned sa_hi = sa;          // highest stack pointer of this call (overflow is decided once, at the exit)
+    unsigned sa_hi = 0u;          // highest stack pointer a NODE STEP of this call started with (overflow is decided once, at the
+                                  // exit; a lane may enter with more: leaf links above the three free entries are fine)
     // The loop is left by the WAVE: when fewer than n_leave lanes are still traversing (`regroup`, and only if some lane
     // finished its ray in this call -- it can refill, so the caller always makes progress) or when none is.  A lane whose
     // ray is decided idles until then: a miss holds HZ_EMPTY and an empty queue; a hit holds HZ_EMPTY and the NUMBER of

@@ -170,3 +170,18 @@ def test_stray_element_replay_is_clean():
             assert p.returncode == 0, log[-3000:]
             assert "DIRTY" not in log and "DAMAGED" not in log and "use after free" not in log, log[-3000:]
             assert "replay done: 0 problems" in log
+
+
+def test_ray_count_survives_leaf_links_above_the_free_stack_entries(hip, orc):
+    """Round 4 (wide sweep seed 45001, adversarial configuration 85): a lane may re-enter the traversal with leaf links above
+    the three free stack entries a node step wants; taking that for "out of entries" dropped the wave's tallies when the
+    stack could not overflow at all (horizon identical, ray count 5 % low)."""
+    rng = np.random.default_rng(45001 + 7)
+    for it in range(86):
+        kw, par, desc = cases.adversarial_near_case(rng)
+    h, a = hip.horizon.horizon_gridded(**kw, **par, count_work=True, _verify_near=1)
+    st = hip.horizon.last_stats
+    ho, ao, so = orc.horizon_gridded(**kw, **par, return_stats=True)
+    assert np.array_equal(h, ho, equal_nan=True), desc
+    assert st["num_rays"] == so["rays"] and st["guard_events"] == so["guards"], desc
+    assert st["stack_redo_blocks"] == 0 and st["stack_fallbacks"] == 0
