@@ -121,6 +121,8 @@ def load_valu_model():
         mj = json.load(open(os.path.join(ROOT, "profiles", "valu_model.json")))
         if mj.get("kernel_source_sha") == sha:
             model.update({k: mj[k] for k in model if k in mj})
+            if "shadow_setup_winst_per_64_cells" in mj:
+                model["shadow_setup"] = mj["shadow_setup_winst_per_64_cells"]
             notes["valu_model"] = "profiles/valu_model.json (calibrated on SQ_INSTS_VALU, same kernel sources)"
         else:
             notes["valu_model"] = "built-in constants (profiles/valu_model.json was measured for other kernel sources)"
@@ -1045,10 +1047,12 @@ def run_c4(ctx):
         # VALU port as the bound, as for k_horizon: the traversal is the same hz_trace (147 / 218 wave instructions per node /
         # leaf step, class mix of those sections); the per-cell set-up (ray, self-shading test, refraction) is priced with
         # SETUP wave instructions per 64 cells handed out (calibrated on SQ_INSTS_VALU, profiles/r03/pmc_shadow_refill.json)
-        setup = SHADOW_SETUP_WINST[int(bool(args.refrac))]
         n_it, l_it = cw["wave_node_iters"], cw["wave_leaf_iters"]
         rounds = S * cells / 64.0
         vm, vmix, vnotes = load_valu_model()
+        # (calibrated with the traversal constants on the shadow kernel's own SQ_INSTS_VALU when the profiles are current;
+        #  refraction adds the round-3 difference of the two built-in figures)
+        setup = vm.pop("shadow_setup", SHADOW_SETUP_WINST[0]) + (SHADOW_SETUP_WINST[1] - SHADOW_SETUP_WINST[0]) * int(bool(args.refrac))
         winst = vm["node_iter"] * n_it + vm["leaf_iter"] * l_it + setup * rounds
         roof.update({"nodes_per_ray": cw["nodes_visited"] / max(cw["num_rays"], 1), "tris_per_ray": cw["tris_tested"] / max(cw["num_rays"], 1),
                      "wave_node_iters": n_it, "wave_leaf_iters": l_it,
@@ -1061,8 +1065,10 @@ def run_c4(ctx):
             need = (vm["node_iter"] * n_it * cyc(vmix["node_step"])
                     + vm["leaf_iter"] * l_it * cyc(vmix["leaf_step"]) + setup * rounds * cyc(0.7))
             have = peaks["simds"] * peaks["clock_ghz"] * 1e9 * k_step
-            roof.update({"bound": "valu_issue", "achieved": need / k_step / 1e9, "peak": peaks["simds"] * peaks["clock_ghz"],
-                         "unit": "G SIMD-cycles/s (VALU busy)", "frac": need / have,
+            # (the two-class model has a few per cent of error: a launch it prices above its own cycles is reported as
+            #  saturated, with the raw figure next to it)
+            roof.update({"bound": "valu_issue", "achieved": min(need, have) / k_step / 1e9, "peak": peaks["simds"] * peaks["clock_ghz"],
+                         "unit": "G SIMD-cycles/s (VALU busy)", "frac": min(need / have, 1.0), "frac_model_raw": need / have,
                          "frac_uniform_4_cycle": 4.0 * winst / have, "class_rates_cycles_per_wave_inst": cr,
                          "valu_model": vnotes["valu_model"], "valu_model_constants": vm, "class_mix_fast_fraction": vmix,
                          "peak_note": "as for k_horizon (c3 line): SIMD cycles the instructions need at the measured issue rates of "

@@ -110,6 +110,12 @@ try:
         out4["node_iter_leaf_iter_used"] = [ni, li]
         rest = m["SQ_INSTS_VALU"] - ni * rf["wave_node_iters"] - li * rf["wave_leaf_iters"]
         out4["setup_winst_per_64_cells"] = rest / (144 * 3569 * 3569 / 64.0)
+        # the bench line of config 4 prices the per-cell set-up with this (stamped with the kernel sources like the rest)
+        try:
+            vmj["shadow_setup_winst_per_64_cells"] = out4["setup_winst_per_64_cells"]
+            json.dump(vmj, open("profiles/valu_model.json", "w"), indent=1)
+        except Exception:
+            pass
     json.dump(out4, open("profiles/%s/pmc_shadow_refill.json" % rnd, "w"), indent=1)
     print(json.dumps(out4))
 except (ValueError, OSError, KeyError) as e:
