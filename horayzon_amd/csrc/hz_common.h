@@ -376,17 +376,6 @@ __device__ __forceinline__ void hz_load_node(const Node *n, float4 &n0, uint4 &n
                  : "memory");
 }
 
-// The same with the array base in scalar registers and a 32-bit byte offset per lane (node number << 5): one instruction
-// of address arithmetic instead of three.  For scenes with fewer than 2^27 nodes (the launcher checks).
-__device__ __forceinline__ void hz_load_node_s(const Node *base, unsigned off, float4 &n0, uint4 &n1) {
-    asm volatile("global_load_dwordx4 %0, %2, %3\n\t"
-                 "global_load_dwordx4 %1, %2, %3 offset:16\n\t"
-                 "s_waitcnt vmcnt(0)"
-                 : "=&v"(n0), "=&v"(n1)
-                 : "v"(off), "s"(base)
-                 : "memory");
-}
-
 // The same node from the LDS nodelet (2 x ds_read_b128, one wait).
 __device__ __forceinline__ void hz_load_node_lds(const float4 *q, float4 &n0, uint4 &n1) {
     const unsigned addr = (unsigned)(size_t)reinterpret_cast<const __attribute__((address_space(3))) char *>(
@@ -599,9 +588,6 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
                 // a per-lane pointer select would be compiled into slow flat loads).  Measured 2 % slower
                 // than plain global loads -- the top of the tree is L1 resident -- so it is opt-in.
                 if (NODELET && node < ntop) hz_load_node_lds(top + 2 * node, n0, n1);
-#ifdef HZ_V_SADDR
-                else if (!LEVELSTACK) hz_load_node_s(nodes, (unsigned)node << 5, n0, n1);
-#endif
                 else hz_load_node(nodes + node, n0, n1);
                 if (COUNT) { cnt.nodes++; HZ_WAVE_TICK(cnt.w_nodes, lane); }
                 const NodeRay nr = hz_node_ray(rb, n0.x, n0.y, n0.z);
