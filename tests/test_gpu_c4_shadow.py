@@ -85,3 +85,19 @@ def test_c4_full_tile_144_sun_positions(hip, orc, refrac):
                       "shadow_kernel_s": st_sh["t_kernel_s"], "shadow_ms_per_position": 1e3 * st_sh["t_kernel_s"] / 144,
                       "shadow_mray_per_s": st_sh["num_rays"] / st_sh["t_kernel_s"] / 1e6,
                       "sw_dir_cor_kernel_s": st_sw["t_kernel_s"], "cells_checked_vs_oracle": checked}))
+
+
+def test_overflowed_shadow_rays_are_traced_again_with_the_level_stack():
+    """Round 4: the shadow kernel runs the fast stack (19 entries); a ray that runs out of entries is traced again with the
+    one-entry-per-level discipline in its lane's own LDS column.  With 6 entries that retry is the common case: the shadow /
+    sw_dir_cor parity tests must stay bit-identical (the variable is read once per process, hence the subprocess)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HZ_SHADOW_FAST_CAP="6")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_gpu_parity.py"), "-k", "shadow_and_sw_dir_cor"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
