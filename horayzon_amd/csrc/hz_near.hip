@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
     constexpr int NEC = 10;            // per-edge constants kept in LDS: a_e a_n a_z b_e b_n b_z r_a r_b x_a x_b
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_near[];
     const int A = p.azim_num;
-    // LDS: [ sin phi_k, cos phi_k : 2 A floats, shared ] then per wave
+    // LDS: [ (sin phi_k, cos phi_k) pairs : 2 A floats, shared ] then per wave
     //      [ q: NVERT x 5 | E: A | flags: 4 | first azimuth bin, bins per edge: 2 NEDGE | task prefix: NEDGE + 1 |
     //        edge constants: NEC x NEDGE | task -> edge map: HZ_NEAR_MAXT bytes ]
     const int per_wave = near_per_wave_words<W>(A);
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
     int *pre = ek + 2 * NEDGE;                                      // [NEDGE + 1]
     float *ec = reinterpret_cast<float *>(pre + NEDGE + 1);         // [NEDGE][NEC]
     unsigned char *tmap = reinterpret_cast<unsigned char *>(ec + NEC * NEDGE);   // [HZ_NEAR_MAXT]
-    for (int k = threadIdx.x; k < A; k += 256) { tab[k] = p.azim_sin[k]; tab[A + k] = p.azim_cos[k]; }
+    for (int k = threadIdx.x; k < A; k += 256) { tab[2 * k] = p.azim_sin[k]; tab[2 * k + 1] = p.azim_cos[k]; }   // (sin, cos) pairs: one 8 B read
     const int cl = blockIdx.x * 4 + wave;                           // cell of this wave (launch local)
     const bool have = cl < p.n_cells;
     const int i = have ? p.row_begin + cl / p.dim_in_1 : 0, j = have ? cl % p.dim_in_1 : 0;
@@ -222,12 +222,13 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
             const float er = 6.0e-7f * (ra + rb), ez = 6.0e-7f * ((__builtin_fabsf(az) + __builtin_fabsf(bz)) + (ra + rb));
             const float dz = bz - az;
             const float ninf = -__builtin_inff();
-            for (int kk = first; kk < last; kk++) {
+            int k = first;                                           // first lies in (-A, 2 A): wrapped once, then stepped
+            if (k < 0) k += A;
+            if (k >= A) k -= A;
+            for (int kk = first; kk < last; kk++, k = (k + 1 == A) ? 0 : k + 1) {
 #pragma clang fp contract(fast)      // bounds, not the bit-exact contract: FMAs only remove roundings the error terms allow for
-                int k = kk;                                          // kk lies in (-A, 2 A)
-                if (k < 0) k += A;
-                if (k >= A) k -= A;
-                const float sp = tab[k], cp = tab[A + k];
+                const float2 sc = reinterpret_cast<const float2 *>(tab)[k];
+                const float sp = sc.x, cp = sc.y;
                 const float da = ae * cp - an * sp, db = be * cp - bn * sp;     // signed distances from the plane
                 const float fa = ae * sp + an * cp, fb = be * sp + bn * cp;     // along the azimuth (r of the end points)
                 const bool in_a = __builtin_fabsf(da) <= tol_a, in_b = __builtin_fabsf(db) <= tol_b;
