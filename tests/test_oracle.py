@@ -175,6 +175,26 @@ def test_random_configurations_bvh_equals_brute_force(orc):
         assert sa["rays"] == sb["rays"] and sa["guards"] == sb["guards"], desc
 
 
+def test_known_counter_example_grazing_ray_at_its_origin(orc):
+    """DESIGN.md section 4 item 3, found by scripts/fuzz_near_adversarial.py --seed 48001 (configuration 2536): the float
+    triangle test accepts, at t = 0, a ray whose origin lies 5 mm OUTSIDE the triangle's box -- it grazes the plane of a
+    cliff triangle and T cancels to exactly 0.  Brute force (and the GPU) report the hit, the oracle's tree culls the box.
+    This test pins the case as it is (guard count 89 / 88, same horizon); whoever makes the box tests start below 0 on
+    both sides turns it into an equality."""
+    rng = np.random.default_rng(48001)
+    for _ in range(2537):
+        kw, par, desc = cases.adversarial_near_case(rng)
+    assert desc["dem"] == [17, 22] and par["ray_algorithm"] == "discrete_sampling"
+    sc = orc.Scene(kw["vert_grid"], 17, 22)
+    o = np.array([[140.00006, 50.000305, 533.005]], np.float32)
+    d = np.array([[0.01114424, 0.06120159, 0.9980782]], np.float32)
+    assert bool(sc.occluded(o, d, 132.0, mode=orc.MODE_BRUTE)[0]) and not bool(sc.occluded(o, d, 132.0, mode=orc.MODE_BVH)[0])
+    h0, _, s0 = orc.horizon_gridded(**kw, **par, return_stats=True, mode=orc.MODE_BVH)
+    h1, _, s1 = orc.horizon_gridded(**kw, **par, return_stats=True, mode=orc.MODE_BRUTE)
+    assert np.array_equal(h0, h1, equal_nan=True) and s0["rays"] == s1["rays"]
+    assert (s0["guards"], s1["guards"]) == (88, 89)
+
+
 def test_horizon_bvh_equals_brute_force_and_tin(orc):
     g = cases.rough_terrain(34, 38, seed=15, offset=3, relief=500.0)
     kw = cases.grid_kwargs(g)
