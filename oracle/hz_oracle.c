@@ -47,6 +47,10 @@ static int g_platform_libm = 0;
 void orc_set_libm(int platform) { g_platform_libm = platform; }
 static int g_quad_order = 0;      /* 1: second triangle of a quad as Embree's quad / grid intersector orders it */
 void orc_set_quad_order(int embree_quad) { g_quad_order = embree_quad; }
+/* Experiment hook (the grazing-at-the-origin counter-example): the tree's box tests start at the
+ * parameter -tau_pads * pad instead of 0.  0 (the default) is the contract the GPU is compared with. */
+static float g_box_start_pads = 0.0f;
+void orc_set_box_start(float tau_pads) { g_box_start_pads = tau_pads; }
 static inline float r_acosf(float x) { return g_platform_libm ? acosf(x) : hz_crm_acosf(x); }
 static inline float r_tanf(float x) { return g_platform_libm ? tanf(x) : hz_crm_tanf(x); }
 static inline float r_cosf(float x) { return g_platform_libm ? cosf(x) : hz_crm_cosf(x); }
@@ -378,18 +382,18 @@ static inline int tin_hit(const orc_scene *s, int t, const float *o,
 /* ray / box: conservative slab test                                          */
 /* ------------------------------------------------------------------------- */
 
-typedef struct { float o[3], d[3], rd[3], tfar; } ray_t;
+typedef struct { float o[3], d[3], rd[3], tfar, tstart; } ray_t;
 
 static inline void ray_init(ray_t *r, const float *o, const float *d, float tfar) {
     for (int k = 0; k < 3; k++) {
         r->o[k] = o[k]; r->d[k] = d[k];
         r->rd[k] = (fabsf(d[k]) > 1e-30f) ? 1.0f / d[k] : copysignf(1e30f, d[k]);
     }
-    r->tfar = tfar;
+    r->tfar = tfar; r->tstart = 0.0f;
 }
 
 static inline int box_hit(const ray_t *r, const float *lo, const float *hi) {
-    float tmin = 0.0f, tmax = r->tfar;
+    float tmin = r->tstart, tmax = r->tfar;
     for (int k = 0; k < 3; k++) {
         const float t0 = (lo[k] - r->o[k]) * r->rd[k];
         const float t1 = (hi[k] - r->o[k]) * r->rd[k];
@@ -558,7 +562,7 @@ static int occluded(const orc_scene *s, const float *o, const float *d, float tf
 static int occluded_impl(const orc_scene *s, const float *o, const float *d, float tfar,
                          int mode, orc_counters *cnt) {
     if (mode == 0) {
-        ray_t r; ray_init(&r, o, d, tfar);
+        ray_t r; ray_init(&r, o, d, tfar); r.tstart = -g_box_start_pads * s->pad;
         int stack[128]; int sp = 0;
         if (s->n_gn > 0) {
             stack[sp++] = 0;
@@ -611,7 +615,7 @@ static int closest(const orc_scene *s, const float *o, const float *d, float tfa
         const float *p2 = s->vs + 3 * (size_t)s->ts[3 * (tt) + 2]; \
         if (tri_hit_t_f(o, d, tfar, p0, p1, p2, &t)) { any = 1; if (t < best) best = t; } } while (0)
     if (mode == 0) {
-        ray_t r; ray_init(&r, o, d, tfar);
+        ray_t r; ray_init(&r, o, d, tfar); r.tstart = -g_box_start_pads * s->pad;
         int stack[128]; int sp = 0;
         if (s->n_gn > 0) {
             stack[sp++] = 0;

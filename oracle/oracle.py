@@ -63,6 +63,7 @@ def lib():
         L.orc_num_threads.restype = C.c_int
         L.orc_set_libm.argtypes = [C.c_int]
         L.orc_set_quad_order.argtypes = [C.c_int]
+        L.orc_set_box_start.argtypes = [C.c_float]
         L.orc_crmath_sweep.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, u64p]
         _lib = L
     return _lib
@@ -125,6 +126,12 @@ def set_quad_order(embree_quad):
     (horizon_comp.cpp:142-148).  True: as (d, c, b), the order Embree's quad / grid intersector forms from the quad
     (v0, v1, v2, v3) of horizon_comp.cpp:165-172 -- same triangle, rotated vertices, different rounding."""
     lib().orc_set_quad_order(int(bool(embree_quad)))
+
+
+def set_box_start(tau_pads=0.0):
+    """Experiment hook: the tree's box tests start at -tau_pads * pad instead of 0 (0 = the contract; DESIGN.md section 4
+    item 3 has the counter-example this is for)."""
+    lib().orc_set_box_start(float(tau_pads))
 
 
 def crmath_sweep(which, lo, hi, y=0.0):

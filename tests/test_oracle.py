@@ -193,6 +193,14 @@ def test_known_counter_example_grazing_ray_at_its_origin(orc):
     h1, _, s1 = orc.horizon_gridded(**kw, **par, return_stats=True, mode=orc.MODE_BRUTE)
     assert np.array_equal(h0, h1, equal_nan=True) and s0["rays"] == s1["rays"]
     assert (s0["guards"], s1["guards"]) == (88, 89)
+    # the experiment hook for the fix: box tests that start 8 pads below 0 find the triangle
+    orc.set_box_start(8.0)
+    try:
+        assert bool(sc.occluded(o, d, 132.0, mode=orc.MODE_BVH)[0])
+        h2, _, s2 = orc.horizon_gridded(**kw, **par, return_stats=True, mode=orc.MODE_BVH)
+        assert np.array_equal(h2, h1, equal_nan=True) and s2["guards"] == 89
+    finally:
+        orc.set_box_start(0.0)
 
 
 def test_horizon_bvh_equals_brute_force_and_tin(orc):
