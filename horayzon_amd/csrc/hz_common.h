@@ -253,7 +253,21 @@ __device__ __forceinline__ bool hz_tri_hit_t(float ox, float oy, float oz, float
 
 // ---------------------------------------------------------------------------
 // per-ray constants for the conservative slab test (centred frame)
+//
+// Where the box tests START (round 5).  The triangle test accepts 0 <= T sgn(den) in float32.
+// For a ray whose origin lies within rounding of a triangle's plane (|h| <~ 16 u |v0| / sin(phi), u = 2^-24, phi the
+// triangle's angle at v0) the computed T can have the wrong sign: the test then accepts a crossing that in exact
+// arithmetic lies BEHIND the origin, at t* = h / sin(theta) (theta = angle between ray and plane) -- millimetres for a
+// grazing ray, while the origin may sit just outside that triangle's padded box.  A tree whose box tests start at exactly
+// 0 culls that box; brute force reports the hit (found by the adversarial sweep at the end of round 4: seed 48001, #2536).
+// So box tests run over [-tau, tfar + tau] of the ray, tau = HZ_BOX_START_PADS * pad (hz_scene.hip: pad = 1e-6 diag +
+// 4 eps max|coord|): every traversal kernel shifts the box-test origin BACK by tau along the ray (the same mechanism the
+// near-field certificates use to shift it forward) and passes tfar_box = tfar + 2 tau (the far end seen from the shifted
+// origin) -- no instruction in the node step changes.  Triangles are always tested with the true origin and the true tfar.
 // ---------------------------------------------------------------------------
+#ifndef HZ_BOX_START_PADS
+#define HZ_BOX_START_PADS 16.0f
+#endif
 struct RayBox {
     float rdx, rdy, rdz;     // 1 / d (clamped away from inf)
     float ordx, ordy, ordz;  // (o - center) * rd
@@ -477,7 +491,7 @@ template <int TPB, bool COUNT, int QLEN = 2, bool NODELET = false, bool LEVELSTA
 __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Prim *__restrict__ prims,
                                         const float4 *top, int ntop, int *stack, int tid,
                                         float ox, float oy, float oz, float dx, float dy, float dz, float tfar,
-                                        const RayBox &rb, TravState &t, int regroup, int leaf_bias,
+                                        float tfar_box, const RayBox &rb, TravState &t, int regroup, int leaf_bias,
                                         TravCounters &cnt, int stack_cap, bool &overflow) {
     const int lane = tid & 63;
     int node = t.node, sp = t.sp, pf = t.pf, pm = t.pm, lq0 = t.lq0, lq1 = t.lq1;
@@ -597,7 +611,7 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
                 // nick a crest are served by the hit cache.  (Rounds 2-3 stored the tallest child first: +1 %; the
                 // quadrant order is what lets x and y share one range per half, i.e. the 32 B node.)
                 bool h0, h1, h2, h3;
-                hz_node_hits(nr, rb, tfar, n1, h0, h1, h2, h3);
+                hz_node_hits(nr, rb, tfar_box, n1, h0, h1, h2, h3);
                 const int first = __float_as_int(n0.w);
                 HZ_PROBE_PADS(n0.x);
                 if (LEVELSTACK) {
@@ -668,7 +682,7 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
 template <int TPB>
 __device__ __forceinline__ bool hz_closest(const Node *__restrict__ nodes, const Prim *__restrict__ prims,
                                            int *stack, int tid, float ox, float oy, float oz, float dx,
-                                           float dy, float dz, float tfar, const RayBox &rb, float *dist) {
+                                           float dy, float dz, float tfar, float tau, const RayBox &rb, float *dist) {
     int node = 0, sp = 0;
     float best = __builtin_inff();
     bool any = false;
@@ -676,7 +690,8 @@ __device__ __forceinline__ bool hz_closest(const Node *__restrict__ nodes, const
         if (node >= 0) {
             float4 n0; uint4 n1;
             hz_load_node(nodes + node, n0, n1);
-            const float tf = any ? __builtin_fminf(tfar, best * 1.0001f) : tfar;
+            // (`rb` is the frame of the origin shifted back by tau: the box tests run over [-tau, tf + tau] of the ray)
+            const float tf = (any ? __builtin_fminf(tfar, best * 1.0001f) : tfar) + 2.0f * tau;
             const NodeRay nr = hz_node_ray(rb, n0.x, n0.y, n0.z);
             bool h0, h1, h2, h3;
             hz_node_hits(nr, rb, tf, n1, h0, h1, h2, h3);

@@ -207,7 +207,7 @@ __global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : HZ_WG_PER_CU) void k_horizon(Ho
                 dx = (r00 * rx + r01 * ry) + r02 * rz;
                 dy = (r10 * rx + r11 * ry) + r12 * rz;
                 dz = (r20 * rx + r21 * ry) + r22 * rz;
-                tn = (s.ind >= near_i) ? near_rad : 0.0f;
+                tn = (s.ind >= near_i) ? near_rad : -p.sv.tau;    // no certificate: the box tests start at -tau (hz_common.h)
                 if (COUNT && tn > 0.0f) shortened++;
                 if (COUNT) want_v = p.verify_near && tn > 0.0f && (((rays + cert) & p.verify_mask) == 0u);
                 HZ_OC(ocx, ocy, ocz)
@@ -226,14 +226,14 @@ __global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : HZ_WG_PER_CU) void k_horizon(Ho
         bool start_v = false, viol = false;
         if (ray_active) {
             const int r = hz_trace<HZ_TPB, COUNT, HZ_QLEN, NODELET, LEVELSTACK>(p.sv.nodes, p.sv.prims, top, ntop, stack, tid, ox, oy, oz,
-                                                 dx, dy, dz, tfar, rb, ts, p.regroup, p.leaf_bias, tc, p.stack_cap, overflow);
+                                                 dx, dy, dz, tfar, tfar + 2.0f * p.sv.tau, rb, ts, p.regroup, p.leaf_bias, tc, p.stack_cap, overflow);
             if (r == 0 && second) {                      // nothing in the cached subtree: full traversal
                 second = false; hz_trav_reset(ts);
             } else if (COUNT && want_v && r != 2) {
                 // the shortened ray is done: trace it again over its full length and compare the decisions
                 want_v = false; verifying = true; first_result = (r == 1); start_v = true;
                 HZ_OC(ocx, ocy, ocz)
-                rb = hz_raybox(ocx, ocy, ocz, dx, dy, dz);
+                rb = hz_raybox(ocx - p.sv.tau * dx, ocy - p.sv.tau * dy, ocz - p.sv.tau * dz, dx, dy, dz);
                 hz_trav_reset(ts);
             } else if (r != 2) {
                 if (COUNT && verifying) { viol = ((r == 1) != first_result); verifying = false; }

@@ -74,6 +74,7 @@ struct SceneView {
     int d1;          // DEM row length (vertices)
     int n_top;       // BFS-ordered top nodes available for LDS staging
     float cx, cy, cz;
+    float tau;       // box tests start at -tau and end at tfar + tau (hz_common.h: HZ_BOX_START_PADS)
 };
 
 inline SceneView scene_view(const Scene *sc) {
@@ -81,6 +82,7 @@ inline SceneView scene_view(const Scene *sc) {
     v.verts = sc->verts(); v.nodes = sc->nodes(); v.prims = sc->prims(); v.anc = sc->anc();
     v.d1 = sc->hdr.d1; v.n_top = sc->hdr.n_top;
     v.cx = sc->hdr.center[0]; v.cy = sc->hdr.center[1]; v.cz = sc->hdr.center[2];
+    v.tau = HZ_BOX_START_PADS * sc->hdr.pad;
     return v;
 }
 

@@ -39,13 +39,16 @@ __global__ __launch_bounds__(HZ_TPB) void k_locations(LocParams p) {
         const float ini_x = p.coords[3 * i], ini_y = p.coords[3 * i + 1], ini_z = p.coords[3 * i + 2];
         // put the location onto the mesh: +normal, then -normal (horizon_comp.cpp:947-957)
         float dist = 0.0f;
-        RayBox rbn = hz_raybox(ini_x - p.sv.cx, ini_y - p.sv.cy, ini_z - p.sv.cz, norm_x, norm_y, norm_z);
+        // (every box test starts at -tau: the frame of a RayBox is the origin shifted back by tau, hz_common.h)
+        const float tau = p.sv.tau;
+        const float icx = ini_x - p.sv.cx, icy = ini_y - p.sv.cy, icz = ini_z - p.sv.cz;
+        RayBox rbn = hz_raybox(icx - tau * norm_x, icy - tau * norm_y, icz - tau * norm_z, norm_x, norm_y, norm_z);
         bool hit = hz_closest<HZ_TPB>(p.sv.nodes, p.sv.prims, stack, tid, ini_x, ini_y, ini_z, norm_x, norm_y, norm_z,
-                                      100000.0f, rbn, &dist);
+                                      100000.0f, tau, rbn, &dist);
         if (!hit) {
-            rbn = hz_raybox(ini_x - p.sv.cx, ini_y - p.sv.cy, ini_z - p.sv.cz, -norm_x, -norm_y, -norm_z);
+            rbn = hz_raybox(icx + tau * norm_x, icy + tau * norm_y, icz + tau * norm_z, -norm_x, -norm_y, -norm_z);
             hit = hz_closest<HZ_TPB>(p.sv.nodes, p.sv.prims, stack, tid, ini_x, ini_y, ini_z, -norm_x, -norm_y,
-                                     -norm_z, 100000.0f, rbn, &dist);
+                                     -norm_z, 100000.0f, tau, rbn, &dist);
             dist = (float)((double)dist * -1.0);
         }
         if (!hit) {
@@ -92,16 +95,16 @@ __global__ __launch_bounds__(HZ_TPB) void k_locations(LocParams p) {
             }
         }
         if (have_ray) {
-            const RayBox rb = hz_raybox(ocx, ocy, ocz, dx, dy, dz);
+            const RayBox rb = hz_raybox(ocx - p.sv.tau * dx, ocy - p.sv.tau * dy, ocz - p.sv.tau * dz, dx, dy, dz);
             if (DIST) {                                             // castRay_intersect1, :268-292
                 float d = 0.0f;
-                last_hit = hz_closest<HZ_TPB>(p.sv.nodes, p.sv.prims, stack, tid, ox, oy, oz, dx, dy, dz, p.tfar, rb, &d);
+                last_hit = hz_closest<HZ_TPB>(p.sv.nodes, p.sv.prims, stack, tid, ox, oy, oz, dx, dy, dz, p.tfar, p.sv.tau, rb, &d);
                 if (last_hit) out.dist_hit = d;                     // :545-547 / :589-591
             } else {                                                // castRay_occluded1, :241-262
                 TravState ts; hz_trav_reset(ts);
                 bool overflow = false;       // unused: the one-entry-per-level stack cannot overflow
                 last_hit = hz_trace<HZ_TPB, false>(p.sv.nodes, p.sv.prims, nullptr, 0, stack, tid, ox, oy, oz, dx, dy,
-                                                   dz, p.tfar, rb, ts, 0, 16, tc, 0, overflow) == 1;
+                                                   dz, p.tfar, p.tfar + 2.0f * p.sv.tau, rb, ts, 0, 16, tc, 0, overflow) == 1;
             }
         }
     }

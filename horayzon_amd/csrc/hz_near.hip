@@ -328,7 +328,9 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
         rin = __builtin_sqrtf(cx * cx + cy * cy);
     }
     for (int off = 32; off > 0; off >>= 1) rin = __builtin_fminf(rin, __shfl_xor(rin, off));
-    const bool ok = valid && flags[0] == 0 && rin < 1.0e30f;
+    // (a certificate whose radius is not positive would start the cell's box tests at 0 instead of -tau (hz_common.h): none)
+    const float near_rad = 0.97f * rin - 4.0f * p.pad;
+    const bool ok = valid && flags[0] == 0 && rin < 1.0e30f && near_rad > 0.0f;
     if (p.reasons != nullptr && have && lane == 0) {      // debug histogram (HZ_NEAR_REASONS=1): why cells got no certificate
         const int f = valid ? flags[0] : HZ_NR_WINDOW;
         atomicAdd(&p.reasons[0], 1u);
@@ -353,7 +355,7 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
             }
             p.near_idx[(size_t)cl * A + k] = out;
         }
-        if (lane == 0) p.near_r[cl] = ok ? __builtin_fmaxf(0.97f * rin - 4.0f * p.pad, 0.0f) : 0.0f;
+        if (lane == 0) p.near_r[cl] = ok ? near_rad : 0.0f;
     }
 }
 

@@ -72,11 +72,12 @@ __device__ __forceinline__ bool occluded(const SceneView &sv, int *stack, int ti
     const float tn_ = (float)HZ_PROBE_SHADOW_TN;
     const RayBox rb = hz_raybox(ox - sv.cx + tn_ * dx, oy - sv.cy + tn_ * dy, oz - sv.cz + tn_ * dz, dx, dy, dz);
 #else
-    const RayBox rb = hz_raybox(ox - sv.cx, oy - sv.cy, oz - sv.cz, dx, dy, dz);
+    // (box tests start at -tau: hz_common.h)
+    const RayBox rb = hz_raybox((ox - sv.cx) - sv.tau * dx, (oy - sv.cy) - sv.tau * dy, (oz - sv.cz) - sv.tau * dz, dx, dy, dz);
 #endif
     TravState ts; hz_trav_reset(ts);
     bool overflow = false;      // unused: the one-entry-per-level stack cannot overflow
-    return hz_trace<HZ_TPB, COUNT>(sv.nodes, sv.prims, nullptr, 0, stack, tid, ox, oy, oz, dx, dy, dz, tfar, rb,
+    return hz_trace<HZ_TPB, COUNT>(sv.nodes, sv.prims, nullptr, 0, stack, tid, ox, oy, oz, dx, dy, dz, tfar, tfar + 2.0f * sv.tau, rb,
                                    ts, 0, HZ_SHADOW_LEAF_BIAS, tc, 0, overflow) == 1;
 }
 
@@ -244,7 +245,9 @@ __global__ __launch_bounds__(HZ_TPB, COUNT ? 5 : HZ_SHADOW_WG) void k_shadow_ref
                     const int i = i_base + ((my & 63) >> 3), j = j_base + (my >> 6) * 16 + (my & 7);
                     if (i < p.dim_in_0 && j < p.dim_in_1 && shadow_setup(p, i, j, p_sun_x, p_sun_y, p_sun_z, out_u8, out_f32, r)) {
                         cell = (size_t)i * p.dim_in_1 + j;
-                        rb = hz_raybox(r.ox - p.sv.cx, r.oy - p.sv.cy, r.oz - p.sv.cz, r.dx, r.dy, r.dz);
+                        // (box tests start at -tau: hz_common.h; tfar is infinite here)
+                        rb = hz_raybox((r.ox - p.sv.cx) - p.sv.tau * r.dx, (r.oy - p.sv.cy) - p.sv.tau * r.dy, (r.oz - p.sv.cz) - p.sv.tau * r.dz,
+                                       r.dx, r.dy, r.dz);
                         hz_trav_reset(ts);
                         overflow = false;
                         ray_active = true;
@@ -260,12 +263,12 @@ __global__ __launch_bounds__(HZ_TPB, COUNT ? 5 : HZ_SHADOW_WG) void k_shadow_ref
         if (ray_active) {
             // while cells are left the traversal returns when fewer than 40 lanes are busy (and one finished)
             int res = hz_trace<HZ_TPB, COUNT, 2, false, !FAST>(p.sv.nodes, p.sv.prims, nullptr, 0, stack, tid, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz,
-                                                    __builtin_inff(), rb, ts, (next < total) ? HZ_SHADOW_REGROUP : 0, HZ_SHADOW_LEAF_BIAS, tc, p.stack_cap, overflow);
+                                                    __builtin_inff(), __builtin_inff(), rb, ts, (next < total) ? HZ_SHADOW_REGROUP : 0, HZ_SHADOW_LEAF_BIAS, tc, p.stack_cap, overflow);
             if (FAST && res != 2 && overflow) {
                 bool unused = false;
                 hz_trav_reset(ts);
                 res = hz_trace<HZ_TPB, COUNT, 2, false, true>(p.sv.nodes, p.sv.prims, nullptr, 0, stack, tid, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz,
-                                                                    __builtin_inff(), rb, ts, 0, HZ_SHADOW_LEAF_BIAS, tc, 0, unused);
+                                                                    __builtin_inff(), __builtin_inff(), rb, ts, 0, HZ_SHADOW_LEAF_BIAS, tc, 0, unused);
                 if (COUNT && p.counters) atomicAdd(&p.counters[8], 1ull);     // rays traced twice
             }
             if (res != 2) {

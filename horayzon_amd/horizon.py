@@ -141,7 +141,10 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
     # True: certificates when the scene allows them; False: never; "force": even for a mesh that is not a height field (tests)
     opts.no_near_skip = -1 if _near_skip == "force" else (0 if _near_skip else 1)
     opts.level_stack = int(_level_stack)      # True / 1: level stack from the start; -n: fast stack of n entries (tests)
-    opts.verify_near = int(_verify_near) if not isinstance(_verify_near, bool) else int(_verify_near)
+    n_verify = int(_verify_near)              # False / 0: off; True / 1: every shortened ray; N: one of every N (rounded up to 2^k)
+    if n_verify < 0 or n_verify != _verify_near:
+        raise ValueError("_verify_near must be a non-negative integer (or a bool)")
+    opts.verify_near = n_verify
     opts.skip_hori = 1 if svf_only else 0
     opts.count_work = int(bool(count_work))
     if rows is not None:

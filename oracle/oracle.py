@@ -128,9 +128,12 @@ def set_quad_order(embree_quad):
     lib().orc_set_quad_order(int(bool(embree_quad)))
 
 
-def set_box_start(tau_pads=0.0):
-    """Experiment hook: the tree's box tests start at -tau_pads * pad instead of 0 (0 = the contract; DESIGN.md section 4
-    item 3 has the counter-example this is for)."""
+BOX_START_PADS = 16.0      # hz_oracle.c: ORC_BOX_START_PADS = hz_common.h: HZ_BOX_START_PADS
+
+
+def set_box_start(tau_pads=BOX_START_PADS):
+    """The tree's box tests run over [-tau, tfar + tau], tau = tau_pads * pad.  The default
+    (16 pads) is the contract; 0 restores the round-4 tree, which culls the grazing-at-the-origin counter-example."""
     lib().orc_set_box_start(float(tau_pads))
 
 

@@ -1,12 +1,12 @@
 """Replay ONE configuration of scripts/fuzz_near_adversarial.py (seed, index) and say what differs from the oracle.
-usage: python scripts/r04/replay_adv.py <seed> <index>"""
+usage: python scripts/replay_adv.py <seed> <index>"""
 import json
 import os
 import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import horayzon_amd as hz          # noqa: E402
 from tests import cases            # noqa: E402

@@ -178,9 +178,9 @@ def test_random_configurations_bvh_equals_brute_force(orc):
 def test_known_counter_example_grazing_ray_at_its_origin(orc):
     """DESIGN.md section 4 item 3, found by scripts/fuzz_near_adversarial.py --seed 48001 (configuration 2536): the float
     triangle test accepts, at t = 0, a ray whose origin lies 5 mm OUTSIDE the triangle's box -- it grazes the plane of a
-    cliff triangle and T cancels to exactly 0.  Brute force (and the GPU) report the hit, the oracle's tree culls the box.
-    This test pins the case as it is (guard count 89 / 88, same horizon); whoever makes the box tests start below 0 on
-    both sides turns it into an equality."""
+    cliff triangle and T cancels to exactly 0.  Brute force reports the hit; a tree whose box tests start at exactly 0 culls
+    the box (round 4: guard count 88 against 89).  Since round 5 the box tests of the oracle's tree (and of the HIP
+    kernels, tests/test_gpu_fuzz.py::test_grazing_ray_counter_example_on_the_gpu) run over [-tau, tfar + tau]: tree = brute force."""
     rng = np.random.default_rng(48001)
     for _ in range(2537):
         kw, par, desc = cases.adversarial_near_case(rng)
@@ -188,19 +188,24 @@ def test_known_counter_example_grazing_ray_at_its_origin(orc):
     sc = orc.Scene(kw["vert_grid"], 17, 22)
     o = np.array([[140.00006, 50.000305, 533.005]], np.float32)
     d = np.array([[0.01114424, 0.06120159, 0.9980782]], np.float32)
-    assert bool(sc.occluded(o, d, 132.0, mode=orc.MODE_BRUTE)[0]) and not bool(sc.occluded(o, d, 132.0, mode=orc.MODE_BVH)[0])
+    assert bool(sc.occluded(o, d, 132.0, mode=orc.MODE_BRUTE)[0]) and bool(sc.occluded(o, d, 132.0, mode=orc.MODE_BVH)[0])
     h0, _, s0 = orc.horizon_gridded(**kw, **par, return_stats=True, mode=orc.MODE_BVH)
     h1, _, s1 = orc.horizon_gridded(**kw, **par, return_stats=True, mode=orc.MODE_BRUTE)
     assert np.array_equal(h0, h1, equal_nan=True) and s0["rays"] == s1["rays"]
-    assert (s0["guards"], s1["guards"]) == (88, 89)
-    # the experiment hook for the fix: box tests that start 8 pads below 0 find the triangle
-    orc.set_box_start(8.0)
+    assert (s0["guards"], s1["guards"]) == (89, 89)
+    # the hole is real: with box tests that start at exactly 0 (the round-4 tree) the triangle's box is culled;
+    # 4 pads are the least that find it, the contract has 16
     try:
-        assert bool(sc.occluded(o, d, 132.0, mode=orc.MODE_BVH)[0])
-        h2, _, s2 = orc.horizon_gridded(**kw, **par, return_stats=True, mode=orc.MODE_BVH)
-        assert np.array_equal(h2, h1, equal_nan=True) and s2["guards"] == 89
-    finally:
         orc.set_box_start(0.0)
+        assert not bool(sc.occluded(o, d, 132.0, mode=orc.MODE_BVH)[0])
+        _, _, s2 = orc.horizon_gridded(**kw, **par, return_stats=True, mode=orc.MODE_BVH)
+        assert s2["guards"] == 88
+        orc.set_box_start(2.0)
+        assert not bool(sc.occluded(o, d, 132.0, mode=orc.MODE_BVH)[0])
+        orc.set_box_start(4.0)
+        assert bool(sc.occluded(o, d, 132.0, mode=orc.MODE_BVH)[0])
+    finally:
+        orc.set_box_start()
 
 
 def test_horizon_bvh_equals_brute_force_and_tin(orc):
