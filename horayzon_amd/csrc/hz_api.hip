@@ -537,13 +537,15 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     a.hit_cache = (opts && opts->no_hit_cache) ? 0 : 1;
     a.counters = (unsigned long long *)cnt_dev;
     // near-field certificates (hz_near.hip): one pre-pass per chunk into a scratch buffer kept with the scene.
-    // Off with an outer-domain TIN (its triangles are not part of the height field the distance bound relies on),
-    // beyond the azimuth count the pre-pass holds in LDS, and on request.
-    // Off, too, for a mesh that is not a height field over the world (x, y) plane (HZ_BLOB_HEIGHT_FIELD, checked by the
-    // scene build: the distance bound near_r assumes it); opts.no_near_skip < 0 overrides that check (tests only).
+    // Off beyond the azimuth count the pre-pass holds in LDS, and on request.  The distance bound near_r assumes a height
+    // field over the world (x, y) plane (HZ_BLOB_HEIGHT_FIELD, checked by the scene build).  Where only SOME quads break
+    // that, or an outer-domain TIN is present, the scene carries a bitmap of their (x, y) footprints (HZ_BLOB_BAD_MAP) and
+    // the pre-pass refuses the cells near them, one by one (round 5; rounds 3-4: off for the whole scene).  Neither flag
+    // (a bad primitive too large to rasterise): off.  opts.no_near_skip < 0 overrides both checks (tests only).
     const int near_opt = opts ? opts->no_near_skip : 0;
     const bool height_field = (sc->hdr.flags & HZ_BLOB_HEIGHT_FIELD) != 0;
-    const bool use_near = near_opt <= 0 && (height_field || near_opt < 0) && sc->hdr.n_tin == 0 &&
+    const bool bad_map = (sc->hdr.flags & HZ_BLOB_BAD_MAP) != 0;
+    const bool use_near = near_opt <= 0 && (height_field || bad_map || near_opt < 0) &&
                           azim_num <= near_max_azim() && tb.elev_num <= 65534;
     a.near_idx = nullptr; a.near_r = nullptr;
     a.tile_list = nullptr; a.n_list = 0;
@@ -652,6 +654,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             na.near_idx = (unsigned short *)sc->near_buf;
             na.near_r = (float *)((char *)sc->near_buf + idx_bytes);
             na.reasons = near_reasons;
+            na.ignore_bad_map = near_opt < 0 ? 1 : 0;
             hipEvent_t n0 = nullptr, n1 = nullptr;
             if (hipEventCreate(&n0) != hipSuccess || hipEventCreate(&n1) != hipSuccess) return fail(set_error(HZ_ERR_HIP, "hipEventCreate failed"));
             (void)hipEventRecord(n0, st);
@@ -774,10 +777,11 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     if (near_reasons) {
         unsigned h[20] = {0};
         if (hipMemcpy(h, near_reasons, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
-            static const char *nm[13] = {"frame", "vertex_on_axis", "edge_over_axis", "az_tolerance", "inplane_edge", "crossing_near_axis",
-                                         "interval", "precision", "edge_on", "orientation", "origin_below", "axis_in_triangle", "window_or_mask"};
+            static const char *nm[14] = {"frame", "vertex_on_axis", "edge_over_axis", "az_tolerance", "inplane_edge", "crossing_near_axis",
+                                         "interval", "precision", "edge_on", "orientation", "origin_below", "axis_in_triangle", "window_or_mask",
+                                         "bad_mesh_nearby"};
             fprintf(stderr, "hz near reasons: cells %u certified %u", h[0], h[1]);
-            for (int b = 0; b < 13; b++) if (h[2 + b]) fprintf(stderr, " %s %u", nm[b], h[2 + b]);
+            for (int b = 0; b < 14; b++) if (h[2 + b]) fprintf(stderr, " %s %u", nm[b], h[2 + b]);
             fprintf(stderr, " | tasks %u bins %u\n", h[16], h[17]);
         }
     }
@@ -793,12 +797,12 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         printf("Average number of rays per location and azimuth: %.2f \n",
                cnt[4] ? (double)((float)cnt[0] / (float)(cnt[4] * (unsigned long long)azim_num)) : 0.0);
         // (not a line of the reference: why this call ran without the near-field certificates, if it did)
-        if (!use_near && near_opt <= 0) {
-            if (!height_field)
-                printf("Near-field certificates off: %u DEM triangle(s) are near-vertical or oriented against the majority in the "
-                       "(x, y) plane -- the mesh is not a height field (results unaffected, slower)\n", sc->hdr.n_flipped);
-            else if (sc->hdr.n_tin != 0) printf("Near-field certificates off: outer simplified domain present (results unaffected)\n");
-        }
+        if (!use_near && near_opt <= 0 && !height_field && !bad_map)
+            printf("Near-field certificates off: a DEM quad that is not part of a height field over the (x, y) plane, or a triangle "
+                   "of the outer simplified domain, is too large for the per-cell guard (results unaffected, slower)\n");
+        else if (use_near && bad_map)
+            printf("Near-field certificates per cell: %u DEM triangle(s) project onto the (x, y) plane collapsed or against the "
+                   "majority, %d outer-domain triangle(s); cells near them run without (results unaffected)\n", sc->hdr.n_flipped, sc->hdr.n_tin);
         fflush(stdout);
     }
     return HZ_OK;

@@ -30,7 +30,7 @@
 #include <hip/hip_runtime.h>
 
 #define HZ_BLOB_MAGIC 0x485a4c42u /* "HZLB" */
-#define HZ_BLOB_VERSION 9u
+#define HZ_BLOB_VERSION 10u
 #define HZ_WAVE 64
 
 struct BlobHeader {
@@ -46,17 +46,28 @@ struct BlobHeader {
     uint64_t off_anc;        // int32[P]: for every leaf the node `anc_levels` levels above it (hit cache)
     int32_t anc_levels;
     int32_t n_prim_slots;    // leaf records incl. the unused slots of partly filled blocks (prims, anc are this long)
-    uint32_t flags;          // HZ_BLOB_HEIGHT_FIELD: see below
+    uint32_t flags;          // HZ_BLOB_HEIGHT_FIELD / HZ_BLOB_BAD_MAP: see below
     uint32_t n_flipped;      // DEM triangles whose (x, y) projection is degenerate or oriented against the majority
-    uint8_t reserved[256 - 144];
+    uint64_t off_bad;        // HZ_BLOB_BAD_MAP: bitmap of bad_nb x bad_nb bits (row-major in y, uint32 words) over the scene's (x, y) box
+    int32_t bad_nb;
+    float bad_x0, bad_y0, bad_sx, bad_sy;   // bitmap cell of a point: (floor((x - bad_x0) * bad_sx), floor((y - bad_y0) * bad_sy)), clamped
+    uint8_t reserved[256 - 172];
 };
 static_assert(sizeof(BlobHeader) == 256, "BlobHeader must be 256 bytes");
-// flags bit 0: the DEM mesh is a height field over the world (x, y) plane -- every DEM triangle projects onto that plane
-// with the same orientation and a non-degenerate area (|n_z| > 1e-3 |n|), so the projection of the grid is injective
-// and "outside a window of quads" implies "horizontally outside its boundary polygon".  The near-field certificates
-// (hz_near.hip) rely on exactly that; the reference accepts any vertex buffer (horizon_comp.cpp:126-127), e.g. a frame
-// whose z axis is not "up", and for such a mesh the certificates stay off.
+// flags bit 0 (HZ_BLOB_HEIGHT_FIELD): the DEM mesh is a height field over the world (x, y) plane -- every DEM triangle
+// projects onto that plane with the same orientation and a non-degenerate area (the 2-D cross product of two projected
+// edges is larger than its own rounding: |n_z| > 1e-5 (|ux vy| + |uy vx|); how STEEP a triangle is does not matter -- a
+// NoData hole or a 30 km step on a regular (x, y) grid is a height field), and there is no outer TIN: then the
+// projection of the grid is injective and "outside a window of quads" implies "horizontally outside its boundary
+// polygon".  The near-field certificates (hz_near.hip) rely on exactly that; the reference accepts any vertex buffer
+// (horizon_comp.cpp:126-127), e.g. a frame whose z axis is not "up" or a mesh folded over itself.
+// flags bit 1 (HZ_BLOB_BAD_MAP; round 5): some DEM quads are NOT like that (or there is an outer TIN), and the blob
+// carries a coarse bitmap over the scene's (x, y) box in which every such quad and every TIN triangle has marked the
+// cells its (x, y) footprint touches.  A cell whose window's (x, y) bounding box touches no marked bitmap cell keeps
+// its certificate (hz_near.hip; DESIGN.md section 4.3 row R has the argument), every other cell is refused.  Neither
+// flag: a bad primitive's footprint was too large to rasterise -- no certificates for this scene.
 #define HZ_BLOB_HEIGHT_FIELD 1u
+#define HZ_BLOB_BAD_MAP 2u
 
 // traversal links: >= 0 node index; < 0 leaf, record index = link & 0x7fffffff (sign + magnitude, so that child k of
 // a block is `first + k` for both kinds); HZ_EMPTY: nothing (the largest positive value: "is a node" is one unsigned

@@ -43,6 +43,8 @@ struct HorizonParams {
     int row_begin, row_end;
     TileMap tm;                    // tile grid of the slab -> workgroups (XCD aware)
     float dist, hori_fill, ray_org_elev;
+    float dist_box, neg_tau;       // dist + 2 tau and -tau (hz_common.h: where the box tests start and end), formed on the host: uniform
+                                   // float arithmetic in the kernel would sit in vector registers, and there is none to spare
     int top_nodes, regroup, stack_bytes, leaf_bias, stage_bytes, hit_cache, stack_cap;
     int pre_bytes;                 // LDS in front of the stack: the output staging buffer, or (no staging) two padding rows --
                                    // the fast stack reads the rows below its sentinel together with the top (hz_trace)
@@ -68,6 +70,10 @@ template <int ALG, bool COUNT, bool STAGE, bool NODELET, bool LEVELSTACK>
 #endif
 __global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : HZ_WG_PER_CU) void k_horizon(HorizonParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+#ifdef HZ_CODE_SHIFT   // measurement probe: moves everything below by 4 * HZ_CODE_SHIFT bytes (does the position of the traversal loop matter?)
+#pragma unroll
+    for (int q_ = 0; q_ < HZ_CODE_SHIFT; q_++) asm volatile("s_nop 0");
+#endif
     int *stack = reinterpret_cast<int *>(smem + p.pre_bytes);
     const float4 *top = reinterpret_cast<const float4 *>(smem + p.pre_bytes + p.stack_bytes);
     const int tid = threadIdx.x;
@@ -207,7 +213,7 @@ __global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : HZ_WG_PER_CU) void k_horizon(Ho
                 dx = (r00 * rx + r01 * ry) + r02 * rz;
                 dy = (r10 * rx + r11 * ry) + r12 * rz;
                 dz = (r20 * rx + r21 * ry) + r22 * rz;
-                tn = (s.ind >= near_i) ? near_rad : -p.sv.tau;    // no certificate: the box tests start at -tau (hz_common.h)
+                tn = (s.ind >= near_i) ? near_rad : p.neg_tau;    // no certificate: the box tests start at -tau (hz_common.h)
                 if (COUNT && tn > 0.0f) shortened++;
                 if (COUNT) want_v = p.verify_near && tn > 0.0f && (((rays + cert) & p.verify_mask) == 0u);
                 HZ_OC(ocx, ocy, ocz)
@@ -226,14 +232,14 @@ __global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : HZ_WG_PER_CU) void k_horizon(Ho
         bool start_v = false, viol = false;
         if (ray_active) {
             const int r = hz_trace<HZ_TPB, COUNT, HZ_QLEN, NODELET, LEVELSTACK>(p.sv.nodes, p.sv.prims, top, ntop, stack, tid, ox, oy, oz,
-                                                 dx, dy, dz, tfar, tfar + 2.0f * p.sv.tau, rb, ts, p.regroup, p.leaf_bias, tc, p.stack_cap, overflow);
+                                                 dx, dy, dz, tfar, p.dist_box, rb, ts, p.regroup, p.leaf_bias, tc, p.stack_cap, overflow);
             if (r == 0 && second) {                      // nothing in the cached subtree: full traversal
                 second = false; hz_trav_reset(ts);
             } else if (COUNT && want_v && r != 2) {
                 // the shortened ray is done: trace it again over its full length and compare the decisions
                 want_v = false; verifying = true; first_result = (r == 1); start_v = true;
                 HZ_OC(ocx, ocy, ocz)
-                rb = hz_raybox(ocx - p.sv.tau * dx, ocy - p.sv.tau * dy, ocz - p.sv.tau * dz, dx, dy, dz);
+                rb = hz_raybox(ocx + p.neg_tau * dx, ocy + p.neg_tau * dy, ocz + p.neg_tau * dz, dx, dy, dz);
                 hz_trav_reset(ts);
             } else if (r != 2) {
                 if (COUNT && verifying) { viol = ((r == 1) != first_result); verifying = false; }
@@ -347,6 +353,7 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
     const int tiles_i = (rows + 15) / 16;
     p.tm = make_tile_map(tiles_i, (a.dim_in_1 + 15) / 16);
     p.dist = a.dist; p.hori_fill = a.hori_fill; p.ray_org_elev = a.ray_org_elev;
+    p.dist_box = a.dist + 2.0f * p.sv.tau; p.neg_tau = -p.sv.tau;
     // stack.  The fast discipline keeps every pending sibling as its own LDS entry (fewest VALU instructions in a
     // VALU-issue-bound kernel) and gets the entries that still allow 5 workgroups per CU next to the 4 KB output
     // staging: 27 (measured: <= 31 KiB of LDS per workgroup -> 5 resident, 32 KiB -> 4); rays of the 3601^2 tile use

@@ -153,6 +153,7 @@ struct NearArgs {
     unsigned short *near_idx;            // out [rows * dim_in_1][azim_num]
     float *near_r;                       // out [rows * dim_in_1]
     unsigned *reasons = nullptr;         // debug: device u32[20] histogram of refusals (hz_near.hip), or null
+    int ignore_bad_map = 0;              // tests only (opts.no_near_skip < 0): certificates without the scene's per-cell guard
 };
 int near_launch(const Scene *sc, const NearArgs &a, hipStream_t st);
 int near_max_azim();

@@ -32,8 +32,9 @@
 //    north) projection); a cell whose frame is tilted against terrain steeper than the tilt allows gets no certificate.
 //  * The mesh is a height field over the world (x, y) plane, so every triangle outside W projects outside W's
 //    boundary polygon, and its 3-D distance from o is at least the horizontal distance from o to that polygon:
-//    near_r = that distance (shrunk).  Outer-domain TIN triangles do not obey this; with a TIN the certificates
-//    are switched off (near_r = 0).
+//    near_r = that distance (shrunk).  Quads that break the height-field property and outer-domain TIN triangles do
+//    not obey this: the scene build marks their (x, y) footprints in a coarse bitmap (HZ_BLOB_BAD_MAP) and a cell whose
+//    window box touches a marked bitmap cell gets no certificate (round 5; rounds 3-4 switched the whole scene off).
 #include "hz_internal.h"
 
 namespace hz {
@@ -54,12 +55,15 @@ struct NearParams {
     unsigned short *near_idx;          // [n_cells][azim_num]
     float *near_r;                     // [n_cells]
     unsigned *reasons;                 // null, or 20 counters: [0] cells, [1] with a certificate, [2 + b] refused for reason bit b, [16] tasks, [17] bins
+    const uint32_t *bad_bits;          // HZ_BLOB_BAD_MAP: the scene's bitmap of bad (x, y) cells (hz_common.h), or null
+    int bad_nb;
+    float bad_x0, bad_y0, bad_sx, bad_sy;
 };
 
 // why a cell gets no certificate (bits of the per-wave flag word; HZ_NEAR_REASONS=1 prints the histogram of a call)
 enum { HZ_NR_FRAME = 1, HZ_NR_VERTEX_ON_AXIS = 2, HZ_NR_EDGE_OVER_AXIS = 4, HZ_NR_AZ_TOLERANCE = 8, HZ_NR_INPLANE_EDGE = 16,
        HZ_NR_CROSSING_NEAR_AXIS = 32, HZ_NR_INTERVAL = 64, HZ_NR_PRECISION = 128, HZ_NR_EDGE_ON = 256, HZ_NR_ORIENTATION = 512,
-       HZ_NR_ORIGIN_BELOW = 1024, HZ_NR_AXIS_IN_TRIANGLE = 2048, HZ_NR_WINDOW = 4096 };
+       HZ_NR_ORIGIN_BELOW = 1024, HZ_NR_AXIS_IN_TRIANGLE = 2048, HZ_NR_WINDOW = 4096, HZ_NR_BAD_MESH = 8192 };
 
 // order-preserving float <-> int so that LDS atomicMax works on floats
 __device__ __forceinline__ int f2o(float f) { const int i = __float_as_int(f); return i >= 0 ? i : (i ^ 0x7fffffff); }
@@ -116,6 +120,35 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
         q[5 * lane + 2] = (rx * nx + ry * ny) + rz * nz;
         q[5 * lane + 3] = rx; q[5 * lane + 4] = ry;
     }
+    // HZ_BLOB_BAD_MAP (hz_common.h): the distance bound near_r (row R of DESIGN.md section 4.3) holds for this cell if no
+    // bad quad and no TIN triangle projects into the window's (x, y) bounding box.  Those have marked the scene's coarse
+    // bitmap; the window's box spans a few of its cells (one lane each; more than 8 x 8: refused).
+    bool bad_mesh = false;
+    if (p.bad_bits != nullptr && valid) {           // (`valid` is wave uniform)
+        float wx = 0.0f, wy = 0.0f;
+        if (lane < NVERT) {
+            const int a = lane / NV - W, b = lane % NV - W;
+            const float *w = p.verts + 3 * ((size_t)(gi + a) * p.d1 + (size_t)(gj + b));
+            wx = w[0]; wy = w[1];
+        }
+        float xl = lane < NVERT ? wx : __builtin_inff(), xh = lane < NVERT ? wx : -__builtin_inff();
+        float yl = lane < NVERT ? wy : __builtin_inff(), yh = lane < NVERT ? wy : -__builtin_inff();
+        for (int off = 32; off > 0; off >>= 1) {
+            xl = __builtin_fminf(xl, __shfl_xor(xl, off)); xh = __builtin_fmaxf(xh, __shfl_xor(xh, off));
+            yl = __builtin_fminf(yl, __shfl_xor(yl, off)); yh = __builtin_fmaxf(yh, __shfl_xor(yh, off));
+        }
+        const int nb = p.bad_nb;
+        const int i0 = min(max((int)__builtin_floorf((xl - p.bad_x0) * p.bad_sx), 0), nb - 1);
+        const int i1 = min(max((int)__builtin_floorf((xh - p.bad_x0) * p.bad_sx), 0), nb - 1);
+        const int j0 = min(max((int)__builtin_floorf((yl - p.bad_y0) * p.bad_sy), 0), nb - 1);
+        const int j1 = min(max((int)__builtin_floorf((yh - p.bad_y0) * p.bad_sy), 0), nb - 1);
+        if (i1 - i0 >= 8 || j1 - j0 >= 8) bad_mesh = true;
+        else {
+            const int i = i0 + (lane & 7), j = j0 + (lane >> 3);
+            const bool hit = i <= i1 && j <= j1 && ((p.bad_bits[((size_t)j * nb + i) >> 5] >> (i & 31)) & 1u) != 0u;
+            bad_mesh = __ballot(hit) != 0ull;
+        }
+    }
     for (int k = lane; k < A; k += 64) E[k] = f2o(-__builtin_inff());
     if (lane == 0) {
         // The whole construction works in the cell's (east, north, norm) coordinates and assumes that the ray of table
@@ -129,7 +162,7 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
             const float nn = (nx * nx + ny * ny) + nz * nz, tt = (tx * tx + ty * ty) + tz * tz, nt = (nx * tx + ny * ty) + nz * tz;
             if (!(__builtin_fabsf(nn - 1.0f) <= 1.0e-4f && __builtin_fabsf(tt - 1.0f) <= 1.0e-4f && __builtin_fabsf(nt) <= 1.0e-4f)) bad = 1;
         }
-        flags[0] = bad ? HZ_NR_FRAME : 0;
+        flags[0] = (bad ? HZ_NR_FRAME : 0) | (bad_mesh ? HZ_NR_BAD_MESH : 0);
     }
     __syncthreads();
     const float dphi = 6.283185307179586f / (float)A;
@@ -370,6 +403,12 @@ int near_launch(const Scene *sc, const NearArgs &a, hipStream_t st) {
     p.ray_org_elev = a.ray_org_elev; p.low = a.low; p.step = (float)((double)a.hori_acc / 5.0); p.up = a.up;
     p.pad = sc->hdr.pad;
     p.near_idx = a.near_idx; p.near_r = a.near_r; p.reasons = a.reasons;
+    // per-cell guard for scenes that are not a height field everywhere (a.ignore_bad_map: the tests' override)
+    p.bad_bits = nullptr; p.bad_nb = 0; p.bad_x0 = p.bad_y0 = p.bad_sx = p.bad_sy = 0.0f;
+    if ((sc->hdr.flags & HZ_BLOB_BAD_MAP) && !a.ignore_bad_map) {
+        p.bad_bits = reinterpret_cast<const uint32_t *>((const char *)sc->blob + sc->hdr.off_bad);
+        p.bad_nb = sc->hdr.bad_nb; p.bad_x0 = sc->hdr.bad_x0; p.bad_y0 = sc->hdr.bad_y0; p.bad_sx = sc->hdr.bad_sx; p.bad_sy = sc->hdr.bad_sy;
+    }
     if (p.n_cells <= 0) return HZ_OK;
     const size_t lds = ((size_t)2 * a.azim_num + (size_t)4 * near_per_wave_words<HZ_NEAR_W>(a.azim_num)) * sizeof(float);
     HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_near_cert<HZ_NEAR_W>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));

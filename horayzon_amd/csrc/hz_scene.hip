@@ -187,6 +187,73 @@ __device__ __forceinline__ void refit_notify(int parent, int *__restrict__ arriv
     if (atomicAdd(&arrivals[parent], 1) == 1) next_list[atomicAdd(next_count, 1u)] = parent;
 }
 
+// Orientation of a triangle's projection onto the world (x, y) plane: +1 counter-clockwise, -1 clockwise, 0 when the 2-D
+// cross product is not larger than its own rounding (collapsed or edge-on projection: which way it faces is not known).
+// Only the PROJECTION matters for the near-field certificates' distance bound (hz_common.h: HZ_BLOB_HEIGHT_FIELD) -- a
+// triangle may be arbitrarily steep.  (Rounds 3-4 also counted |n_z| <= 1e-3 |n| as degenerate: one NoData sample of
+// -32768 m in a 30 m grid switched the certificates off for the whole scene.)
+__device__ __forceinline__ int tri_orient_xy(const float (&p0)[3], const float (&p1)[3], const float (&p2)[3]) {
+    const float ux = p1[0] - p0[0], uy = p1[1] - p0[1], vx = p2[0] - p0[0], vy = p2[1] - p0[1];
+    const float m0 = ux * vy, m1 = uy * vx, nz = m0 - m1;
+    // the differences carry <= 2^-24 relative each (plus the vertices' own), the products and the difference one more
+    // each: |error of nz| <= 4 * 2^-24 (|m0| + |m1|) to first order -- 1e-5 leaves a factor 40
+    if (!(__builtin_fabsf(nz) > 1.0e-5f * (__builtin_fabsf(m0) + __builtin_fabsf(m1)))) return 0;
+    return nz > 0.0f ? 1 : -1;
+}
+
+// HZ_BLOB_BAD_MAP: every DEM quad with a degenerate or minority-oriented triangle, and every TIN triangle, marks the
+// bitmap cells its (x, y) footprint touches (bounding box + one cell all round: the look-up side computes its cell
+// indices with the same expression, a float product that can land one cell off at a cell border; a TIN triangle, which
+// can be kilometres long, only the cells of that box that no edge of the triangle separates from it).  A footprint of
+// more than HZ_BAD_MAX_SPAN cells per axis raises `overflow` instead (no certificates for the scene).
+#define HZ_BAD_MAX_SPAN 512
+struct BadMap { uint32_t *bits; int nb; float x0, y0, sx, sy; };
+__device__ __forceinline__ int bad_cell(float v, float v0, float s, int nb) {
+    return min(max((int)__builtin_floorf((v - v0) * s), 0), nb - 1);
+}
+__global__ __launch_bounds__(256) void k_mark_bad(BuildParams b, int majority, BadMap m, unsigned int *__restrict__ overflow) {
+    const int p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= b.n_prims) return;
+    float a[3], bb[3], c[3], d[3];
+    const bool quad = prim_vertices(b, p, a, bb, c, d);
+    if (quad && tri_orient_xy(a, bb, c) == majority && tri_orient_xy(bb, d, c) == majority) return;
+    const float xl = fminf(fminf(a[0], bb[0]), fminf(c[0], d[0])), xh = fmaxf(fmaxf(a[0], bb[0]), fmaxf(c[0], d[0]));
+    const float yl = fminf(fminf(a[1], bb[1]), fminf(c[1], d[1])), yh = fmaxf(fmaxf(a[1], bb[1]), fmaxf(c[1], d[1]));
+    const int i0 = max(bad_cell(xl, m.x0, m.sx, m.nb) - 1, 0), i1 = min(bad_cell(xh, m.x0, m.sx, m.nb) + 1, m.nb - 1);
+    const int j0 = max(bad_cell(yl, m.y0, m.sy, m.nb) - 1, 0), j1 = min(bad_cell(yh, m.y0, m.sy, m.nb) + 1, m.nb - 1);
+    if (i1 - i0 >= HZ_BAD_MAX_SPAN || j1 - j0 >= HZ_BAD_MAX_SPAN) { atomicAdd(overflow, 1u); return; }
+    // TIN triangle: skip bitmap cells that lie strictly on the outer side of one of its edges (with two cells of margin);
+    // a collapsed triangle has no usable edge normals: its whole box is marked
+    float ex[3] = {0, 0, 0}, ey[3] = {0, 0, 0}, ec[3] = {0, 0, 0};
+    bool cull = false;
+    if (!quad) {
+        const int o = tri_orient_xy(a, bb, c);
+        if (o != 0) {
+            const float px[3] = {a[0], bb[0], c[0]}, py[3] = {a[1], bb[1], c[1]};
+            const float wx = 1.0f / m.sx, wy = 1.0f / m.sy;
+            for (int k = 0; k < 3; k++) {
+                const int k1 = (k + 1) % 3;
+                // outward normal of edge k -> k1 (for a counter-clockwise triangle: (dy, -dx)); a point q is outside by
+                // more than the margin when n . (q - p_k) > margin
+                const float dx_ = px[k1] - px[k], dy_ = py[k1] - py[k];
+                ex[k] = (float)o * dy_; ey[k] = -(float)o * dx_;
+                ec[k] = ex[k] * px[k] + ey[k] * py[k] + 3.0f * (__builtin_fabsf(ex[k]) * wx + __builtin_fabsf(ey[k]) * wy);
+            }
+            cull = true;
+        }
+    }
+    for (int j = j0; j <= j1; j++) {
+        const float cy = m.y0 + ((float)j + 0.5f) / m.sy;
+        for (int i = i0; i <= i1; i++) {
+            if (cull) {
+                const float cx = m.x0 + ((float)i + 0.5f) / m.sx;
+                if (ex[0] * cx + ey[0] * cy > ec[0] || ex[1] * cx + ey[1] * cy > ec[1] || ex[2] * cx + ey[2] * cy > ec[2]) continue;
+            }
+            atomicOr(&m.bits[((size_t)j * m.nb + i) >> 5], 1u << (i & 31));
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void k_leaf_boxes(BuildParams b, const uint32_t *__restrict__ vals,
                                                    const int *__restrict__ parent_leaf,
                                                    float4 *__restrict__ leaf_lo, float4 *__restrict__ leaf_hi,
@@ -198,20 +265,11 @@ __global__ __launch_bounds__(256) void k_leaf_boxes(BuildParams b, const uint32_
     float a[3] = {0, 0, 0}, bb[3] = {0, 0, 0}, c[3] = {0, 0, 0}, d[3] = {0, 0, 0};
     const bool quad = have && prim_vertices(b, (int)vals[s], a, bb, c, d);
     {   // height-field check (HZ_BLOB_HEIGHT_FIELD): orientation of the two DEM triangles (a, b, c) / (b, d, c) in the
-        // world (x, y) plane; orient[0] counter-clockwise, [1] clockwise, [2] (nearly) vertical: |n_z| <= 1e-3 |n|
+        // world (x, y) plane; orient[0] counter-clockwise, [1] clockwise, [2] degenerate projection (tri_orient_xy)
         unsigned pos = 0, neg = 0, deg = 0;
         if (quad) {
-            auto classify = [&](const float (&p0)[3], const float (&p1)[3], const float (&p2)[3]) {
-                const float ux = p1[0] - p0[0], uy = p1[1] - p0[1], uz = p1[2] - p0[2];
-                const float vx = p2[0] - p0[0], vy = p2[1] - p0[1], vz = p2[2] - p0[2];
-                const float nx = uy * vz - uz * vy, ny = uz * vx - ux * vz, nz = ux * vy - uy * vx;
-                const float n2 = (nx * nx + ny * ny) + nz * nz;
-                if (!(nz * nz > 1.0e-6f * n2)) deg++;
-                else if (nz > 0.0f) pos++;
-                else neg++;
-            };
-            classify(a, bb, c);
-            classify(bb, d, c);
+            const int o0 = tri_orient_xy(a, bb, c), o1 = tri_orient_xy(bb, d, c);
+            pos = (o0 > 0) + (o1 > 0); neg = (o0 < 0) + (o1 < 0); deg = (o0 == 0) + (o1 == 0);
         }
         for (int off = 32; off > 0; off >>= 1) { pos += __shfl_xor(pos, off); neg += __shfl_xor(neg, off); deg += __shfl_xor(deg, off); }
         if ((threadIdx.x & 63) == 0) {
@@ -534,7 +592,7 @@ __global__ __launch_bounds__(256) void k_bfs_emit(BfsEmit e, BuildParams b) {
     const int pos = blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= e.cnt) return;
     const int v = e.frontier[pos];
-    if (v == -1) return;                                  // unused slot of a block (zero-filled, never referenced)
+    if (v == -1) return;                                  // unused slot of a block (a dead node: k_fill_dead_nodes)
     const int self = e.level_start + pos;
     if (v <= -2) {                                        // wrapper node (header written by its parent): its one leaf
         const int lb = e.leaf_blocks_before + (int)e.scan_leaf[pos];
@@ -579,6 +637,24 @@ __global__ __launch_bounds__(256) void k_bfs_emit(BfsEmit e, BuildParams b) {
         }
     }
     e.nodes[self] = n;
+}
+
+// Unused node slots (the three spare slots of the root's block, absent children of node blocks) are never the target of
+// a link whose box can be hit -- the parent marks an absent child with an inverted z pair.  The box test has a relative
+// slack (tmin <= tmax * (1 + 1e-6)), though, so for a ray that starts several scene diagonals outside the scene
+// (hz_horizon_locations accepts any coordinates) an inverted pair of a very flat node CAN pass.  Round 4 left these slots
+// zero: a zero node is a point box at the scene centre whose children are block 0 -- the root -- so a ray through that
+// point would walk the tree again and again.  Every slot now starts as a DEAD node: all ranges inverted by 255 steps of
+// 1 m on every axis (passes only for |t| > 2.5e8) and a link to leaf block 0 -- real triangles, tested with the real test:
+// harmless for any-hit and closest-hit alike.  The breadth-first pass overwrites the slots that are in use.
+__global__ __launch_bounds__(256) void k_fill_dead_nodes(Node *__restrict__ nodes, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Node d;
+    d.org[0] = __uint_as_float(127u); d.org[1] = 0.0f; d.org[2] = __uint_as_float(127u);    // steps 2^0 in the low bits
+    d.first = (int)HZ_LEAF_BIT;
+    d.qx = d.qy = d.qz[0] = d.qz[1] = HZ_PAIR_EMPTY | (HZ_PAIR_EMPTY << 16);
+    nodes[i] = d;
 }
 
 // hit-cache ancestors: for every leaf slot the node `levels` levels above it (the leaf block's parent counts as 1)
@@ -804,13 +880,17 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
             return set_error(HZ_ERR_DEPTH, "BVH refit did not converge (%zu of %d nodes)", finished, n_bin);
     }
 
-    {   // height field over the world (x, y) plane?  (hz_common.h: HZ_BLOB_HEIGHT_FIELD)
+    int majority = 1;
+    bool want_bad_map = false;
+    {   // height field over the world (x, y) plane?  (hz_common.h: HZ_BLOB_HEIGHT_FIELD / HZ_BLOB_BAD_MAP)
         unsigned int oc[3] = {0, 0, 0};
         HZ_HIP(hipMemcpyAsync(oc, orient, sizeof(oc), hipMemcpyDeviceToHost, st));
         HZ_HIP(hipStreamSynchronize(st));
         const unsigned int minority = std::min(oc[0], oc[1]);
+        majority = (oc[0] >= oc[1]) ? 1 : -1;
         h.n_flipped = minority + oc[2];
-        h.flags = (h.n_flipped == 0 && n_quads > 0) ? HZ_BLOB_HEIGHT_FIELD : 0u;
+        h.flags = (h.n_flipped == 0 && n_quads > 0 && n_tin == 0) ? HZ_BLOB_HEIGHT_FIELD : 0u;
+        want_bad_map = h.flags == 0u && n_quads > 0;
     }
 
     // ---- 6. which binary nodes open a 4-wide node; compact indices ------------------------
@@ -875,6 +955,17 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     h.off_anc = align_up(h.off_prims + n_prim_slots * sizeof(Prim), 256);
     h.anc_levels = HZ_ANC_LEVELS;
     h.total_bytes = align_up(h.off_anc + n_prim_slots * 4, 256);
+    if (want_bad_map) {
+        // bitmap cells of about two DEM cells: a bad quad then costs the certificates of a handful of cells around it
+        int nb = 8;
+        while (nb < 2048 && 2 * nb < std::max(d0, d1)) nb *= 2;
+        h.bad_nb = nb;
+        h.bad_x0 = lo[0]; h.bad_y0 = lo[1];
+        h.bad_sx = (hi[0] > lo[0]) ? (float)nb / (hi[0] - lo[0]) : 0.0f;
+        h.bad_sy = (hi[1] > lo[1]) ? (float)nb / (hi[1] - lo[1]) : 0.0f;
+        h.off_bad = h.total_bytes;
+        h.total_bytes = align_up(h.off_bad + (size_t)nb * nb / 8, 256);
+    }
     HZ_HIP(hipMalloc(&sc->blob, h.total_bytes));
     sc->owns_blob = true;
     sc->blob_bytes = h.total_bytes;
@@ -884,8 +975,22 @@ int scene_build(Scene *sc, const float *vert_grid, int d0, int d1,
     Prim *d_prims = (Prim *)(blob + h.off_prims);
     int *d_anc = (int *)(blob + h.off_anc);
     HZ_HIP(hipMemcpyAsync(d_verts, d_verts_src, nvert * 12, hipMemcpyDeviceToDevice, st));
-    // unused slots of partly filled blocks stay zero (never referenced: their boxes cannot be hit)
+    // unused leaf slots stay zero (a collapsed triangle: den = 0, never a hit); unused node slots: k_fill_dead_nodes
     HZ_HIP(hipMemsetAsync(blob + h.off_nodes, 0, h.total_bytes - h.off_nodes, st));
+    hipLaunchKernelGGL(k_fill_dead_nodes, dim3((unsigned)((n_nodes + 255) / 256)), dim3(256), 0, st, d_nodes, n_nodes);
+    if (want_bad_map && h.bad_sx > 0.0f && h.bad_sy > 0.0f) {
+        TempBuf b_ovf;
+        HZ_HIP(b_ovf.alloc(16));
+        HZ_HIP(hipMemsetAsync(b_ovf.p, 0, 4, st));
+        BadMap bm;
+        bm.bits = (uint32_t *)(blob + h.off_bad); bm.nb = h.bad_nb;
+        bm.x0 = h.bad_x0; bm.y0 = h.bad_y0; bm.sx = h.bad_sx; bm.sy = h.bad_sy;
+        hipLaunchKernelGGL(k_mark_bad, dim3(gp), dim3(256), 0, st, bp, majority, bm, (unsigned int *)b_ovf.p);
+        unsigned int ovf = 0;
+        HZ_HIP(hipMemcpyAsync(&ovf, b_ovf.p, 4, hipMemcpyDeviceToHost, st));
+        HZ_HIP(hipStreamSynchronize(st));
+        if (ovf == 0) h.flags |= HZ_BLOB_BAD_MAP;
+    }
 
     // ---- 8. breadth-first numbering, level by level ---------------------------------------------------------
     TempBuf b_fr0, b_fr1, b_need_n, b_need_l, b_scan_n, b_scan_l, b_scan_tmp, b_parent, b_lparent;

@@ -241,9 +241,12 @@ def gather_rows(local, slabs, dst=0, group=None):
     local = _host_staged(local, group).contiguous()
     if local.shape[0] != slabs[rank][1] - slabs[rank][0]:
         raise ValueError("rank %d holds %d rows, its slab has %d" % (rank, local.shape[0], slabs[rank][1] - slabs[rank][0]))
+    # `dst` and the slab index r are ranks OF THE GROUP; torch's point-to-point calls take GLOBAL ranks
+    def glob(r):
+        return r if group is None else dist.get_global_rank(group, r)
     if rank != dst:
         if local.shape[0] > 0:
-            dist.send(local, dst=dst, group=group)
+            dist.send(local, dst=glob(dst), group=group)
         return None
     parts = []
     for r in range(world):
@@ -252,7 +255,7 @@ def gather_rows(local, slabs, dst=0, group=None):
             parts.append(local)
         elif rows > 0:
             buf = torch.empty((rows,) + tail, dtype=local.dtype, device=local.device)
-            dist.recv(buf, src=r, group=group)
+            dist.recv(buf, src=glob(r), group=group)
             parts.append(buf)
     return torch.cat(parts, dim=0).to(dev)
 

@@ -88,6 +88,46 @@ def test_sharded_equals_unsharded_gloo():
     assert len(t_ranks) == 2 and all(t > 0 for t in t_ranks) and 1.0 <= imbalance <= 2.0
 
 
+def _subgroup_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from horayzon_amd.dist import gather_rows
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        grp = dist.new_group([1, 2])                    # every rank calls new_group; ranks 1 and 2 are its members
+        if rank in (1, 2):
+            gr = dist.get_rank(grp)                     # 0 / 1 inside the group = global 1 / 2
+            slabs = [(0, 3), (3, 5)]
+            local = torch.full((slabs[gr][1] - slabs[gr][0], 4), float(10 + gr))
+            full = gather_rows(local, slabs, dst=0, group=grp)
+            if gr == 0:
+                q.put(("ok", full.tolist()))
+            else:
+                assert full is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_rows_on_a_sub_group():
+    """gather_rows addresses its peers by rank OF THE GROUP; torch's send / recv take global ranks: on a group
+    that is not the world -- ranks 1 and 2 of three -- the rows must still arrive at the group's rank 0."""
+    pytest.importorskip("torch")
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_subgroup_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    tag, full = q.get(timeout=10)
+    assert tag == "ok" and full == [[10.0] * 4] * 3 + [[11.0] * 4] * 2
+
+
 def test_cost_balanced_slabs():
     from horayzon_amd.dist import row_slabs, estimate_row_cost, predicted_imbalance, sample_rows
     cost = np.concatenate([np.ones(60), 4.0 * np.ones(40)])         # the last 40 rows cost four times as much

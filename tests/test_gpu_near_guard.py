@@ -1,7 +1,9 @@
 """The near-field certificates (hz_near.hip) assume that the DEM mesh is a height field over the WORLD (x, y) plane;
-the reference accepts any vertex buffer (horizon_comp.cpp:126-127).  The scene build checks the assumption
-(HZ_BLOB_HEIGHT_FIELD: every DEM triangle projects onto (x, y) with the same orientation and |n_z| > 1e-3 |n|) and the
-certificates are only used when it holds.  These tests feed meshes that violate it."""
+the reference accepts any vertex buffer (horizon_comp.cpp:126-127).  The scene build checks the assumption per triangle
+(HZ_BLOB_HEIGHT_FIELD: every DEM triangle projects onto (x, y) with the same orientation and a 2-D area above its own
+rounding -- steepness does not matter).  Where some quads violate it (or an outer TIN is present) their (x, y) footprints
+are marked in a coarse bitmap (HZ_BLOB_BAD_MAP) and only the cells near them lose their certificates (round 5; rounds
+3-4 switched the whole scene off).  These tests feed meshes that violate the assumption."""
 import numpy as np
 import pytest
 
@@ -27,19 +29,23 @@ def _rotated_hill(angle_deg):
     return kw
 
 
-def test_rotated_frame_is_not_a_height_field_and_certificates_stay_off(hip, orc):
+def test_rotated_frame_is_not_a_height_field_and_certificates_are_per_cell(hip, orc):
     kw = _rotated_hill(80.0)
     par = dict(dist_search=10.0, azim_num=36)
-    h, _ = hip.horizon.horizon_gridded(**kw, **par, count_work=True)
+    h, _ = hip.horizon.horizon_gridded(**kw, **par, count_work=True, _verify_near=1)
     st = dict(hip.horizon.last_stats)
-    assert st["height_field"] == 0 and st["near_used"] == 0 and st["rays_shortened"] == 0
+    # the slopes that face away from the world z axis project flipped: not a height field; the cells near those quads run
+    # without certificates, the others keep them -- and every shortened ray, traced again over its full length, agrees
+    assert st["height_field"] == 0 and st["near_used"] == 1
+    assert st["near_violations"] == 0 and st["near_verified"] == st["rays_shortened"]
     ref, _, so = orc.horizon_gridded(**kw, **par, return_stats=True)
-    assert np.array_equal(h, ref) and st["num_rays"] == so["rays"]
+    assert np.array_equal(h, ref) and st["num_rays"] == so["rays"] and st["guard_events"] == so["guards"]
     # the same hill unrotated is a height field: certificates on, many rays shortened
     g = cases.c2_hill()
     h0, _ = hip.horizon.horizon_gridded(**cases.grid_kwargs(g), **par, count_work=True)
     st0 = dict(hip.horizon.last_stats)
     assert st0["height_field"] == 1 and st0["near_used"] == 1 and st0["rays_shortened"] > 0.3 * st0["num_rays"]
+    assert st["rays_shortened"] < st0["rays_shortened"]
     # and both describe the same terrain: different float roundings of the rotated coordinates move a few grazing
     # rays, i.e. a result by one search step (10 table entries = 0.5 deg) at most
     d = np.abs(h - h0)
@@ -65,19 +71,85 @@ def _folded_sheet(n=64, dx=50.0, gap=3.0):
                 vec_north=vec_north, offset_0=off, offset_1=off)
 
 
-def test_folded_mesh_certificates_would_drop_hits_and_are_switched_off(hip, orc):
+def test_folded_mesh_certificates_would_drop_hits_and_are_refused(hip, orc):
     kw = _folded_sheet()
     par = dict(dist_search=2.0, azim_num=24, hori_acc=1.0, elev_ang_low_lim=-60.0)
     ref, _, so = orc.horizon_gridded(**kw, **par, return_stats=True)
     h, _ = hip.horizon.horizon_gridded(**kw, **par, count_work=True, _verify_near=True)
     st = dict(hip.horizon.last_stats)
-    assert st["height_field"] == 0 and st["near_used"] == 0
+    # one of the two sheets projects against the other: its quads cover the whole (x, y) footprint of the mesh in the
+    # scene's bad-quad bitmap, so EVERY cell is refused its certificate
+    assert st["height_field"] == 0 and st["rays_shortened"] == 0
     assert np.array_equal(h, ref) and st["num_rays"] == so["rays"] and st["near_violations"] == 0
     # with the guard overridden the certificates shorten rays that the upper sheet blocks right above the origin:
     # the full-length re-trace of those rays disagrees (this is the failure the guard prevents)
     hip.horizon.horizon_gridded(**kw, **par, count_work=True, _verify_near=True, _near_skip="force")
     forced = dict(hip.horizon.last_stats)
     assert forced["near_used"] == 1 and forced["near_violations"] > 0
+
+
+def _tile_with_defects(n=3601):
+    """The config-3 tile with what real DEMs bring along: 20 rectangular blocks raised or lowered by 0.3 ... 30 km (vertical
+    steps along their rims; slopes of up to 1400 : 1), a 40 x 40 NoData hole at -32768 m, and five vertices whose (x, y)
+    is displaced by 1.5 cells, so that the quads around them fold over their neighbours (triangles that project flipped)."""
+    g = synth.fractal_tile(n=n, offset=16)
+    rng = np.random.default_rng(505)
+    z = g["z"].copy()
+    steps = []
+    for k in range(20):
+        i0, j0 = int(rng.integers(100, n - 300)), int(rng.integers(100, n - 300))
+        h, w = int(rng.integers(3, 120)), int(rng.integers(3, 120))
+        dz = float(rng.choice([300.0, -300.0, 1000.0, 3000.0, 30000.0]))
+        z[i0:i0 + h, j0:j0 + w] += np.float32(dz)
+        steps.append((i0, j0, h, w, dz))
+    hole = (1200, 2400, 40, 40)
+    z[hole[0]:hole[0] + 40, hole[1]:hole[1] + 40] = np.float32(-32768.0)
+    xx, yy = np.meshgrid(g["x"], g["y"])
+    folds = []
+    for k in range(5):
+        i, j = int(rng.integers(200, n - 200)), int(rng.integers(200, n - 200))
+        xx[i, j] += np.float32(1.5 * 21.44); yy[i, j] -= np.float32(1.5 * 30.87)
+        folds.append((i, j))
+    kw = cases.grid_kwargs(g)
+    kw["vert_grid"] = synth.pack_vertices(xx, yy, z)
+    return kw, dict(steps=steps, hole=hole, folds=folds, x=g["x"], y=g["y"], z=z)
+
+
+def test_per_cell_guard_on_the_c3_tile_with_steps_a_nodata_hole_and_folds(hip, orc):
+    """one near-vertical or flipped triangle used to switch the certificates off for all 12.7 M cells.
+    Steps and NoData holes on a regular (x, y) grid ARE a height field (only the projection counts); the folded quads are
+    not, and cost the certificates of the cells around them only."""
+    kw, info = _tile_with_defects()
+    in0 = in1 = 3569
+    sc = hip.Scene.create(kw["vert_grid"], 3601, 3601)
+    assert sc.vertices()[3] is False                      # the five folds
+    vec_tilt = np.zeros((in0, in1, 3), np.float32); vec_tilt[:, :, 2] = 1.0
+    par = dict(dist_search=50.0, azim_num=360)
+    # the whole tile, every shortened ray traced a second time over its full length
+    out = hip.horizon.horizon_gridded(**kw, **par, scene=sc, svf_vec_tilt=vec_tilt, svf_only=True, count_work=True, _verify_near=1)
+    st = dict(hip.horizon.last_stats)
+    assert st["near_used"] == 1 and st["height_field"] == 0
+    assert st["near_violations"] == 0 and st["near_verified"] == st["rays_shortened"]
+    assert st["rays_shortened"] >= 0.78 * st["num_rays"], st["rays_shortened"] / st["num_rays"]
+    # bands through the defects: a fold, the rim of the NoData hole, the rim of a 30 km and of a 300 m step
+    big = [s_ for s_ in info["steps"] if abs(s_[4]) == 30000.0][0]
+    small = [s_ for s_ in info["steps"] if abs(s_[4]) == 300.0][0]
+    bands = [info["folds"][0][0] - 16 - 1, info["hole"][0] - 16 - 1, big[0] - 16 - 1, small[0] + small[2] - 16 - 1]
+    for r0 in bands:
+        # (the band as an inner domain of its own: two rows of frames, offset_0 moved -- no 18 GB host array)
+        kb = dict(kw, vec_norm=np.ascontiguousarray(kw["vec_norm"][r0:r0 + 2]), vec_north=np.ascontiguousarray(kw["vec_north"][r0:r0 + 2]),
+                  offset_0=16 + r0)
+        h, _ = hip.horizon.horizon_gridded(**kb, **par, scene=sc, count_work=True, _verify_near=1)
+        s = dict(hip.horizon.last_stats)
+        ref, _, so = orc.horizon_gridded(**kb, **par, return_stats=True)
+        assert np.array_equal(h, ref), r0
+        assert (s["num_rays"], s["guard_events"]) == (so["rays"], so["guards"]) and s["near_violations"] == 0, r0
+        assert s["near_used"] == 1 and s["rays_shortened"] > 0
+    # without the folds the same tile is a height field again, whatever the steps' slopes
+    kw2 = dict(kw)
+    xx, yy = np.meshgrid(info["x"], info["y"])
+    kw2["vert_grid"] = synth.pack_vertices(xx, yy, info["z"])
+    assert hip.Scene.create(kw2["vert_grid"], 3601, 3601).vertices()[3] is True
 
 
 def test_scene_reports_height_field(hip):
