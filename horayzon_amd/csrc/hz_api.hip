@@ -207,6 +207,7 @@ struct Terrain {
     bool owns_scene = false;
     int offset_0 = 0, offset_1 = 0, dim_in_0 = 0, dim_in_1 = 0;
     void *tilt = nullptr, *norm = nullptr, *enl = nullptr, *elev = nullptr, *mask = nullptr;
+    double *refrac_fac = nullptr;             // refrac_cor: per cell the pressure / temperature factor of the refraction formula (hz_shadow.hip)
     bool own_tilt = false, own_norm = false, own_enl = false, own_elev = false, own_mask = false;
     float fill = 0, ang_max = 89.0f;
     int refrac = 0;
@@ -225,6 +226,7 @@ static void terrain_release_arrays(Terrain *t) {
     if (t->own_enl && t->enl) (void)hipFree(t->enl);
     if (t->own_elev && t->elev) (void)hipFree(t->elev);
     if (t->own_mask && t->mask) (void)hipFree(t->mask);
+    if (t->refrac_fac) { (void)hipFree(t->refrac_fac); t->refrac_fac = nullptr; }
     t->tilt = t->norm = t->enl = t->elev = t->mask = nullptr;
     t->own_tilt = t->own_norm = t->own_enl = t->own_elev = t->own_mask = false;
     // the counters live on the terrain's current GPU; a re-initialisation may move the terrain to another one
@@ -1398,6 +1400,12 @@ static int terrain_init_common(Terrain *t, int offset_0, int offset_1, const flo
     if ((rc = persist(elevation, nc * 4, st, &t->elev, &t->own_elev))) return rc;
     if ((rc = persist(mask, nc, st, &t->mask, &t->own_mask))) return rc;
     if (!t->counters) HZ_HIP(hipMalloc((void **)&t->counters, 16 * sizeof(unsigned long long)));
+    if (refrac_cor) {
+        // what the refraction formula needs from the cell's elevation alone -- temperature, pressure (a powf), two float64
+        // divisions -- is the same for every sun position: formed once here (shadow_comp.cpp:438-441, :151-157)
+        HZ_HIP(hipMalloc((void **)&t->refrac_fac, nc * sizeof(double)));
+        if ((rc = shadow_refrac_factor((const float *)t->elev, nc, t->refrac_fac, st))) return rc;
+    }
     HZ_HIP(hipStreamSynchronize(st));
     t->offset_0 = offset_0; t->offset_1 = offset_1; t->dim_in_0 = dim_in_0; t->dim_in_1 = dim_in_1;
     t->fill = sw_dir_cor_fill; t->ang_max = ang_max; t->refrac = refrac_cor ? 1 : 0;
@@ -1470,7 +1478,7 @@ static int terrain_run(Terrain *t, const float *sun_positions, int num_sun, int 
     a.offset_0 = t->offset_0; a.offset_1 = t->offset_1; a.dim_in_0 = t->dim_in_0; a.dim_in_1 = t->dim_in_1;
     a.sw_dir_cor_fill = t->fill;
     a.dot_prod_min = cosf(deg2rad_f(t->ang_max));            // shadow_comp.cpp:498
-    a.refrac_cor = t->refrac; a.which = which; a.top_nodes = -1; a.counters = t->counters;
+    a.refrac_cor = t->refrac; a.refrac_fac = t->refrac_fac; a.which = which; a.top_nodes = -1; a.counters = t->counters;
     a.count_work = t->count_work;
     float ms = 0.0f;
     unsigned long long cnt[16];

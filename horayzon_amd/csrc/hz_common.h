@@ -134,6 +134,13 @@ __device__ __forceinline__ bool hz_tile_of_block(const TileMap &m, int b, int *t
 
 #ifdef __HIPCC__
 
+// "den != 0" of the triangle test with the rounding of den taken into account (round 5): a ray
+// within 2^-20 (relative to |nx dx| + |ny dy| + |nz dz|) of a triangle's plane counts as parallel to it.  With a den that is
+// rounding noise all three edge functions are noise too (coplanar lines meet somewhere), so the exact `den != 0` of rounds 1-4
+// accepted "hits at t = 0" of triangles the ray passes kilometres beside whenever the origin lay in their plane as well
+// (integer terrace heights with an integer ray_org_elev) -- hits that depend on which boxes a traversal happens to open.
+#define HZ_DEN_NOISE 9.5367431640625e-07f      // 2^-20
+
 // ---------------------------------------------------------------------------
 // ray / triangle: Embree-robust style Pluecker edge test in float32.
 // This translation unit is compiled with -ffp-contract=off: every multiply
@@ -174,9 +181,10 @@ __device__ __forceinline__ bool hz_tri_hit(float ox, float oy, float oz,
     const float nx = e1y * e0z - e1z * e0y;
     const float ny = e1z * e0x - e1x * e0z;
     const float nz = e1x * e0y - e1y * e0x;
-    const float den = (nx * dx + ny * dy) + nz * dz;
+    const float pnx = nx * dx, pny = ny * dy, pnz = nz * dz;
+    const float den = (pnx + pny) + pnz;
     const float T = (v0x * nx + v0y * ny) + v0z * nz;
-    if (den == 0.0f) return false;
+    if (!(__builtin_fabsf(den) > HZ_DEN_NOISE * ((__builtin_fabsf(pnx) + __builtin_fabsf(pny)) + __builtin_fabsf(pnz)))) return false;   // (parallel within rounding)
     const float Ts = (den < 0.0f) ? -T : T;
     const float ad = __builtin_fabsf(den);
     if (!(Ts >= 0.0f)) return false;
@@ -215,10 +223,13 @@ __device__ __forceinline__ bool hz_quad_hit(float ox, float oy, float oz, float 
         const float mn = __builtin_fminf(U, __builtin_fminf(V, W));
         const float mx = __builtin_fmaxf(U, __builtin_fmaxf(V, W));
         const float nx = e1y * e0z - e1z * e0y, ny = e1z * e0x - e1x * e0z, nz = e1x * e0y - e1y * e0x;
-        const float den = (nx * dx + ny * dy) + nz * dz;
+        const float pnx = nx * dx, pny = ny * dy, pnz = nz * dz;
+        const float den = (pnx + pny) + pnz;
         const float T = (v0x * nx + v0y * ny) + v0z * nz;
         const float Ts = (den < 0.0f) ? -T : T;
-        hit0 = ((mn >= -eps) | (mx <= eps)) & (den != 0.0f) & (Ts >= 0.0f) & (Ts <= tfar * __builtin_fabsf(den));
+        const float ad = __builtin_fabsf(den);
+        hit0 = ((mn >= -eps) | (mx <= eps)) & (ad > HZ_DEN_NOISE * ((__builtin_fabsf(pnx) + __builtin_fabsf(pny)) + __builtin_fabsf(pnz))) &
+               (Ts >= 0.0f) & (Ts <= tfar * ad);
     }
     // triangle (b, d, c): v0' = b, v1' = d, v2' = c
     const float w1x = qx - ox, w1y = qy - oy, w1z = qz - oz;      // d
@@ -235,11 +246,14 @@ __device__ __forceinline__ bool hz_quad_hit(float ox, float oy, float oz, float 
     const float mn = __builtin_fminf(U1, __builtin_fminf(V1, W1));
     const float mx = __builtin_fmaxf(U1, __builtin_fmaxf(V1, W1));
     const float nx = f1y * f0z - f1z * f0y, ny = f1z * f0x - f1x * f0z, nz = f1x * f0y - f1y * f0x;
-    const float den = (nx * dx + ny * dy) + nz * dz;
+    const float pnx = nx * dx, pny = ny * dy, pnz = nz * dz;
+    const float den = (pnx + pny) + pnz;
     const float T = (v1x * nx + v1y * ny) + v1z * nz;
     const float Ts = (den < 0.0f) ? -T : T;
+    const float ad = __builtin_fabsf(den);
     // (a TIN triangle's record holds NaNs in d: every comparison below is false for it, `second` only states it)
-    const bool hit1 = second & ((mn >= -eps) | (mx <= eps)) & (den != 0.0f) & (Ts >= 0.0f) & (Ts <= tfar * __builtin_fabsf(den));
+    const bool hit1 = second & ((mn >= -eps) | (mx <= eps)) & (ad > HZ_DEN_NOISE * ((__builtin_fabsf(pnx) + __builtin_fabsf(pny)) + __builtin_fabsf(pnz))) &
+                      (Ts >= 0.0f) & (Ts <= tfar * ad);
     return hit0 | hit1;
 }
 
@@ -382,6 +396,37 @@ __device__ __forceinline__ void hz_node_hits(const NodeRay &n, const RayBox &r, 
     HZ_CHILD(pz3, cx1, gx1, ny1, fy1, h3);
 #undef HZ_CHILD
 #undef HZ_SLACK
+}
+
+// The same test with the four results as lane MASKS (all ones: the child box is hit; zero: it is not) formed from the SIGN of
+// tmin - tmax * slack, for the fast stack discipline: a compare plus the selects that consume it are slow-class VALU
+// instructions (v_cmp_le_f32 4.2 cycles, v_cndmask_b32 with a scalar mask 4.1: profiles/r04/inst_rates.json), a fused
+// multiply-add, an arithmetic shift and a logic operation fast-class ones (2.3 - 2.5).  One rounding instead of two, and a
+// box whose interval has shrunk to exactly a point (tmin == tmax * slack) now counts as missed: both are far inside the slack.
+__device__ __forceinline__ void hz_node_hit_masks(const NodeRay &n, const RayBox &r, float tfar, const uint4 &q,
+                                                  int &m0, int &m1, int &m2, int &m3) {
+    const uint32_t px0 = __builtin_amdgcn_perm(HZ_HALF_MAGIC, q.x, r.sel_x), px1 = __builtin_amdgcn_perm(HZ_HALF_MAGIC, q.x, r.sel_x + HZ_SEL_PAIR1);
+    const uint32_t py0 = __builtin_amdgcn_perm(HZ_HALF_MAGIC, q.y, r.sel_y), py1 = __builtin_amdgcn_perm(HZ_HALF_MAGIC, q.y, r.sel_y + HZ_SEL_PAIR1);
+    const uint32_t pz0 = __builtin_amdgcn_perm(HZ_HALF_MAGIC, q.z, r.sel_z), pz1 = __builtin_amdgcn_perm(HZ_HALF_MAGIC, q.z, r.sel_z + HZ_SEL_PAIR1);
+    const uint32_t pz2 = __builtin_amdgcn_perm(HZ_HALF_MAGIC, q.w, r.sel_z), pz3 = __builtin_amdgcn_perm(HZ_HALF_MAGIC, q.w, r.sel_z + HZ_SEL_PAIR1);
+    const float nx0 = hz_fma_mix_lo(px0, n.ax, n.bx), fx0 = hz_fma_mix_hi(px0, n.ax, n.bx);
+    const float nx1 = hz_fma_mix_lo(px1, n.ax, n.bx), fx1 = hz_fma_mix_hi(px1, n.ax, n.bx);
+    const float ny0 = hz_fma_mix_lo(py0, n.ay, n.by), fy0 = hz_fma_mix_hi(py0, n.ay, n.by);
+    const float ny1 = hz_fma_mix_lo(py1, n.ay, n.by), fy1 = hz_fma_mix_hi(py1, n.ay, n.by);
+    const float cx0 = __builtin_fmaxf(nx0, 0.0f), cx1 = __builtin_fmaxf(nx1, 0.0f);
+    const float gx0 = __builtin_fminf(fx0, tfar), gx1 = __builtin_fminf(fx1, tfar);
+#define HZ_CHILD_M(pz, nx, fx, ny, fy, out) do { \
+        const float nz_ = hz_fma_mix_lo(pz, n.az, n.bz), fz_ = hz_fma_mix_hi(pz, n.az, n.bz); \
+        const float tmin_ = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz_); \
+        const float tmax_ = __builtin_fminf(__builtin_fminf(fx, fy), fz_); \
+        out = __float_as_int(__builtin_fmaf(tmax_, -1.000001f, tmin_)) >> 31; \
+        asm volatile("" : "+v"(out));     /* (the compiler must not know that this is 0 / -1: it would turn every use back into a compare + select) */ \
+        } while (0)
+    HZ_CHILD_M(pz0, cx0, gx0, ny0, fy0, m0);      // slot k: column half k & 1, row half k >> 1
+    HZ_CHILD_M(pz1, cx1, gx1, ny0, fy0, m1);
+    HZ_CHILD_M(pz2, cx0, gx0, ny1, fy1, m2);
+    HZ_CHILD_M(pz3, cx1, gx1, ny1, fy1, m3);
+#undef HZ_CHILD_M
 }
 
 // One 32 B node = 2 x 16 B global loads issued back to back and waited for once.
@@ -578,13 +623,17 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
             const int t1 = HZ_STACK_AT(sa);
 #else
             hz_int2 t10;
-            asm volatile("ds_read2st64_b32 %0, %1 offset1:4\n\ts_waitcnt lgkmcnt(0)" : "=v"(t10) : "v"(sa) : "memory");
+            // (second element = one stack row above: TPB * 4 bytes = TPB / 64 units of 64 dwords)
+            asm volatile("ds_read2st64_b32 %0, %1 offset1:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(t10) : "v"(sa), "n"(TPB / 64) : "memory");
             int t0 = t10.y;
             const int t1 = t10.x;
 #endif
             // "node is a leaf link (negative) and the place is free (HZ_EMPTY: positive)" as ONE vector compare of
             // node & ~place: scalar logic on two compare results waits for both (round 4: a scalar instruction that
             // consumes a vector compare costs about 1 % of the kernel, profiles/r04/ab_scalar_mask_logic.log)
+            // (round 5: the sign of node & ~place is smeared into a lane mask and the moves are bit selects -- v_ashrrev_i32 +
+            //  v_bitop3_b32, fast-class instructions, instead of a compare and v_cndmask_b32s, slow-class ones)
+#ifdef HZ_V_CMP_NODE_STEP
             int m1 = node & ~lq0;
             asm volatile("" : "+v"(m1));
             const bool c1 = m1 < 0;
@@ -593,6 +642,16 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
             asm volatile("" : "+v"(m2));
             const bool c2 = m2 < 0;
             lq1 = c2 ? node : lq1; node = c2 ? t0 : node; sa -= c2 ? (unsigned)(TPB * 4) : 0u;
+#else
+#define HZ_SELM(m, x, y) (((m) & (x)) | (~(m) & (y)))
+            int m1 = (node & ~lq0) >> 31;
+            asm volatile("" : "+v"(m1));          // (the compiler must not know that this is 0 / -1)
+            lq0 = HZ_SELM(m1, node, lq0); node = HZ_SELM(m1, t0, node); t0 = HZ_SELM(m1, t1, t0); sa -= (unsigned)m1 & (unsigned)(TPB * 4);
+            int m2 = (node & ~lq1) >> 31;
+            asm volatile("" : "+v"(m2));
+            lq1 = HZ_SELM(m2, node, lq1); node = HZ_SELM(m2, t0, node); sa -= (unsigned)m2 & (unsigned)(TPB * 4);
+#undef HZ_SELM
+#endif
         }
         can_node = HZ_IS_NODE(node);
         can_leaf = lq0 < 0;
@@ -621,11 +680,11 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
                 // is blocked over a long stretch behind the first ridge, and near-horizon rays that only
                 // nick a crest are served by the hit cache.  (Rounds 2-3 stored the tallest child first: +1 %; the
                 // quadrant order is what lets x and y share one range per half, i.e. the 32 B node.)
-                bool h0, h1, h2, h3;
-                hz_node_hits(nr, rb, tfar_box, n1, h0, h1, h2, h3);
                 const int first = __float_as_int(n0.w);
                 HZ_PROBE_PADS(n0.x);
                 if (LEVELSTACK) {
+                    bool h0, h1, h2, h3;
+                    hz_node_hits(nr, rb, tfar_box, n1, h0, h1, h2, h3);
                     const int h = (h0 ? 1 : 0) | (h1 ? 2 : 0) | (h2 ? 4 : 0) | (h3 ? 8 : 0);
                     if (h != 0) {                    // the hit children become the pending set of this level ...
                         if (pm != 0) { stack[sp * TPB + tid] = hz_entry_pack(pf, pm); sp++; }
@@ -633,22 +692,32 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
                     }
                     HZ_POP();                        // ... and the first of them (or of a level above) is entered
                 } else {
+#ifdef HZ_V_CMP_NODE_STEP        // the round-4 form (compares + selects), kept for A/Bs
+                    bool h0, h1, h2, h3;
+                    hz_node_hits(nr, rb, tfar_box, n1, h0, h1, h2, h3);
+                    const int m0 = h0 ? -1 : 0, m1 = h1 ? -1 : 0, m2 = h2 ? -1 : 0, m3 = h3 ? -1 : 0;
+#else
+                    int m0, m1, m2, m3;              // lane masks: all ones = child hit (hz_node_hit_masks)
+                    hz_node_hit_masks(nr, rb, tfar_box, n1, m0, m1, m2, m3);
+#endif
                     // out of entries: remember the highest pointer (checked once, at the exit) and clamp
                     sa_hi = max(sa_hi, sa);
                     sa = min(sa, sa_cap);
-                    // Pushes without a branch and without scalar logic: the three candidates are always stored above the top
-                    // and only kept (pointer advanced) when they were real links, i.e. when a higher slot was hit too.  The
-                    // hit flags become 0 / one-entry steps in vector registers once (a_k), "a higher slot was hit" is an OR of
-                    // those, "advance" an AND; the lane without a hit child continues with the top entry pv and steps down.
+                    // Pushes without a branch, without scalar logic and (round 5) without compares: the three candidates are
+                    // always stored above the top and only kept (pointer advanced) when they were real links, i.e. when a
+                    // higher slot was hit too.  The hit masks become 0 / one-entry steps (a_k = m_k & S), "a higher slot was
+                    // hit" is an OR of those, "advance" an AND; the link that continues is picked with bit selects (m ? x : y
+                    // = v_bfi_b32); the lane without a hit child continues with the top entry pv and steps down.
                     const unsigned S = (unsigned)(TPB * 4);
                     const int pv = HZ_STACK_AT(sa + S);
-                    unsigned a0 = h0 ? S : 0u, a1 = h1 ? S : 0u, a2 = h2 ? S : 0u, a3 = h3 ? S : 0u;
-                    asm volatile("" : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3));    // (keeps them out of the compiler's mask algebra)
+                    const unsigned a0 = (unsigned)m0 & S, a1 = (unsigned)m1 & S, a2 = (unsigned)m2 & S, a3 = (unsigned)m3 & S;
                     const unsigned o32 = a3 | a2, o321 = o32 | a1, o3210 = o321 | a0;
-                    int next = h3 ? first + 3 : pv;
-                    HZ_STACK_AT(sa + 2u * S) = next; sa += a2 & a3;   next = h2 ? first + 2 : next;
-                    HZ_STACK_AT(sa + 2u * S) = next; sa += a1 & o32;  next = h1 ? first + 1 : next;
-                    HZ_STACK_AT(sa + 2u * S) = next; sa += a0 & o321; next = h0 ? first : next;
+#define HZ_SEL(m, x, y) (((m) & (x)) | (~(m) & (y)))
+                    int next = HZ_SEL(m3, first + 3, pv);
+                    HZ_STACK_AT(sa + 2u * S) = next; sa += a2 & a3;   next = HZ_SEL(m2, first + 2, next);
+                    HZ_STACK_AT(sa + 2u * S) = next; sa += a1 & o32;  next = HZ_SEL(m1, first + 1, next);
+                    HZ_STACK_AT(sa + 2u * S) = next; sa += a0 & o321; next = HZ_SEL(m0, first, next);
+#undef HZ_SEL
                     node = next; sa = sa + o3210 - S;
                 }
                 HZ_PF(node);

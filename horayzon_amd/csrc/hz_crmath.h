@@ -27,33 +27,47 @@
 #define HZ_CRM_LN2_HI 0.6931471803691238       /* ln 2, upper 33 bits           */
 #define HZ_CRM_LN2_LO 1.9082149292705877e-10   /* ln 2 - HZ_CRM_LN2_HI          */
 
-/* sin(r), cos(r) for |r| <= pi/4: Taylor series, 11 / 11 terms (remainder < 2e-18) */
+/* sin(r), cos(r) for |r| <= pi/4.  Round 5 (the refraction branch cost 40 % of a sun position): the
+ * 10-term Taylor series of rounds 2-4 are replaced by
+ *   |r| <= 2^-5 (the rotation angle of the refraction, < 0.015 rad): 5 / 5 Taylor terms, remainder < 1e-23 relative;
+ *   else: the degree-13 / degree-14 minimax polynomials of fdlibm's k_sin.c / k_cos.c (|error| < 2^-58 on [-pi/4, pi/4]).
+ * Both stay far inside the 1e-14 of the contract above. */
 HZ_CRM double hz_crm_sin_k(double r) {
     const double z = r * r;
-    double p = -1.0 / 51090942171709440000.0;                 /* -1/21! */
-    p = p * z + 1.0 / 121645100408832000.0;                    /*  1/19! */
-    p = p * z - 1.0 / 355687428096000.0;                       /* -1/17! */
-    p = p * z + 1.0 / 1307674368000.0;                         /*  1/15! */
-    p = p * z - 1.0 / 6227020800.0;                            /* -1/13! */
-    p = p * z + 1.0 / 39916800.0;                              /*  1/11! */
-    p = p * z - 1.0 / 362880.0;                                /* -1/9!  */
-    p = p * z + 1.0 / 5040.0;                                  /*  1/7!  */
-    p = p * z - 1.0 / 120.0;                                   /* -1/5!  */
-    p = p * z + 1.0 / 6.0;                                     /*  1/3!  */
-    return r - (r * z) * p;
+    double p;
+    if (z <= 0.0009765625) {                                 /* |r| <= 2^-5 */
+        p = -1.0 / 362880.0;                                   /* -1/9!  */
+        p = p * z + 1.0 / 5040.0;                              /*  1/7!  */
+        p = p * z - 1.0 / 120.0;                               /* -1/5!  */
+        p = p * z + 1.0 / 6.0;                                 /*  1/3!  */
+        return r - (r * z) * p;
+    }
+    p = 1.58969099521155010221e-10;
+    p = p * z - 2.50507602534068634195e-08;
+    p = p * z + 2.75573137070700676789e-06;
+    p = p * z - 1.98412698298579493134e-04;
+    p = p * z + 8.33333333332248946124e-03;
+    p = p * z - 1.66666666666666324348e-01;
+    return r + (r * z) * p;
 }
 HZ_CRM double hz_crm_cos_k(double r) {
     const double z = r * r;
-    double p = 1.0 / 2432902008176640000.0;                    /*  1/20! */
-    p = p * z - 1.0 / 6402373705728000.0;                      /* -1/18! */
-    p = p * z + 1.0 / 20922789888000.0;                        /*  1/16! */
-    p = p * z - 1.0 / 87178291200.0;                           /* -1/14! */
-    p = p * z + 1.0 / 479001600.0;                             /*  1/12! */
-    p = p * z - 1.0 / 3628800.0;                               /* -1/10! */
-    p = p * z + 1.0 / 40320.0;                                 /*  1/8!  */
-    p = p * z - 1.0 / 720.0;                                   /* -1/6!  */
-    p = p * z + 1.0 / 24.0;                                    /*  1/4!  */
-    p = p * z - 0.5;                                           /* -1/2!  */
+    double p;
+    if (z <= 0.0009765625) {
+        p = -1.0 / 3628800.0;                                  /* -1/10! */
+        p = p * z + 1.0 / 40320.0;                             /*  1/8!  */
+        p = p * z - 1.0 / 720.0;                               /* -1/6!  */
+        p = p * z + 1.0 / 24.0;                                /*  1/4!  */
+        p = p * z - 0.5;                                       /* -1/2!  */
+        return 1.0 + z * p;
+    }
+    p = -1.13596475577881948265e-11;
+    p = p * z + 2.08757232129817482790e-09;
+    p = p * z - 2.75573143513906633035e-07;
+    p = p * z + 2.48015872894767294178e-05;
+    p = p * z - 1.38888888888741095749e-03;
+    p = p * z + 4.16666666666666019037e-02;
+    p = p * z - 0.5;
     return 1.0 + z * p;
 }
 
@@ -71,17 +85,24 @@ HZ_CRM float hz_crm_tanf(float xf) {
     return (float)(hz_crm_cos_k(r) / hz_crm_sin_k(r));
 }
 
-/* asin(t) for |t| <= 0.5: t + t^3 * sum c_n t^(2n), c_n = (2n+1)!! / ((2n+2)!! (2n+3)); 26 terms, remainder < 1e-17 */
+/* asin(t) for |t| <= 0.5: t + t^3 g(t^2), g = the degree-12 polynomial that interpolates (asin(t) / t - 1) / t^2 at the
+ * Chebyshev nodes of t^2 in [0, 0.25] (computed in 80-bit arithmetic; |asin error| < 3e-16 relative, measured, double
+ * rounding included).  Rounds 2-4 summed 26 Taylor terms. */
 HZ_CRM double hz_crm_asin_k(double t) {
     const double z = t * t;
-    double c[26];
-    double num = 1.0;        /* (2n+1)!! / (2n+2)!! built incrementally */
-    for (int n = 0; n < 26; n++) {
-        num = num * (double)(2 * n + 1) / (double)(2 * n + 2);
-        c[n] = num / (double)(2 * n + 3);
-    }
-    double p = c[25];
-    for (int n = 24; n >= 0; n--) p = p * z + c[n];
+    double p = 0.034553784590501055;
+    p = p * z - 0.02364695072174073;
+    p = p * z + 0.023283466983300003;
+    p = p * z + 0.0031765613418358813;
+    p = p * z + 0.010889791739128478;
+    p = p * z + 0.011384931937545141;
+    p = p * z + 0.013981803080779488;
+    p = p * z + 0.017351599310672417;
+    p = p * z + 0.022372210988752014;
+    p = p * z + 0.030381943060510043;
+    p = p * z + 0.044642857161844712;
+    p = p * z + 0.074999999999905781;
+    p = p * z + 0.16666666666666666;
     return t + (t * z) * p;
 }
 

@@ -25,10 +25,14 @@
 // reproduced exactly (hard part 2); tables are built on the
 // host with the reference's expressions (hz_api.hip) and only read here.
 #include "hz_search.h"
+#include <vector>
 
 namespace hz {
 
-#define HZ_TPB 256
+#ifndef HZ_TPB
+#define HZ_TPB 256    // threads per workgroup: 4 waves = a 16 x 16 tile (64 / 128: probes with 1 / 2 waves per workgroup; the tile stays the unit of the XCD mapping)
+#endif
+#define HZ_WPB (HZ_TPB / 64)
 #ifndef HZ_QLEN
 #define HZ_QLEN 2       // leaves a lane sets aside before it needs a leaf step (3 and 4 measured slower)
 #endif
@@ -64,11 +68,14 @@ struct HorizonParams {
 // (the counting instantiation carries ~20 more live values: at 5 workgroups per CU it spilled 10 - 22 VGPRs, so it is built
 //  for 4.  Its tallies -- rays, node visits, triangle tests, wave iterations -- are functions of the lanes' states only, not
 //  of the schedule, so they are the production launch's numbers: the ray counts of the two instantiations are compared by the tests.)
+#ifdef HZ_WG_TRACE   // measurement probe (scripts/build_variant.sh trace -DHZ_WG_TRACE): start / end of every wave on the 100 MHz clock
+__device__ unsigned long long *hz_wg_trace_buf = nullptr;      // [waves of the launch][2]
+#endif
 template <int ALG, bool COUNT, bool STAGE, bool NODELET, bool LEVELSTACK>
 #ifndef HZ_WG_PER_CU
 #define HZ_WG_PER_CU 5     // resident workgroups per CU the register allocation is held to (6: 80 VGPRs, measured slower)
 #endif
-__global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : HZ_WG_PER_CU) void k_horizon(HorizonParams p) {
+__global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) void k_horizon(HorizonParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef HZ_CODE_SHIFT   // measurement probe: moves everything below by 4 * HZ_CODE_SHIFT bytes (does the position of the traversal loop matter?)
 #pragma unroll
@@ -89,14 +96,23 @@ __global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : HZ_WG_PER_CU) void k_horizon(Ho
     // blocks whose fast stack overflowed -- the block the list names (entry = workgroup number * 4 + quadrant)
     int ti = 0, tj = 0;
     const int wave = tid >> 6, lane = tid & 63;
-    int blk = (int)blockIdx.x * 4 + wave;
+    int blk = (int)blockIdx.x * HZ_WPB + wave;
     if (p.tile_list) blk = (blk < p.n_list) ? p.tile_list[blk] : -1;
+    else if (HZ_WPB != 4) {
+        // fewer than 4 waves per workgroup: the 4 / HZ_WPB workgroups of one tile follow each other ON THE SAME XCD
+        // (workgroup b runs on XCD b % 8), so the tile -> XCD mapping is that of the 4-wave kernel
+        const int b = (int)blockIdx.x, x = b & 7, t = b >> 3, per = 4 / HZ_WPB;
+        blk = (((t / per) * 8 + x) * 4) + (t % per) * HZ_WPB + wave;
+    }
     const bool has_tile = blk >= 0 && hz_tile_of_block(p.tm, blk >> 2, &ti, &tj);
     const int i = p.row_begin + ti * 16 + ((blk >> 1) & 1) * 8 + (lane >> 3);
     const int j = tj * 16 + (blk & 1) * 8 + (lane & 7);
     const bool in_dom = has_tile && (i < p.row_end) && (j < p.dim_in_1);
 
     const Tables &t = p.tb;
+#ifdef HZ_WG_TRACE
+    const unsigned long long trace_t0 = (unsigned long long)wall_clock64();
+#endif
     const unsigned long long t_start = COUNT ? (unsigned long long)wall_clock64() : 0ull;
     const size_t cell = in_dom ? ((size_t)i * p.dim_in_1 + j) : 0;
     bool done = !in_dom;
@@ -253,6 +269,13 @@ __global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : HZ_WG_PER_CU) void k_horizon(Ho
         }
     }
 
+#ifdef HZ_WG_TRACE
+    if (lane == 0 && hz_wg_trace_buf != nullptr && !p.tile_list) {
+        const size_t w = (size_t)blockIdx.x * HZ_WPB + wave;
+        hz_wg_trace_buf[2 * w] = trace_t0;
+        hz_wg_trace_buf[2 * w + 1] = (unsigned long long)wall_clock64() | ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) << 60);
+    }
+#endif
     // one atomic per wave and counter
     unsigned long long r = rays, g = guards, nc = tc.nodes, tcn = tc.tris, cc = cells_cnt;
     unsigned long long wn = tc.w_nodes, wl = tc.w_leaves, wa = w_adv;
@@ -268,7 +291,7 @@ __global__ __launch_bounds__(HZ_TPB, COUNT ? 4 : HZ_WG_PER_CU) void k_horizon(Ho
     if (!LEVELSTACK && __ballot(overflow) != 0ull) {
         if (lane == 0) {
             const unsigned long long slot = atomicAdd(&p.counters[8], 1ull);
-            if (slot < (unsigned long long)HZ_REDO_CAP) p.redo_list[slot] = (int)blockIdx.x * 4 + wave;
+            if (slot < (unsigned long long)HZ_REDO_CAP) p.redo_list[slot] = blk;
         }
         return;
     }
@@ -368,7 +391,7 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
     // (with the opt-in LDS nodelet the fast stack gives up the entries the nodelet's bytes need, so that 5 workgroups stay resident)
     const int want_top = (a.top_nodes > 0 && a.alg == ALG_GUESS && !a.count_work) ? std::min(a.top_nodes, sc->hdr.n_top) : 0;
     // (HZ_LDS_BUDGET: bytes of LDS per workgroup the fast stack may use with staging and nodelet -- experiments with the residency)
-    static const int lds_budget = []() { const char *e = getenv("HZ_LDS_BUDGET"); return e && atoi(e) > 8192 ? atoi(e) : 31 * 1024; }();
+    static const int lds_budget = []() { const char *e = getenv("HZ_LDS_BUDGET"); return (e && atoi(e) > 8192 ? atoi(e) : 31 * 1024) / (4 / HZ_WPB); }();
     // (entry 0 of the fast stack is the sentinel, and a node step wants three free entries above the top: at least 4)
     const int fast_cap = a.level_stack < 0 ? std::max(-a.level_stack, 4)
                                            : std::max((lds_budget - pre - want_top * (int)sizeof(Node)) / (HZ_TPB * 4), 4);
@@ -403,14 +426,44 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
     p.tile_list = a.tile_list; p.n_list = a.n_list;
     p.redo_list = reinterpret_cast<int *>(a.counters + 24);
     const size_t lds = (size_t)p.pre_bytes + (size_t)p.stack_bytes + (size_t)top * sizeof(Node);
-    const int grid = a.tile_list ? (a.n_list + 3) / 4 : p.tm.per_xcd * 8;
+    const int grid = a.tile_list ? (a.n_list + HZ_WPB - 1) / HZ_WPB : p.tm.per_xcd * 8 * (4 / HZ_WPB);
     if (grid <= 0) return HZ_OK;
     const bool count = a.count_work != 0;
-    switch (a.alg) {
-        case ALG_DISCRETE: return launch_alg<ALG_DISCRETE>(p, grid, lds, count, level_stack, st);
-        case ALG_BINARY: return launch_alg<ALG_BINARY>(p, grid, lds, count, level_stack, st);
-        default: return launch_alg<ALG_GUESS>(p, grid, lds, count, level_stack, st);
+#ifdef HZ_WG_TRACE
+    // probe build: every launch is synchronous and appends "start end xcc" lines (10 ns ticks relative to the first start) to $HZ_WG_TRACE_OUT
+    unsigned long long *trace_dev = nullptr;
+    const size_t n_waves = (size_t)grid * HZ_WPB;
+    if (getenv("HZ_WG_TRACE_OUT") && !a.tile_list) {
+        HZ_HIP(hipMalloc((void **)&trace_dev, n_waves * 16));
+        HZ_HIP(hipMemsetAsync(trace_dev, 0, n_waves * 16, st));
+        HZ_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(hz_wg_trace_buf), &trace_dev, sizeof(trace_dev), 0, hipMemcpyHostToDevice, st));
     }
+#endif
+    int rc_launch;
+    switch (a.alg) {
+        case ALG_DISCRETE: rc_launch = launch_alg<ALG_DISCRETE>(p, grid, lds, count, level_stack, st); break;
+        case ALG_BINARY: rc_launch = launch_alg<ALG_BINARY>(p, grid, lds, count, level_stack, st); break;
+        default: rc_launch = launch_alg<ALG_GUESS>(p, grid, lds, count, level_stack, st); break;
+    }
+#ifdef HZ_WG_TRACE
+    if (trace_dev) {
+        std::vector<unsigned long long> h(2 * n_waves);
+        HZ_HIP(hipStreamSynchronize(st));
+        HZ_HIP(hipMemcpy(h.data(), trace_dev, n_waves * 16, hipMemcpyDeviceToHost));
+        unsigned long long *nul = nullptr;
+        HZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(hz_wg_trace_buf), &nul, sizeof(nul)));
+        (void)hipFree(trace_dev);
+        unsigned long long t0 = ~0ull;
+        for (size_t w = 0; w < n_waves; w++) if (h[2 * w]) t0 = std::min(t0, h[2 * w]);
+        if (FILE *f = fopen(getenv("HZ_WG_TRACE_OUT"), "a")) {
+            fprintf(f, "# launch rows %d..%d waves %zu wpb %d\n", a.row_begin, a.row_end, n_waves, HZ_WPB);
+            for (size_t w = 0; w < n_waves; w++)
+                if (h[2 * w]) fprintf(f, "%llu %llu %llu\n", h[2 * w] - t0, (h[2 * w + 1] & 0x0fffffffffffffffull) - t0, h[2 * w + 1] >> 60);
+            fclose(f);
+        }
+    }
+#endif
+    return rc_launch;
 }
 
 // ---------------------------------------------------------------------------------------

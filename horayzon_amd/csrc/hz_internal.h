@@ -179,6 +179,7 @@ struct ShadowArgs {
     int num_sun;                         // positions computed by ONE launch (grid.y); outputs [num_sun][dim_in_0][dim_in_1]
     float sw_dir_cor_fill, dot_prod_min;
     int refrac_cor;
+    const double *refrac_fac;            // refrac_cor: device f64[cells], shadow_refrac_factor()
     int which;                           // 0 shadow (u8), 1 sw_dir_cor (f32)
     uint8_t *out_u8; float *out_f32;
     int top_nodes;
@@ -187,6 +188,7 @@ struct ShadowArgs {
                                          // [3] / [4] wave-level node / leaf steps
 };
 int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st);
+int shadow_refrac_factor(const float *elevation, size_t n, double *out, hipStream_t st);
 
 // hz_sort.hip: hand-written stable LSD radix sort (pairs) and exclusive scan, uint32
 size_t sort_temp_elems(size_t n);

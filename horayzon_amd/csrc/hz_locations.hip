@@ -4,13 +4,22 @@
 // put onto the mesh with a closest-hit query along +normal, then -normal (max 100 km, :951-957);
 // the search then runs exactly as in the gridded case (any-hit), or with closest-hit queries that
 // also return the distance to the horizon (the *_hori_dist variants, :519-612).
-// One lane per location; locations are few, so this kernel shares the traversal code of the
-// gridded path but is not a throughput target.
+// One lane per location.  Round 5: the any-hit searches run like the gridded kernel's -- a lane whose ray is decided takes
+// the next sample of ITS search as soon as fewer than 40 lanes of the wave are still traversing (ray compaction), on the
+// fast stack discipline of hz_trace with an in-kernel retry on the one-entry-per-level stack for a ray that runs out of
+// entries (the pattern of k_shadow_refill).  Rounds 1-4 traced every ray of a wave to completion before any lane got its
+// next one.  The closest-hit variants (distance output, snap onto the mesh) keep their plain per-lane loop.
 #include "hz_search.h"
 
 namespace hz {
 
 #define HZ_TPB 256
+#ifndef HZ_LOC_REGROUP
+#define HZ_LOC_REGROUP 40      // refill when fewer lanes than this are still traversing (the gridded kernel's value)
+#endif
+#ifndef HZ_LOC_FAST_CAP
+#define HZ_LOC_FAST_CAP 27     // entries of the fast stack: (27 + 2) x 1 KiB of LDS per workgroup, 5 resident
+#endif
 
 struct LocParams {
     SceneView sv;
@@ -18,6 +27,7 @@ struct LocParams {
     const float *coords, *vec_norm, *vec_north, *ray_org_elev;
     float *hori, *dist;
     int num_loc, stack_bytes;
+    int stack_cap;                  // entries of the fast stack (0: the one-entry-per-level stack only)
     float tfar;
     unsigned long long *counters;   // [0] rays, [1] guards, [4] locations on the mesh
 };
@@ -78,33 +88,71 @@ __global__ __launch_bounds__(HZ_TPB) void k_locations(LocParams p) {
     unsigned rays = 0, guards = 0;
     bool last_hit = false;
     TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.w_nodes = 0; tc.w_leaves = 0;
-    while (__ballot(!done) != 0ull) {
-        bool have_ray = false;
-        float dx = 0, dy = 0, dz = 1;
-        if (!done) {
-            if (advance<ALG, false>(s, last_hit, t, out, guards)) {
-                const float ec = t.elev_cos[s.ind], es = t.elev_sin[s.ind];
-                const float rx = ec * t.azim_sin[s.k], ry = ec * t.azim_cos[s.k], rz = es;
-                dx = (r00 * rx + r01 * ry) + r02 * rz;
-                dy = (r10 * rx + r11 * ry) + r12 * rz;
-                dz = (r20 * rx + r21 * ry) + r22 * rz;
-                have_ray = true;
-                rays++;
-            } else {
-                done = true;
+    if (DIST) {
+        while (__ballot(!done) != 0ull) {
+            bool have_ray = false;
+            float dx = 0, dy = 0, dz = 1;
+            if (!done) {
+                if (advance<ALG, false>(s, last_hit, t, out, guards)) {
+                    const float ec = t.elev_cos[s.ind], es = t.elev_sin[s.ind];
+                    const float rx = ec * t.azim_sin[s.k], ry = ec * t.azim_cos[s.k], rz = es;
+                    dx = (r00 * rx + r01 * ry) + r02 * rz;
+                    dy = (r10 * rx + r11 * ry) + r12 * rz;
+                    dz = (r20 * rx + r21 * ry) + r22 * rz;
+                    have_ray = true;
+                    rays++;
+                } else {
+                    done = true;
+                }
             }
-        }
-        if (have_ray) {
-            const RayBox rb = hz_raybox(ocx - p.sv.tau * dx, ocy - p.sv.tau * dy, ocz - p.sv.tau * dz, dx, dy, dz);
-            if (DIST) {                                             // castRay_intersect1, :268-292
+            if (have_ray) {                                             // castRay_intersect1, :268-292
+                const RayBox rb = hz_raybox(ocx - p.sv.tau * dx, ocy - p.sv.tau * dy, ocz - p.sv.tau * dz, dx, dy, dz);
                 float d = 0.0f;
                 last_hit = hz_closest<HZ_TPB>(p.sv.nodes, p.sv.prims, stack, tid, ox, oy, oz, dx, dy, dz, p.tfar, p.sv.tau, rb, &d);
-                if (last_hit) out.dist_hit = d;                     // :545-547 / :589-591
-            } else {                                                // castRay_occluded1, :241-262
-                TravState ts; hz_trav_reset(ts);
-                bool overflow = false;       // unused: the one-entry-per-level stack cannot overflow
-                last_hit = hz_trace<HZ_TPB, false>(p.sv.nodes, p.sv.prims, nullptr, 0, stack, tid, ox, oy, oz, dx, dy,
-                                                   dz, p.tfar, p.tfar + 2.0f * p.sv.tau, rb, ts, 0, 16, tc, 0, overflow) == 1;
+                if (last_hit) out.dist_hit = d;                         // :545-547 / :589-591
+            }
+        }
+    } else {                                                            // castRay_occluded1, :241-262
+        const bool fast = p.stack_cap > 0;
+        int *fstack = reinterpret_cast<int *>(smem + (fast ? 2 * HZ_TPB * 4 : 0));     // two padding rows below the fast stack (hz_trace)
+        bool ray_active = false, overflow = false;
+        float dx = 0, dy = 0, dz = 1;
+        RayBox rb = hz_raybox(0, 0, 0, 0, 0, 1);
+        TravState ts; hz_trav_reset(ts);
+        const float tfar_box = p.tfar + 2.0f * p.sv.tau;
+        while (__ballot(!done) != 0ull) {
+            if (!done && !ray_active) {
+                if (advance<ALG, false>(s, last_hit, t, out, guards)) {
+                    const float ec = t.elev_cos[s.ind], es = t.elev_sin[s.ind];
+                    const float rx = ec * t.azim_sin[s.k], ry = ec * t.azim_cos[s.k], rz = es;
+                    dx = (r00 * rx + r01 * ry) + r02 * rz;
+                    dy = (r10 * rx + r11 * ry) + r12 * rz;
+                    dz = (r20 * rx + r21 * ry) + r22 * rz;
+                    rb = hz_raybox(ocx - p.sv.tau * dx, ocy - p.sv.tau * dy, ocz - p.sv.tau * dz, dx, dy, dz);
+                    hz_trav_reset(ts);
+                    overflow = false;
+                    ray_active = true;
+                    rays++;
+                } else {
+                    done = true;
+                }
+            }
+            if (ray_active) {
+                int res;
+                if (fast) {
+                    res = hz_trace<HZ_TPB, false, 2, false, false>(p.sv.nodes, p.sv.prims, nullptr, 0, fstack, tid, ox, oy, oz, dx, dy, dz,
+                                                                   p.tfar, tfar_box, rb, ts, HZ_LOC_REGROUP, 24, tc, p.stack_cap, overflow);
+                    if (res != 2 && overflow) {        // out of entries: this ray again, to completion, one entry per tree level
+                        bool unused = false;
+                        hz_trav_reset(ts);
+                        res = hz_trace<HZ_TPB, false, 2, false, true>(p.sv.nodes, p.sv.prims, nullptr, 0, fstack, tid, ox, oy, oz, dx, dy, dz,
+                                                                      p.tfar, tfar_box, rb, ts, 0, 24, tc, 0, unused);
+                    }
+                } else {
+                    res = hz_trace<HZ_TPB, false, 2, false, true>(p.sv.nodes, p.sv.prims, nullptr, 0, stack, tid, ox, oy, oz, dx, dy, dz,
+                                                                  p.tfar, tfar_box, rb, ts, HZ_LOC_REGROUP, 24, tc, 0, overflow);
+                }
+                if (res != 2) { ray_active = false; last_hit = (res == 1); }
             }
         }
     }
@@ -138,11 +186,18 @@ int locations_launch(const Scene *sc, const LocationsArgs &a, hipStream_t st) {
     p.coords = a.coords; p.vec_norm = a.vec_norm; p.vec_north = a.vec_north; p.ray_org_elev = a.ray_org_elev;
     p.hori = a.hori; p.dist = a.dist; p.num_loc = a.num_loc; p.tfar = a.dist_m;
     p.counters = a.counters;
-    const int depth = 3 * std::max(sc->hdr.height, 1);
+    const int height = std::max(sc->hdr.height, 1);
+    const bool d = a.hori_dist_out != 0;
+    // closest hit: individual child links, up to 3 per level; any-hit: the fast stack (+ 2 padding rows) if the level stack
+    // of the in-kernel retry fits into it, else the level stack alone
+    const int fast_cap = std::min(HZ_LOC_FAST_CAP, 3 * height + 1);
+    const bool fast = !d && fast_cap >= 5 && fast_cap >= height;
+    p.stack_cap = fast ? fast_cap : 0;
+    // (the snap onto the mesh is a closest-hit query in every variant: its 3 x height entries must fit too)
+    const int depth = std::max(3 * height, fast ? fast_cap + 2 : 0);
     p.stack_bytes = depth * HZ_TPB * 4;
     const size_t lds = (size_t)p.stack_bytes;
     const int grid = (a.num_loc + HZ_TPB - 1) / HZ_TPB;
-    const bool d = a.hori_dist_out != 0;
     switch (a.alg) {
         case ALG_DISCRETE: return d ? launch<ALG_DISCRETE, true>(p, grid, lds, st) : launch<ALG_DISCRETE, false>(p, grid, lds, st);
         case ALG_BINARY: return d ? launch<ALG_BINARY, true>(p, grid, lds, st) : launch<ALG_BINARY, false>(p, grid, lds, st);

@@ -26,6 +26,7 @@ struct ShadowParams {
     size_t out_stride;       // cells per sun position (outputs of position s start at s * out_stride)
     float fill, dot_prod_min;
     int refrac, which;
+    const double *refrac_fac;   // refrac: per cell ((double)pressure / 101.0) * (283.0 / (273.0 + (double)temperature_degC)), k_refrac_factor
     uint8_t *out_u8; float *out_f32;
     int top_nodes, stack_bytes;
     int stack_cap;                 // FAST: entries of the fast stack (hz_trace, !LEVELSTACK), sentinel included
@@ -53,14 +54,36 @@ __device__ __forceinline__ void vec_unit(float &x, float &y, float &z) {
     x = x / mag; y = y / mag; z = z / mag;
 }
 
-// shadow_comp.cpp:135-159 (Saemundsson), float/double promotions as there
-__device__ __forceinline__ float atmos_refrac(float elev_ang_true, float temp, float pressure) {
+// shadow_comp.cpp:135-159 (Saemundsson), float/double promotions as there.  `fac` = the factor that depends on the cell's
+// pressure and temperature only: ((double)pressure / 101.0) * (283.0 / (273.0 + (double)temp)) (:156), formed once per cell
+// at Terrain::initialise (k_refrac_factor) -- the same float64 value the expression yields here
+__device__ __forceinline__ float atmos_refrac(float elev_ang_true, double fac) {
     elev_ang_true = __builtin_fmaxf(-1.0f, __builtin_fminf(elev_ang_true, 90.0f));
     float refrac_cor = (float)(1.02 / (double)f_tan(deg2rad_f(
         (float)((double)elev_ang_true + 10.3 / ((double)elev_ang_true + 5.11)))));
     refrac_cor = (float)((double)refrac_cor + 0.0019279);
-    refrac_cor = (float)((double)refrac_cor * (((double)pressure / 101.0) * (283.0 / (273.0 + (double)temp))));
+    refrac_cor = (float)((double)refrac_cor * fac);
     return (float)((double)refrac_cor * (1.0 / 60.0));
+}
+
+// :438-441 and the pressure / temperature factor of :156, per cell
+__global__ __launch_bounds__(256) void k_refrac_factor(const float *__restrict__ elevation, size_t n, double *__restrict__ out) {
+    const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    const float temperature_ref = 283.15f, pressure_ref = 101.0f, lapse_rate = 0.0065f;
+    const float g = 9.81f, R_d = 287.0f;
+    const float expo = g / (R_d * lapse_rate);                 // :353-354
+    const float temperature = temperature_ref - (lapse_rate * elevation[c]);
+    const float pressure = pressure_ref * f_pow(temperature / temperature_ref, expo);
+    const float temp = (float)((double)temperature - 273.15);  // K2degC, :146-148
+    out[c] = ((double)pressure / 101.0) * (283.0 / (273.0 + (double)temp));
+}
+
+int shadow_refrac_factor(const float *elevation, size_t n, double *out, hipStream_t st) {
+    if (n == 0) return HZ_OK;
+    hipLaunchKernelGGL(k_refrac_factor, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, elevation, n, out);
+    HZ_HIP(hipGetLastError());
+    return HZ_OK;
 }
 
 // any-hit traversal to completion (regroup = 0: never suspends; no LDS nodelet: top = null)
@@ -120,13 +143,23 @@ __device__ __forceinline__ int shadow_setup(const ShadowParams &p, int i, int j,
     vec_unit(sun_x, sun_y, sun_z);
     float dot_prod_ns = (norm_x * sun_x + norm_y * sun_y) + norm_z * sun_z;
     if (p.refrac == 1) {                                           // :430-446
+        const double fac = p.refrac_fac[cell];
+        // The refraction turns the sun direction about an axis normal to it by theta <= 38.81' * fac (the formula's value at
+        // the clamp -1 deg, where it is largest) = 0.01129 * fac rad: tilt . sun changes by less than |tilt| * theta.  A cell
+        // whose tilted surface faces away from the unrefracted sun by more than that is self-shaded (`!(dot > 0)` below,
+        // and `!(dot > dot_prod_min)` with dot_prod_min > 0) whatever the refraction is: night positions and back slopes
+        // skip the five libm calls.  (NaN factor: the comparison is false, the full path runs.)
+        {
+            const float dot0 = (tilt_x * sun_x + tilt_y * sun_y) + tilt_z * sun_z;
+            const float tl = __builtin_fmaxf((tilt_x * tilt_x + tilt_y * tilt_y) + tilt_z * tilt_z, 1.0f);     // >= |tilt|
+            const float bound = (0.0114f * __builtin_fabsf((float)fac)) * tl * 1.01f + 1.0e-5f;
+            if (dot0 < -bound) {
+                if (p.which == 0) out_u8[cell] = 1; else out_f32[cell] = 0.0f;
+                return 0;
+            }
+        }
         const float elev_ang_true = (float)(90.0 - (double)rad2deg_f(f_acos(dot_prod_ns)));
-        const float temperature_ref = 283.15f, pressure_ref = 101.0f, lapse_rate = 0.0065f;
-        const float g = 9.81f, R_d = 287.0f;
-        const float expo = g / (R_d * lapse_rate);                 // :353-354
-        const float temperature = temperature_ref - (lapse_rate * p.elevation[cell]);
-        const float pressure = pressure_ref * f_pow(temperature / temperature_ref, expo);
-        const float refrac_cor = atmos_refrac(elev_ang_true, (float)((double)temperature - 273.15), pressure);
+        const float refrac_cor = atmos_refrac(elev_ang_true, fac);
         float k_x = sun_y * norm_z - sun_z * norm_y;
         float k_y = sun_z * norm_x - sun_x * norm_z;
         float k_z = sun_x * norm_y - sun_y * norm_x;
@@ -292,7 +325,7 @@ int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st) {
     p.suns = a.suns; p.out_stride = (size_t)a.dim_in_0 * (size_t)a.dim_in_1;
     if (a.num_sun <= 0) return HZ_OK;
     p.fill = a.sw_dir_cor_fill; p.dot_prod_min = a.dot_prod_min;
-    p.refrac = a.refrac_cor; p.which = a.which;
+    p.refrac = (a.refrac_cor && a.refrac_fac != nullptr) ? 1 : 0; p.which = a.which; p.refrac_fac = a.refrac_fac;
     p.out_u8 = a.out_u8; p.out_f32 = a.out_f32;
     // LDS stack: one entry per tree level (hz_common.h): 12 - 14 KB per workgroup, so the VGPRs decide the residency
     p.stack_bytes = std::max(sc->hdr.height, 1) * HZ_TPB * 4;

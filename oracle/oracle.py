@@ -64,6 +64,7 @@ def lib():
         L.orc_set_libm.argtypes = [C.c_int]
         L.orc_set_quad_order.argtypes = [C.c_int]
         L.orc_set_box_start.argtypes = [C.c_float]
+        L.orc_set_den_noise.argtypes = [C.c_float]
         L.orc_crmath_sweep.argtypes = [C.c_int, C.c_float, C.c_float, C.c_float, u64p]
         _lib = L
     return _lib
@@ -89,9 +90,10 @@ def num_threads():
 
 
 def set_libm(platform):
-    """False (default): the refraction branch uses the shared correctly rounded hz_crmath.h routines;
-    True: the platform's acosf / tanf / powf / cosf / sinf (to measure how much depends on them)."""
-    lib().orc_set_libm(int(bool(platform)))
+    """False / 0: hz_crmath.h (shared with the HIP kernels); True / 1: the platform's float routines (what the reference
+    calls); 2: the oracle's own evaluation of the correctly rounded float through the long double libm (shares no code with
+    the kernels)."""
+    lib().orc_set_libm(int(platform))
 
 
 TRI_MODES = {"plain": 0, "embree_fma_rcp": 1, "moeller_trumbore": 2}
@@ -126,6 +128,14 @@ def set_quad_order(embree_quad):
     (horizon_comp.cpp:142-148).  True: as (d, c, b), the order Embree's quad / grid intersector forms from the quad
     (v0, v1, v2, v3) of horizon_comp.cpp:165-172 -- same triangle, rotated vertices, different rounding."""
     lib().orc_set_quad_order(int(bool(embree_quad)))
+
+
+DEN_NOISE = 2.0 ** -20     # hz_oracle.c: ORC_DEN_NOISE = hz_common.h: HZ_DEN_NOISE
+
+
+def set_den_noise(k=DEN_NOISE):
+    """Threshold of the triangle test's parallel check |den| > k (|nx dx| + |ny dy| + |nz dz|); 0 = the exact den != 0 of rounds 1-4."""
+    lib().orc_set_den_noise(float(k))
 
 
 BOX_START_PADS = 16.0      # hz_oracle.c: ORC_BOX_START_PADS = hz_common.h: HZ_BOX_START_PADS

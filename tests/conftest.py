@@ -23,6 +23,14 @@ def orc():
 @pytest.fixture(scope="session")
 def hip():
     """The product package; the HIP library must be present and a GPU visible."""
+    # PyTorch bundles its own libamdhip64 (ROCm 7.0 here); the library links the system's (7.2).  Whichever loads first
+    # serves both.  With the system's first, the first `import torch` in this process was seen to take 9 minutes on a fresh GPU
+    # box (round 5, tests/test_gpu_parity.py::test_host_output_that_is_already_page_locked: 526 s) -- the suite ran in 5 minutes
+    # whenever a torch-importing test module came first.  The order is pinned here: torch first, if it is installed.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     import horayzon_amd
     from horayzon_amd import _lib
     _lib.lib()

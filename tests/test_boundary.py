@@ -315,9 +315,10 @@ def test_pad_buffer_mirrors_the_reference():
 
 
 def test_bench_roofline_arithmetic():
-    """bench.py's roofline object from known counters: achieved = the SIMD cycles the launch's VALU instructions need at
-    the issue rates of the two instruction classes (wave iterations x instructions per iteration x class mix) per
-    second, peak = SIMDs x clock, frac = achieved / peak; frac_uniform_4_cycle = the round-1/2 model; HBM pair from the
+    """bench.py's roofline object from known counters.  Contract fields = SURVEY 8(d): bound "hbm", achieved = algorithmic
+    bytes (B_io + rays x (nodes x 32 B + triangles x 24 B)) / kernel time, peak 8 TB/s, frac = achieved / peak.  valu.* = the
+    resource that binds: frac_model_raw (class model at the given mean issue rates, raw -- may exceed 1),
+    frac_valu_counter_floor (wave instructions x 2 cycles / SIMD cycles), frac_uniform_4_cycle; HBM counter pair from the
     stamped traffic file only when it matches the run."""
     import types
     import bench
@@ -335,11 +336,19 @@ def test_bench_roofline_arithmetic():
     cyc = lambda f: 2.5 * f + 4.0 * (1.0 - f)
     need = (5e9 * m["node_iter"] * cyc(mix["node_step"]) + 1e9 * m["leaf_iter"] * cyc(mix["leaf_step"])
             + 5e8 * m["refill_iter"] * cyc(mix["refill_and_loop_overhead"]))
-    assert r["bound"] == "valu_issue" and r["unit"].startswith("G SIMD-cycles/s")
+    cells = 12737761
+    b_alg = (53 + 4 * 360) * cells + 1e10 * (22 * 32 + 6 * 24)
+    assert r["bound"] == "hbm" and r["peak"] == bench.HBM_PEAK_GBS and r["binding_resource"] == "valu_issue"
+    assert abs(r["achieved"] - b_alg / 2.0 / 1e9) <= 1e-9 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["frac"] == r["frac_8d_hbm_model"] and r["kernel_ms_per_launch"] == 2000.0
+    v = r["valu"]
+    have = 1024 * 2.4e9 * 2.0
     assert abs(r["valu_winst_per_launch"] - winst) <= 1e-6 * winst
-    assert abs(r["achieved"] - need / 2.0 / 1e9) <= 1e-6 * r["achieved"] and abs(r["peak"] - 1024 * 2.4) < 1e-9
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and r["kernel_ms_per_launch"] == 2000.0
-    assert abs(r["frac_uniform_4_cycle"] - winst / 2.0 / 6.144e11) < 1e-12 and r["frac"] < r["frac_uniform_4_cycle"]
+    assert abs(v["achieved"] - need / 2.0 / 1e9) <= 1e-6 * v["achieved"] and abs(v["peak"] - 1024 * 2.4) < 1e-9
+    assert abs(v["frac_model_raw"] - need / have) < 1e-12 and v["frac_model_raw"] == r["frac_model_raw"]
+    assert abs(v["frac_valu_counter_floor"] - 2.0 * winst / have) < 1e-12
+    assert abs(v["frac_uniform_4_cycle"] - winst / 2.0 / 6.144e11) < 1e-12
+    assert v["frac_valu_counter_floor"] < v["frac_model_raw"] < v["frac_uniform_4_cycle"]
     assert r["nodes_per_ray"] == 22.0 and r["tris_per_ray"] == 6.0
     if r["traffic"] is not None:          # stamped for these kernel sources and this launch shape
         assert abs(r["hbm"]["hbm_frac"] - r["traffic"] / 2.0 / 1e9 / 8000.0) < 1e-12
@@ -348,4 +357,4 @@ def test_bench_roofline_arithmetic():
     assert r2["traffic"] is None and r2["hbm"]["hbm_frac"] is None
     # no counter pass: only the HBM view
     r3 = bench.roofline(args, st, 2, None, None, 360, 3601, 3569)
-    assert r3["bound"] == "hbm" and r3["peak"] == bench.HBM_PEAK_GBS
+    assert r3["bound"] == "hbm" and r3["peak"] == bench.HBM_PEAK_GBS and "valu" not in r3

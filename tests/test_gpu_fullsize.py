@@ -235,3 +235,32 @@ def test_c3_curved_tile_certificates_retraced(hip, tile):
         tot["rays"] += st.num_rays; tot["rays_shortened"] += st.rays_shortened
         tot["retraced"] += st.near_verified; tot["violations"] += st.near_violations
     _log_r04("c3_curved_1024_rows", dict(tot, shortened_fraction=tot["rays_shortened"] / tot["rays"]))
+
+
+def test_c3_locations_against_the_oracle(hip, orc, tile):
+    """horizon_locations at full scene size: 10 000 of the random locations bench.py's `extras.locations`
+    line scatters over the tile (a few metres above / below the surface: the snap onto the mesh runs), 120 azimuths,
+    binary_search; and a tenth of them with the distance output.  Bit-identical to the oracle incl. ray and guard counts.
+    Some locations lie far outside the scene (ten scene diagonals away): absent child slots of the tree must stay
+    unreachable there too (inverted ranges against the box test's relative slack)."""
+    n = 3601
+    rng = np.random.default_rng(5)
+    m = 10000
+    ci = rng.integers(40, n - 40, m); cj = rng.integers(40, n - 40, m)
+    coords = np.stack([tile["x"][cj] + rng.uniform(-8.0, 8.0, m), tile["y"][ci] + rng.uniform(-8.0, 8.0, m),
+                       tile["z"][ci, cj] + rng.uniform(-30.0, 60.0, m)], axis=1).astype(np.float32)
+    coords[:20, 0] += np.float32(1.5e6); coords[20:40, 2] += np.float32(9.0e4)      # far away sideways / 90 km above the mesh
+    vn = np.zeros((m, 3), np.float32); vn[:, 2] = 1.0
+    vo = np.zeros((m, 3), np.float32); vo[:, 1] = 1.0
+    sc = hip.Scene.create(tile["vert_grid"], n, n)
+    par = dict(azim_num=120)
+    h, a = hip.horizon.horizon_locations(tile["vert_grid"], n, n, coords, vn, vo, 50.0, **par, scene=sc)
+    st = dict(hip.horizon.last_stats)
+    ho, ao, so = orc.horizon_locations(tile["vert_grid"], n, n, coords, vn, vo, 50.0, **par, return_stats=True)
+    assert np.array_equal(a, ao) and np.array_equal(h, ho, equal_nan=True)
+    assert st["num_rays"] == so["rays"] and st["guard_events"] == so["guards"]
+    assert np.isnan(h[:20]).all() and not np.isnan(h[40:]).any()
+    k = m // 10
+    h2, d2, _ = hip.horizon.horizon_locations(tile["vert_grid"], n, n, coords[:k], vn[:k], vo[:k], 50.0, **par, hori_dist_out=True, scene=sc)
+    ho2, do2, _ = orc.horizon_locations(tile["vert_grid"], n, n, coords[:k], vn[:k], vo[:k], 50.0, **par, hori_dist_out=True)
+    assert np.array_equal(h2, ho2, equal_nan=True) and np.array_equal(d2, do2, equal_nan=True)

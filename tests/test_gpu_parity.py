@@ -590,6 +590,34 @@ def test_refraction_against_platform_libm(hip, orc):
     assert worst <= 1e-4, worst                       # sw_dir_cor where the classification agrees
 
 
+def test_refraction_against_the_oracles_own_functions(hip, orc):
+    """with hz_crmath.h on both sides, GPU = oracle holds by construction.  Here the oracle evaluates the
+    same CONTRACT (the correctly rounded float of acos / tan / pow / cos / sin) with its own means -- the x87 long double
+    libm, rounded once (orc.set_libm(2)) -- and shares no line with the kernels.  The two agree unless an exact value lies
+    within ~1e-14 relative of a float rounding boundary (hz_crmath.h evaluates in float64): 0 differing shadow codes and
+    0 differing sw_dir_cor bit patterns are expected on this input, and asserted (24 positions x 32 400 cells x 5 calls)."""
+    from horayzon_amd import synth
+    g = cases.c2_hill(height=1500.0)
+    vec_tilt, vec_norm, enl, elev, mask = cases.terrain_inputs(g)
+    tg, tc = hip.shadow.Terrain(), orc.Terrain()
+    args = (g["vert_grid"], 200, 200, 10, 10, vec_tilt, vec_norm, enl, elev, mask)
+    tg.initialise(*args, refrac_cor=True, sw_dir_cor_fill=-9.0)
+    tc.initialise(*args, refrac_cor=True, sw_dir_cor_fill=-9.0)
+    suns, alt, _ = synth.sun_positions(num=24)
+    suns = suns + np.array([5000.0, 5000.0, 0.0], np.float32)
+    orc.set_libm(2)
+    try:
+        for s in range(suns.shape[0]):
+            sg = np.full(mask.shape, 255, np.uint8); sc = sg.copy()
+            tg.shadow(suns[s], sg); tc.shadow(suns[s], sc)
+            fg = np.full(mask.shape, np.nan, np.float32); fc = fg.copy()
+            tg.sw_dir_cor(suns[s], fg); tc.sw_dir_cor(suns[s], fc)
+            assert np.array_equal(sg, sc), s
+            assert np.array_equal(fg.view(np.uint32), fc.view(np.uint32)), s
+    finally:
+        orc.set_libm(False)
+
+
 def test_shadow_batch_matches_single(hip):
     from horayzon_amd import synth
     g = cases.rough_terrain(90, 90, seed=31, offset=5, relief=1500.0)
@@ -681,14 +709,18 @@ def test_near_field_certificates_are_transparent(hip, orc, case):
     assert np.array_equal(h_cnt, h_on) and st_cnt["nodes_visited"] < st_off["nodes_visited"]
 
 
-def test_near_field_certificates_off_with_outer_tin(hip, orc):
-    """An outer-domain TIN is not part of the height field the certificates' distance bound relies on."""
+def test_near_field_certificates_with_an_outer_tin_are_per_cell(hip, orc):
+    """An outer-domain TIN is not part of the height field the certificates' distance bound relies on: its triangles mark
+    the scene's bad-quad bitmap (HZ_BLOB_BAD_MAP) and the cells whose window lies under / next to one run without a
+    certificate; the others keep theirs (rounds 1-4: off for the whole scene).  Every shortened ray is re-traced."""
     g = cases.rough_terrain(40, 44, seed=2, offset=3)
     kw = cases.grid_kwargs(g)
     vs, nvs, ts, nts = cases.outer_tin(g)
     h, _ = hip.horizon.horizon_gridded(**kw, dist_search=6.0, azim_num=24, vert_simp=vs, num_vert_simp=nvs,
-                                       tri_ind_simp=ts, num_tri_simp=nts, count_work=True)
-    assert hip.horizon.last_stats["rays_shortened"] == 0
+                                       tri_ind_simp=ts, num_tri_simp=nts, count_work=True, _verify_near=1)
+    st = dict(hip.horizon.last_stats)
+    assert st["height_field"] == 0 and st["near_used"] == 1 and st["near_violations"] == 0
+    assert st["near_verified"] == st["rays_shortened"]
     h_cpu, _ = orc.horizon_gridded(**kw, dist_search=6.0, azim_num=24, vert_simp=vs, num_vert_simp=nvs,
                                    tri_ind_simp=ts, num_tri_simp=nts)
     assert np.array_equal(h, h_cpu)

@@ -354,6 +354,28 @@ def test_crmath_is_the_correctly_rounded_float(orc):
     assert orc.crmath_sweep("pow", 0.0, 0.0, 5.25)[1] == 0
 
 
+def test_crmath_equals_the_oracles_own_long_double_evaluation(orc):
+    """The shared header against the oracle's OWN evaluation of the contract (long double libm rounded once, set_libm(2)):
+    same shadow codes and the same sw_dir_cor bits over a day of sun positions on config 2 -- the CPU-side twin of
+    tests/test_gpu_parity.py::test_refraction_against_the_oracles_own_functions."""
+    g = cases.c2_hill(height=1500.0)
+    vec_tilt, vec_norm, enl, elev, mask = cases.terrain_inputs(g)
+    from horayzon_amd import synth
+    suns, _, _ = synth.sun_positions(num=24)
+    suns = suns + np.array([5000.0, 5000.0, 0.0], np.float32)
+    t = orc.Terrain()
+    t.initialise(g["vert_grid"], 200, 200, 10, 10, vec_tilt, vec_norm, enl, elev, mask, refrac_cor=True)
+    try:
+        for s in range(suns.shape[0]):
+            a = np.empty(mask.shape, np.uint8); b = a.copy()
+            fa = np.empty(mask.shape, np.float32); fb = fa.copy()
+            orc.set_libm(0); t.shadow(suns[s], a); t.sw_dir_cor(suns[s], fa)
+            orc.set_libm(2); t.shadow(suns[s], b); t.sw_dir_cor(suns[s], fb)
+            assert np.array_equal(a, b) and np.array_equal(fa.view(np.uint32), fb.view(np.uint32)), s
+    finally:
+        orc.set_libm(False)
+
+
 def test_refraction_depends_little_on_the_platform_libm(orc):
     """With the platform's float routines instead of hz_crmath.h a handful of cells per million change: the
     reference's own output moves by that much from one libm to the next."""
