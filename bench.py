@@ -590,6 +590,27 @@ def c3_extras(ctx, L, scene, step_args, peaks, g):
         del terrain
     c4["note"] = "Terrain.shadow_batch / sw_dir_cor_batch over %d diurnal sun positions in one launch, outputs resident in HBM" % S
     res["c4"] = c4
+    # ---- what a strong-scaling run of this tile over N GPUs can reach: the N row slabs of `--gpus N`, one after the other on
+    #      this GPU (each alone, exactly as on its own rank: certificates + kernel + SVF of the slab, GPU event times) ----------
+    try:
+        from horayzon_amd.dist import row_slabs
+        def slab_ms(b, e):
+            st = whole_tile(scene, a["d_norm"], a["d_north"], a["d_tilt"], "guess_constant", rows=(b, e))
+            return 1e3 * (st.t_kernel_s + st.t_near_s + st.t_svf_s)
+        whole_ms = slab_ms(0, in0)
+        whole_ms = min(whole_ms, slab_ms(0, in0))
+        pred = {"whole_tile_ms": whole_ms}
+        for N in (2, 4, 8):
+            ts = [slab_ms(b, e) for b, e in row_slabs(in0, N)]
+            pred["n%d" % N] = {"slab_ms": [round(t, 2) for t in ts], "predicted_efficiency": whole_ms / (N * max(ts)),
+                               "predicted_cells_per_s": in0 * in1 / (1e-3 * max(ts))}
+        pred["note"] = ("one-GPU emulation of `bench.py --gpus N` (strong scaling of this tile): efficiency = whole-tile time / (N x the "
+                        "slowest slab), compute only (certificate pre-pass + kernel + SVF); a real run adds the scene broadcast "
+                        "(job_s_incl_bcast) and the SVF gather.  The loss is the launch tail: a lane owns its cell for all 360 azimuths, "
+                        "a wave lives ~33 ms, and a 1/8-tile launch is only ~5 wave generations deep (DESIGN.md section 8)")
+        res["scaling_prediction"] = pred
+    except Exception as e:
+        res["scaling_prediction"] = {"error": repr(e)[:300]}
     # ---- horizon_locations on the same scene (horizon_comp.cpp:828-1094) -------------------------------
     try:
         res["locations"] = locations_extra(hz, scene, g, n, args, ctx["local_rank"])
@@ -929,7 +950,36 @@ def run_sharded(ctx, kind):
                 rows = [int(r) for r in args.dump_svf_rows.split(",")]
                 np.save(args.dump_path, res["full"][rows].cpu().numpy())
     step_s = elapsed / max(steps, 1)
+    # c3, N > 1: what the one-GPU emulation predicts for this partition, next to what was just measured -- rank 0 computes the
+    # whole tile and then every rank's slab on ITS GPU, one after the other, each alone as on its own rank (untimed; the
+    # other ranks are done).  predicted_efficiency = whole / (N x slowest slab); measured_efficiency = whole / (N x step).
+    prediction = None
+    if c3 and world > 1 and not args.no_extras:
+        try:
+            def alone_ms(b, e):
+                cache.clear(); slab_inputs(b, e)
+                best = None
+                for _ in range(2):
+                    st = _lib.hz_stats()
+                    torch.cuda.synchronize(); t1 = time.perf_counter()
+                    run_slab(b, e, st)
+                    torch.cuda.synchronize(); dt = 1e3 * (time.perf_counter() - t1)
+                    best = dt if best is None else min(best, dt)
+                return best
+            slabs_now = row_slabs(in0, world, cost)
+            ts = [alone_ms(b, e) for b, e in slabs_now]
+            whole_ms = alone_ms(0, in0)
+            cache.clear()
+            prediction = {"whole_tile_ms_one_gpu": whole_ms, "slab_ms_one_gpu": [round(t, 2) for t in ts],
+                          "predicted_efficiency": whole_ms / (world * max(ts)),
+                          "measured_efficiency_same_run": whole_ms / (world * 1e3 * step_s),
+                          "note": "wall times of hz_horizon_gridded_scene on rank 0's GPU, slabs one by one (compute only: certificates + "
+                                  "kernel + SVF); measured_efficiency uses this run's ms_per_step (incl. the SVF gather)"}
+        except Exception as ex:
+            prediction = {"error": repr(ex)[:300]}
     config = {
+        "predicted_efficiency": prediction["predicted_efficiency"] if prediction and "predicted_efficiency" in prediction else None,
+        "scaling_prediction": prediction,
         "parallelism": "strong scaling: row slabs over %d ranks (dist.row_slabs, balanced by %s), scene broadcast once (%s), "
                        "slab-local inputs made on each rank's GPU, %sSVF gathered on rank 0"
                        % (world, "sampled cost" if cost is not None else "cell count",

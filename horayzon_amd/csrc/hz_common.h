@@ -147,6 +147,24 @@ __device__ __forceinline__ bool hz_tile_of_block(const TileMap &m, int b, int *t
 // and add below rounds separately, in exactly this association order.  The
 // hit decision is the product's numerical contract.
 // ---------------------------------------------------------------------------
+// Build-time switch -DHZ_TRI_FMA (NOT the contract; scripts/build_variant.sh fma -DHZ_TRI_FMA): the cross and dot products of
+// the triangle test with fused multiply-adds, the way Embree's vector code evaluates them on an FMA machine (common/math/vec3.h:
+// cross(a, b).x = msub(a.y, b.z, a.z * b.y), dot(a, b) = madd(a.x, b.x, madd(a.y, b.y, a.z * b.z))); everything else unchanged.
+// The oracle's triangle mode "plain_fma" is the same arithmetic on the CPU (tests/test_gpu_tri_fma.py: bit-identical).  37 fewer
+// VALU instructions per leaf step; should the Embree pin (README.md) show that its FMA evaluation decides differently from
+// the unfused one, adopting it is this flag and a re-validation, not a rewrite.
+#ifdef HZ_TRI_FMA
+#define HZ_CROSS1(ay, bz, az, by) __builtin_fmaf((ay), (bz), -((az) * (by)))
+#define HZ_DOT3(ax, bx, ay, by, az, bz) __builtin_fmaf((ax), (bx), __builtin_fmaf((ay), (by), (az) * (bz)))
+#define HZ_DEN_SUM(nx, dx, ny, dy, nz, dz, pnx, pny, pnz) \
+    __builtin_fmaf(__builtin_fabsf(nx), __builtin_fabsf(dx), __builtin_fmaf(__builtin_fabsf(ny), __builtin_fabsf(dy), __builtin_fabsf(nz) * __builtin_fabsf(dz)))
+#define HZ_DEN(nx, dx, ny, dy, nz, dz, pnx, pny, pnz) HZ_DOT3(nx, dx, ny, dy, nz, dz)
+#else
+#define HZ_CROSS1(ay, bz, az, by) ((ay) * (bz) - (az) * (by))
+#define HZ_DOT3(ax, bx, ay, by, az, bz) (((ax) * (bx) + (ay) * (by)) + (az) * (bz))
+#define HZ_DEN_SUM(nx, dx, ny, dy, nz, dz, pnx, pny, pnz) ((__builtin_fabsf(pnx) + __builtin_fabsf(pny)) + __builtin_fabsf(pnz))
+#define HZ_DEN(nx, dx, ny, dy, nz, dz, pnx, pny, pnz) (((pnx) + (pny)) + (pnz))
+#endif
 __device__ __forceinline__ bool hz_tri_hit(float ox, float oy, float oz,
                                            float dx, float dy, float dz, float tfar,
                                            float p0x, float p0y, float p0z,
@@ -161,30 +179,30 @@ __device__ __forceinline__ bool hz_tri_hit(float ox, float oy, float oz,
     const float s0x = v2x + v0x, s0y = v2y + v0y, s0z = v2z + v0z;
     const float s1x = v0x + v1x, s1y = v0y + v1y, s1z = v0z + v1z;
     const float s2x = v1x + v2x, s2y = v1y + v2y, s2z = v1z + v2z;
-    const float c0x = e0y * s0z - e0z * s0y;
-    const float c0y = e0z * s0x - e0x * s0z;
-    const float c0z = e0x * s0y - e0y * s0x;
-    const float c1x = e1y * s1z - e1z * s1y;
-    const float c1y = e1z * s1x - e1x * s1z;
-    const float c1z = e1x * s1y - e1y * s1x;
-    const float c2x = e2y * s2z - e2z * s2y;
-    const float c2y = e2z * s2x - e2x * s2z;
-    const float c2z = e2x * s2y - e2y * s2x;
-    const float U = (c0x * dx + c0y * dy) + c0z * dz;
-    const float V = (c1x * dx + c1y * dy) + c1z * dz;
-    const float W = (c2x * dx + c2y * dy) + c2z * dz;
+    const float c0x = HZ_CROSS1(e0y, s0z, e0z, s0y);
+    const float c0y = HZ_CROSS1(e0z, s0x, e0x, s0z);
+    const float c0z = HZ_CROSS1(e0x, s0y, e0y, s0x);
+    const float c1x = HZ_CROSS1(e1y, s1z, e1z, s1y);
+    const float c1y = HZ_CROSS1(e1z, s1x, e1x, s1z);
+    const float c1z = HZ_CROSS1(e1x, s1y, e1y, s1x);
+    const float c2x = HZ_CROSS1(e2y, s2z, e2z, s2y);
+    const float c2y = HZ_CROSS1(e2z, s2x, e2x, s2z);
+    const float c2z = HZ_CROSS1(e2x, s2y, e2y, s2x);
+    const float U = HZ_DOT3(c0x, dx, c0y, dy, c0z, dz);
+    const float V = HZ_DOT3(c1x, dx, c1y, dy, c1z, dz);
+    const float W = HZ_DOT3(c2x, dx, c2y, dy, c2z, dz);
     const float UVW = (U + V) + W;
     const float eps = 1.1920928955078125e-7f * __builtin_fabsf(UVW);
     const float mn = __builtin_fminf(U, __builtin_fminf(V, W));
     const float mx = __builtin_fmaxf(U, __builtin_fmaxf(V, W));
     if (!((mn >= -eps) || (mx <= eps))) return false;
-    const float nx = e1y * e0z - e1z * e0y;
-    const float ny = e1z * e0x - e1x * e0z;
-    const float nz = e1x * e0y - e1y * e0x;
-    const float pnx = nx * dx, pny = ny * dy, pnz = nz * dz;
-    const float den = (pnx + pny) + pnz;
-    const float T = (v0x * nx + v0y * ny) + v0z * nz;
-    if (!(__builtin_fabsf(den) > HZ_DEN_NOISE * ((__builtin_fabsf(pnx) + __builtin_fabsf(pny)) + __builtin_fabsf(pnz)))) return false;   // (parallel within rounding)
+    const float nx = HZ_CROSS1(e1y, e0z, e1z, e0y);
+    const float ny = HZ_CROSS1(e1z, e0x, e1x, e0z);
+    const float nz = HZ_CROSS1(e1x, e0y, e1y, e0x);
+    const float pnx = nx * dx, pny = ny * dy, pnz = nz * dz;      // (HZ_TRI_FMA: unused, removed by the compiler)
+    const float den = HZ_DEN(nx, dx, ny, dy, nz, dz, pnx, pny, pnz);
+    const float T = HZ_DOT3(v0x, nx, v0y, ny, v0z, nz);
+    if (!(__builtin_fabsf(den) > HZ_DEN_NOISE * HZ_DEN_SUM(nx, dx, ny, dy, nz, dz, pnx, pny, pnz))) return false;   // (parallel within rounding)
     const float Ts = (den < 0.0f) ? -T : T;
     const float ad = __builtin_fabsf(den);
     if (!(Ts >= 0.0f)) return false;
@@ -210,9 +228,9 @@ __device__ __forceinline__ bool hz_quad_hit(float ox, float oy, float oz, float 
     const float s0x = v2x + v0x, s0y = v2y + v0y, s0z = v2z + v0z;
     const float s1x = v0x + v1x, s1y = v0y + v1y, s1z = v0z + v1z;
     const float s2x = v1x + v2x, s2y = v1y + v2y, s2z = v1z + v2z;
-    const float U = ((e0y * s0z - e0z * s0y) * dx + (e0z * s0x - e0x * s0z) * dy) + (e0x * s0y - e0y * s0x) * dz;
-    const float V = ((e1y * s1z - e1z * s1y) * dx + (e1z * s1x - e1x * s1z) * dy) + (e1x * s1y - e1y * s1x) * dz;
-    const float W = ((e2y * s2z - e2z * s2y) * dx + (e2z * s2x - e2x * s2z) * dy) + (e2x * s2y - e2y * s2x) * dz;
+    const float U = HZ_DOT3(HZ_CROSS1(e0y, s0z, e0z, s0y), dx, HZ_CROSS1(e0z, s0x, e0x, s0z), dy, HZ_CROSS1(e0x, s0y, e0y, s0x), dz);
+    const float V = HZ_DOT3(HZ_CROSS1(e1y, s1z, e1z, s1y), dx, HZ_CROSS1(e1z, s1x, e1x, s1z), dy, HZ_CROSS1(e1x, s1y, e1y, s1x), dz);
+    const float W = HZ_DOT3(HZ_CROSS1(e2y, s2z, e2z, s2y), dx, HZ_CROSS1(e2z, s2x, e2x, s2z), dy, HZ_CROSS1(e2x, s2y, e2y, s2x), dz);
     // No early outs (round 4): with ~25 rays of a wave in a leaf step some lane passes every partial test, so the skipped
     // blocks ran anyway and every `if` was an exec-mask save / branch / restore on top.  The decisions are the same
     // comparisons on the same values, combined with non-short-circuit & and |.
@@ -222,13 +240,13 @@ __device__ __forceinline__ bool hz_quad_hit(float ox, float oy, float oz, float 
         const float eps = 1.1920928955078125e-7f * __builtin_fabsf(UVW);
         const float mn = __builtin_fminf(U, __builtin_fminf(V, W));
         const float mx = __builtin_fmaxf(U, __builtin_fmaxf(V, W));
-        const float nx = e1y * e0z - e1z * e0y, ny = e1z * e0x - e1x * e0z, nz = e1x * e0y - e1y * e0x;
+        const float nx = HZ_CROSS1(e1y, e0z, e1z, e0y), ny = HZ_CROSS1(e1z, e0x, e1x, e0z), nz = HZ_CROSS1(e1x, e0y, e1y, e0x);
         const float pnx = nx * dx, pny = ny * dy, pnz = nz * dz;
-        const float den = (pnx + pny) + pnz;
-        const float T = (v0x * nx + v0y * ny) + v0z * nz;
+        const float den = HZ_DEN(nx, dx, ny, dy, nz, dz, pnx, pny, pnz);
+        const float T = HZ_DOT3(v0x, nx, v0y, ny, v0z, nz);
         const float Ts = (den < 0.0f) ? -T : T;
         const float ad = __builtin_fabsf(den);
-        hit0 = ((mn >= -eps) | (mx <= eps)) & (ad > HZ_DEN_NOISE * ((__builtin_fabsf(pnx) + __builtin_fabsf(pny)) + __builtin_fabsf(pnz))) &
+        hit0 = ((mn >= -eps) | (mx <= eps)) & (ad > HZ_DEN_NOISE * HZ_DEN_SUM(nx, dx, ny, dy, nz, dz, pnx, pny, pnz)) &
                (Ts >= 0.0f) & (Ts <= tfar * ad);
     }
     // triangle (b, d, c): v0' = b, v1' = d, v2' = c
@@ -239,20 +257,20 @@ __device__ __forceinline__ bool hz_quad_hit(float ox, float oy, float oz, float 
     const float t1x = v1x + w1x, t1y = v1y + w1y, t1z = v1z + w1z;
     const float t2x = w1x + v2x, t2y = w1y + v2y, t2z = w1z + v2z;
     const float U1 = -W;
-    const float V1 = ((f1y * t1z - f1z * t1y) * dx + (f1z * t1x - f1x * t1z) * dy) + (f1x * t1y - f1y * t1x) * dz;
-    const float W1 = ((f2y * t2z - f2z * t2y) * dx + (f2z * t2x - f2x * t2z) * dy) + (f2x * t2y - f2y * t2x) * dz;
+    const float V1 = HZ_DOT3(HZ_CROSS1(f1y, t1z, f1z, t1y), dx, HZ_CROSS1(f1z, t1x, f1x, t1z), dy, HZ_CROSS1(f1x, t1y, f1y, t1x), dz);
+    const float W1 = HZ_DOT3(HZ_CROSS1(f2y, t2z, f2z, t2y), dx, HZ_CROSS1(f2z, t2x, f2x, t2z), dy, HZ_CROSS1(f2x, t2y, f2y, t2x), dz);
     const float UVW = (U1 + V1) + W1;
     const float eps = 1.1920928955078125e-7f * __builtin_fabsf(UVW);
     const float mn = __builtin_fminf(U1, __builtin_fminf(V1, W1));
     const float mx = __builtin_fmaxf(U1, __builtin_fmaxf(V1, W1));
-    const float nx = f1y * f0z - f1z * f0y, ny = f1z * f0x - f1x * f0z, nz = f1x * f0y - f1y * f0x;
+    const float nx = HZ_CROSS1(f1y, f0z, f1z, f0y), ny = HZ_CROSS1(f1z, f0x, f1x, f0z), nz = HZ_CROSS1(f1x, f0y, f1y, f0x);
     const float pnx = nx * dx, pny = ny * dy, pnz = nz * dz;
-    const float den = (pnx + pny) + pnz;
-    const float T = (v1x * nx + v1y * ny) + v1z * nz;
+    const float den = HZ_DEN(nx, dx, ny, dy, nz, dz, pnx, pny, pnz);
+    const float T = HZ_DOT3(v1x, nx, v1y, ny, v1z, nz);
     const float Ts = (den < 0.0f) ? -T : T;
     const float ad = __builtin_fabsf(den);
     // (a TIN triangle's record holds NaNs in d: every comparison below is false for it, `second` only states it)
-    const bool hit1 = second & ((mn >= -eps) | (mx <= eps)) & (ad > HZ_DEN_NOISE * ((__builtin_fabsf(pnx) + __builtin_fabsf(pny)) + __builtin_fabsf(pnz))) &
+    const bool hit1 = second & ((mn >= -eps) | (mx <= eps)) & (ad > HZ_DEN_NOISE * HZ_DEN_SUM(nx, dx, ny, dy, nz, dz, pnx, pny, pnz)) &
                       (Ts >= 0.0f) & (Ts <= tfar * ad);
     return hit0 | hit1;
 }
@@ -267,11 +285,11 @@ __device__ __forceinline__ bool hz_tri_hit_t(float ox, float oy, float oz, float
     const float v2x = p2x - ox, v2y = p2y - oy, v2z = p2z - oz;
     const float e0x = v2x - v0x, e0y = v2y - v0y, e0z = v2z - v0z;
     const float e1x = v0x - v1x, e1y = v0y - v1y, e1z = v0z - v1z;
-    const float nx = e1y * e0z - e1z * e0y;
-    const float ny = e1z * e0x - e1x * e0z;
-    const float nz = e1x * e0y - e1y * e0x;
-    const float den = (nx * dx + ny * dy) + nz * dz;
-    const float T = (v0x * nx + v0y * ny) + v0z * nz;
+    const float nx = HZ_CROSS1(e1y, e0z, e1z, e0y);
+    const float ny = HZ_CROSS1(e1z, e0x, e1x, e0z);
+    const float nz = HZ_CROSS1(e1x, e0y, e1y, e0x);
+    const float den = HZ_DOT3(nx, dx, ny, dy, nz, dz);
+    const float T = HZ_DOT3(v0x, nx, v0y, ny, v0z, nz);
     *t = T / den;
     return true;
 }

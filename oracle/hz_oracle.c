@@ -307,6 +307,50 @@ static inline int tri_hit_mt(const float *o, const float *d, float tfar,
     return (t >= 0.0f) && (t <= tfar);
 }
 
+/*   mode 3 "plain_fma": tri_hit_plain with the cross and dot products evaluated the way Embree's vector code does on an
+ *           FMA machine (cross(a, b).x = msub(a.y, b.z, a.z b.y); dot(a, b) = madd(a.x, b.x, madd(a.y, b.y, a.z b.z))) and
+ *           everything else (normal e1 x e0, robust parallel test, division-free depth test) as in tri_hit_plain.  This is the
+ *           CPU side of the product's build-time switch -DHZ_TRI_FMA (hz_common.h): a library built with it must agree with
+ *           this mode bit for bit (tests/test_gpu_tri_fma.py).  Not the contract: 37 fewer VALU instructions per leaf step,
+ *           priced in DESIGN.md section 5; adopting it is a flag and a re-validation should the Embree pin ask for it.  */
+static inline int tri_hit_plain_fma(const float *o, const float *d, float tfar,
+                                    const float *p0, const float *p1, const float *p2) {
+#define MSUB(a, b, c) __builtin_fmaf((a), (b), -(c))
+#define MADD(a, b, c) __builtin_fmaf((a), (b), (c))
+    const float v0x = p0[0] - o[0], v0y = p0[1] - o[1], v0z = p0[2] - o[2];
+    const float v1x = p1[0] - o[0], v1y = p1[1] - o[1], v1z = p1[2] - o[2];
+    const float v2x = p2[0] - o[0], v2y = p2[1] - o[1], v2z = p2[2] - o[2];
+    const float e0x = v2x - v0x, e0y = v2y - v0y, e0z = v2z - v0z;
+    const float e1x = v0x - v1x, e1y = v0y - v1y, e1z = v0z - v1z;
+    const float e2x = v1x - v2x, e2y = v1y - v2y, e2z = v1z - v2z;
+    const float s0x = v2x + v0x, s0y = v2y + v0y, s0z = v2z + v0z;
+    const float s1x = v0x + v1x, s1y = v0y + v1y, s1z = v0z + v1z;
+    const float s2x = v1x + v2x, s2y = v1y + v2y, s2z = v1z + v2z;
+    const float c0x = MSUB(e0y, s0z, e0z * s0y), c0y = MSUB(e0z, s0x, e0x * s0z), c0z = MSUB(e0x, s0y, e0y * s0x);
+    const float c1x = MSUB(e1y, s1z, e1z * s1y), c1y = MSUB(e1z, s1x, e1x * s1z), c1z = MSUB(e1x, s1y, e1y * s1x);
+    const float c2x = MSUB(e2y, s2z, e2z * s2y), c2y = MSUB(e2z, s2x, e2x * s2z), c2z = MSUB(e2x, s2y, e2y * s2x);
+    const float U = MADD(c0x, d[0], MADD(c0y, d[1], c0z * d[2]));
+    const float V = MADD(c1x, d[0], MADD(c1y, d[1], c1z * d[2]));
+    const float W = MADD(c2x, d[0], MADD(c2y, d[1], c2z * d[2]));
+    const float UVW = (U + V) + W;
+    const float eps = FLT_EPSILON * fabsf(UVW);
+    const float mn = fminf(U, fminf(V, W));
+    const float mx = fmaxf(U, fmaxf(V, W));
+    if (!((mn >= -eps) || (mx <= eps))) return 0;
+    const float nx = MSUB(e1y, e0z, e1z * e0y), ny = MSUB(e1z, e0x, e1x * e0z), nz = MSUB(e1x, e0y, e1y * e0x);
+    const float den = MADD(nx, d[0], MADD(ny, d[1], nz * d[2]));
+    const float T = MADD(v0x, nx, MADD(v0y, ny, v0z * nz));
+    const float den_sum = MADD(fabsf(nx), fabsf(d[0]), MADD(fabsf(ny), fabsf(d[1]), fabsf(nz) * fabsf(d[2])));
+    if (!(fabsf(den) > g_den_noise * den_sum)) return 0;
+    const float Ts = (den < 0.0f) ? -T : T;
+    const float ad = fabsf(den);
+    if (!(Ts >= 0.0f)) return 0;
+    if (!(Ts <= tfar * ad)) return 0;
+    return 1;
+#undef MSUB
+#undef MADD
+}
+
 static int g_tri_mode = 0, g_tri_compare = -1;
 static _Thread_local int tl_tri_mode = 0;
 static uint64_t g_cmp_rays = 0, g_cmp_flips = 0;
@@ -318,6 +362,7 @@ static inline int tri_hit_f(const float *o, const float *d, float tfar,
                             const float *p0, const float *p1, const float *p2) {
     if (tl_tri_mode == 1) return tri_hit_embree_fma(o, d, tfar, p0, p1, p2);
     if (tl_tri_mode == 2) return tri_hit_mt(o, d, tfar, p0, p1, p2);
+    if (tl_tri_mode == 3) return tri_hit_plain_fma(o, d, tfar, p0, p1, p2);
     return tri_hit_plain(o, d, tfar, p0, p1, p2);
 }
 
@@ -334,6 +379,13 @@ static inline int tri_hit_t_f(const float *o, const float *d, float tfar,
     const float ny = e1z * e0x - e1x * e0z;
     const float nz = e1x * e0y - e1y * e0x;
     if (!tri_hit_f(o, d, tfar, p0, p1, p2)) return 0;
+    if (tl_tri_mode == 3) {      /* "plain_fma": the same normal, den and T as tri_hit_plain_fma */
+        const float fx = __builtin_fmaf(e1y, e0z, -(e1z * e0y)), fy = __builtin_fmaf(e1z, e0x, -(e1x * e0z)), fz = __builtin_fmaf(e1x, e0y, -(e1y * e0x));
+        const float fden = __builtin_fmaf(fx, d[0], __builtin_fmaf(fy, d[1], fz * d[2]));
+        const float fT = __builtin_fmaf(v0x, fx, __builtin_fmaf(v0y, fy, v0z * fz));
+        *t = fT / fden;
+        return 1;
+    }
     const float den = (nx * d[0] + ny * d[1]) + nz * d[2];
     const float T = (v0x * nx + v0y * ny) + v0z * nz;
     *t = T / den;

@@ -96,7 +96,7 @@ def set_libm(platform):
     lib().orc_set_libm(int(platform))
 
 
-TRI_MODES = {"plain": 0, "embree_fma_rcp": 1, "moeller_trumbore": 2}
+TRI_MODES = {"plain": 0, "embree_fma_rcp": 1, "moeller_trumbore": 2, "plain_fma": 3}   # "plain_fma" = a library built with -DHZ_TRI_FMA
 
 
 def set_tri_mode(mode="plain"):
