@@ -332,6 +332,7 @@ struct NearMonitor {
     hipStream_t st_mon = nullptr;
     hipEvent_t ready = nullptr, done = nullptr;
     void *buf = nullptr;
+    size_t buf_bytes = 0;
     unsigned long long *cnt = nullptr;
     bool active = false;
     int launch(const Scene *sc, const HorizonArgs &a, int n, int seed, hipStream_t st) {
@@ -348,10 +349,16 @@ struct NearMonitor {
         if (!st_mon && (rc = stream_acquire(device, &st_mon))) return rc;
         if (!ready) { HZ_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming)); HZ_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming)); }
         const size_t cbytes = 24 * sizeof(unsigned long long) + HZ_REDO_CAP * sizeof(int);
-        if (buf) { (void)hipFree(buf); buf = nullptr; }
-        HZ_HIP(hipMalloc(&buf, cbytes + pick.size() * sizeof(int)));
+        const size_t row_bytes = ((size_t)a.azim_num * sizeof(float) + 255) & ~(size_t)255;     // the scratch row its stores go to
+        const size_t need = cbytes + row_bytes + pick.size() * sizeof(int);
+        if (need > buf_bytes) {                               // (allocated once per call: the chunks of a call pick about as many blocks)
+            if (buf) { (void)hipFree(buf); buf = nullptr; buf_bytes = 0; }
+            HZ_HIP(hipMalloc(&buf, need + need / 4));
+            buf_bytes = need + need / 4;
+        }
         cnt = (unsigned long long *)buf;
-        int *d_list = (int *)((char *)buf + cbytes);
+        float *scratch = (float *)((char *)buf + cbytes);
+        int *d_list = (int *)((char *)buf + cbytes + row_bytes);
         HZ_HIP(hipEventRecord(ready, st));                    // certificates (and everything enqueued before) are complete
         HZ_HIP(hipStreamWaitEvent(st_mon, ready, 0));
         HZ_HIP(hipMemsetAsync(buf, 0, cbytes, st_mon));
@@ -359,6 +366,7 @@ struct NearMonitor {
         HZ_HIP(hipStreamSynchronize(st_mon));                 // `pick` is host memory of this scope; the copy is tiny
         HorizonArgs v = a;
         v.count_work = 1; v.verify_near = 1; v.level_stack = 1;
+        v.scratch_row = scratch;                              // its stores must not land in the production launch's rows
         v.counters = cnt; v.tile_list = d_list; v.n_list = (int)pick.size();
         if ((rc = horizon_launch(sc, v, st_mon, nullptr))) return rc;
         HZ_HIP(hipEventRecord(done, st_mon));
@@ -549,7 +557,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     const bool bad_map = (sc->hdr.flags & HZ_BLOB_BAD_MAP) != 0;
     const bool use_near = near_opt <= 0 && (height_field || bad_map || near_opt < 0) &&
                           azim_num <= near_max_azim() && tb.elev_num <= 65534;
-    a.near_idx = nullptr; a.near_r = nullptr;
+    a.near_idx = nullptr; a.near_r = nullptr; a.scratch_row = nullptr;
     a.tile_list = nullptr; a.n_list = 0;
     // opts.verify_near = N: with count_work the counting instantiation re-traces one of every N shortened rays; without it
     // the production launch stays as it is and a second, counting launch re-traces EVERY shortened ray of one of every N
@@ -690,7 +698,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
                 // monitor: the certificates of a sample of this launch's blocks, checked ray by ray by a counting launch
                 // (every shortened ray traced a second time over its full length) on a stream of its own, so that its few
                 // workgroups run NEXT TO the production launch instead of after it (a launch of its own costs one
-                // workgroup lifetime, ~0.1 s, however small the sample).  It writes the same output values.
+                // workgroup lifetime, ~0.1 s, however small the sample).  Its stores go to a scratch row (HorizonArgs::scratch_row).
                 if ((rc = mon.launch(sc, a, verify_n, rb, st))) return fail(rc);
             }
             int safe = 0;
@@ -740,6 +748,10 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             ms += m1; ms_svf += m2;
             for (int k = 0; k < 16; k++) cnt[k] += c[k];
             n_verified += c[21];
+#ifdef HZ_PROBE_Q1
+            if (a.count_work) fprintf(stderr, "hz probe q1: leaf-step lanes with a second queued leaf %llu, node-step lanes blocked by a full queue %llu, node-step lanes with a decided ray %llu (lane-leaf-steps %llu = tris / 2, wave node iters %llu, wave leaf iters %llu)\n",
+                                      c[22], c[23], c[21], c[3] / 2, c[5], c[6]);
+#endif
             if (a.count_work && getenv("HZ_XCD_TRACE")) {      // per-XCD span of this launch (counting instantiation)
                 const unsigned long long t0 = ~c[20];
                 fprintf(stderr, "hz xcd spans [ms] rows %d..%d:", rb, re);

@@ -506,7 +506,11 @@ __device__ __forceinline__ void hz_load_prim(const Prim *q, float4 &q0, float4 &
 // busy although neighbouring rays reach their leaves at different times.
 // returns 0 = miss, 1 = hit (t.lq0 is the blocking leaf), 2 = suspended (state is valid, call again)
 // ---------------------------------------------------------------------------
-struct TravCounters { unsigned nodes, tris, w_nodes, w_leaves; };
+struct TravCounters { unsigned nodes, tris, w_nodes, w_leaves;
+#ifdef HZ_PROBE_Q1     // measurement probe (counting instantiation): lanes with a SECOND queued leaf at a leaf step; lanes that sit out a
+    unsigned q1, blk, fin;   // node step with a full leaf queue and a leaf link in hand; lanes that sit out a node step with their ray decided
+#endif
+};
 struct TravState { int node, sp, pf, pm, lq0, lq1; };
 
 __device__ __forceinline__ void hz_trav_reset(TravState &t) {
@@ -561,12 +565,21 @@ __device__ __forceinline__ void hz_entry_unpack(int e, int &pf, int &pm) {
 #else
 #define HZ_PROBE_PADS(seed) do { } while (0)
 #endif
-template <int TPB, bool COUNT, int QLEN = 2, bool NODELET = false, bool LEVELSTACK = true>
+// POOL (round 5, fast stack discipline only): the leaf step POOLS the queued leaves of the wave over its lanes.  At a leaf step
+// 72 % of the lanes that test a leaf hold a second one in their queue while 60 % of the wave's lanes have none (probe build
+// -DHZ_PROBE_Q1, profiles/r05/): the items (lane, queued leaf) -- first every lane's lq0, then the lq1s -- are numbered through
+// the wave (v_mbcnt over the two ballots), lane k tests item k with the OWNER's ray, and the owners read their results out of
+// the ballot of the hits.  For that a lane's ray (origin, direction) lives in LDS (`pool`: 6 rows of TPB floats, written by the
+// caller at every refill, ray[k * TPB + tid]) instead of in registers -- ox .. dz are then ignored -- and the wave owns a
+// 64-entry item table behind the pool (item -> owner lane).  Hit decisions are per (ray, leaf) and the answer is "any leaf
+// hit": which lane evaluates a test, and that a lane's second leaf is tested although its first one hits, changes nothing.
+template <int TPB, bool COUNT, int QLEN = 2, bool NODELET = false, bool LEVELSTACK = true, bool POOL = false>
 __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Prim *__restrict__ prims,
                                         const float4 *top, int ntop, int *stack, int tid,
                                         float ox, float oy, float oz, float dx, float dy, float dz, float tfar,
                                         float tfar_box, const RayBox &rb, TravState &t, int regroup, int leaf_bias,
-                                        TravCounters &cnt, int stack_cap, bool &overflow) {
+                                        TravCounters &cnt, int stack_cap, bool &overflow, unsigned pool = 0u) {
+    static_assert(!POOL || !LEVELSTACK, "leaf pooling is written for the fast stack discipline");
     const int lane = tid & 63;
     int node = t.node, sp = t.sp, pf = t.pf, pm = t.pm, lq0 = t.lq0, lq1 = t.lq1;
     const int n_entry = __popcll(__ballot(1));   // lanes that entered with a ray
@@ -684,6 +697,9 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
         const int n_leaf = __popcll(m_leaf);
         if (n_node * 16 >= n_leaf * leaf_bias) {
             // ---------------- node step ------------------------------------------------------
+#ifdef HZ_PROBE_Q1
+            if (COUNT) { if (!can_node && node < 0) cnt.blk++; if (!can_node && !can_leaf && !(node < 0)) cnt.fin++; }
+#endif
             if (can_node) {
                 float4 n0; uint4 n1;
                 // NODELET: top-of-tree nodes from LDS, the rest from global memory (two separate asm paths:
@@ -742,11 +758,60 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
             }
         } else {
             // ---------------- leaf step: the two triangles of a DEM quad (or one TIN triangle) ---
-            if (can_leaf) {
+            if (POOL) {
+                // items: lq0 of every lane that has one (in lane order), then the lq1s, as far as the wave has lanes
+                const unsigned long long m1 = __ballot(lq1 < 0);
+                const bool full = __ballot(1) == ~0ull;         // (a wave with lanes masked off -- cells that are finished --
+                                                                //  cannot hand items to them: every lane tests its own lq0)
+                const int r0 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_leaf >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_leaf, 0u));
+                const int r1 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
+                const int slot0 = full ? r0 : lane;
+                const int slot1 = (full ? n_leaf : 64) + r1;
+                const unsigned tabw = pool + (unsigned)(6 * TPB * 4) + (unsigned)(tid & ~63) * 4u;
+                const bool two = (lq1 < 0) & (slot1 < 64);     // this lane's second leaf is an item of this step
+                int e = lane;
+                if (full) {
+                    if (can_leaf) HZ_STACK_AT(tabw + 4u * (unsigned)slot0) = lane;
+                    if (two) HZ_STACK_AT(tabw + 4u * (unsigned)slot1) = lane | 64;
+                    asm volatile("" ::: "memory");
+                    e = HZ_STACK_AT(tabw + 4u * (unsigned)lane);
+                }
+                const int n_items = min(n_leaf + __popcll(m1), 64);
+                const bool mine = full ? (lane < n_items) : can_leaf;
+                const int src = e & 63;
+                int link = lq0;
+                if (full) {
+                    const int l0 = __builtin_amdgcn_ds_bpermute(src << 2, lq0), l1 = __builtin_amdgcn_ds_bpermute(src << 2, lq1);
+                    link = (e & 64) ? l1 : l0;
+                }
+                bool hit = false;
+                if (mine) {
+                    const unsigned ra = pool + (unsigned)((tid & ~63) + src) * 4u;
+                    const float rox = __int_as_float(HZ_STACK_AT(ra)), roy = __int_as_float(HZ_STACK_AT(ra + (unsigned)(TPB * 4)));
+                    const float roz = __int_as_float(HZ_STACK_AT(ra + (unsigned)(2 * TPB * 4))), rdx_ = __int_as_float(HZ_STACK_AT(ra + (unsigned)(3 * TPB * 4)));
+                    const float rdy_ = __int_as_float(HZ_STACK_AT(ra + (unsigned)(4 * TPB * 4))), rdz_ = __int_as_float(HZ_STACK_AT(ra + (unsigned)(5 * TPB * 4)));
+                    float4 q0, q1, q2;
+                    hz_load_prim(prims + HZ_LEAF_ID(link), q0, q1, q2);
+                    if (COUNT) { cnt.tris += (q2.y == q2.y) ? 2 : 1; HZ_WAVE_TICK(cnt.w_leaves, lane); }
+                    hit = hz_quad_hit(rox, roy, roz, rdx_, rdy_, rdz_, tfar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
+                                      q2.x, q2.y, q2.z, q2.w, q2.y == q2.y);
+                }
+                const unsigned long long H = __ballot(hit);
+                const bool h0 = can_leaf & (((H >> slot0) & 1ull) != 0ull);
+                const bool h1 = two & (((H >> (slot1 & 63)) & 1ull) != 0ull);
+                // decided (blocked): lq0 = the NUMBER of the blocking leaf, node and lq1 empty; else the tested places leave the queue
+                const int blk_leaf = h0 ? HZ_LEAF_ID(lq0) : HZ_LEAF_ID(lq1);
+                const bool dec = h0 | h1;
+                const int nq0 = two ? HZ_EMPTY : lq1;
+                if (can_leaf) { lq0 = dec ? blk_leaf : nq0; lq1 = HZ_EMPTY; node = dec ? HZ_EMPTY : node; }
+            } else if (can_leaf) {
                 float4 q0, q1, q2;
                 hz_load_prim(prims + HZ_LEAF_ID(lq0), q0, q1, q2);
                 // a = (q0.x q0.y q0.z) b = (q0.w q1.x q1.y) c = (q1.z q1.w q2.x) d = (q2.y q2.z q2.w)
                 if (COUNT) { cnt.tris += (q2.y == q2.y) ? 2 : 1; HZ_WAVE_TICK(cnt.w_leaves, lane); }
+#ifdef HZ_PROBE_Q1
+                if (COUNT && lq1 < 0) cnt.q1++;
+#endif
                 const bool hit = hz_quad_hit(ox, oy, oz, dx, dy, dz, tfar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
                                              q2.x, q2.y, q2.z, q2.w, q2.y == q2.y);
                 if (hit) { lq0 = HZ_LEAF_ID(lq0); node = HZ_EMPTY; }     // decided: blocked by this leaf

@@ -54,6 +54,7 @@ struct HorizonParams {
                                    // the fast stack reads the rows below its sentinel together with the top (hz_trace)
     const unsigned short *near_idx;   // near-field certificates of this launch's rows (hz_near.hip) or null
     const float *near_r;
+    float *scratch_row;            // COUNT only: null, or the one row every lane stores into instead of its row of `hori` (certificate monitor)
     int verify_near;               // 0: off; else re-trace the shortened rays selected by verify_mask over their full length
     unsigned verify_mask;          //   (power of two - 1: one of every verify_mask + 1 shortened rays; 0: all of them)
     unsigned long long *counters;
@@ -81,6 +82,17 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
 #pragma unroll
     for (int q_ = 0; q_ < HZ_CODE_SHIFT; q_++) asm volatile("s_nop 0");
 #endif
+#ifdef HZ_LEAF_POOL      // experiment (scripts/build_variant.sh pool -DHZ_LEAF_POOL): the leaf step pools the wave's queued leaves (hz_trace POOL)
+    constexpr bool POOLK = !LEVELSTACK;
+#else
+    constexpr bool POOLK = false;
+#endif
+    // POOLK: [ staging | ray pool: 6 rows of HZ_TPB floats (origin, direction of every lane's ray) | item tables: 64 ints per wave | stack ]
+    constexpr int POOL_BYTES = 7 * HZ_TPB * 4;
+    typedef __attribute__((address_space(3))) float hz_lds_float;
+    const unsigned pool = (unsigned)(size_t)reinterpret_cast<hz_lds_float *>(
+                              (__attribute__((address_space(3))) char *)reinterpret_cast<char *>(smem)) + (unsigned)(p.pre_bytes - POOL_BYTES);
+#define HZ_POOL_AT(k) (*reinterpret_cast<hz_lds_float *>((size_t)(pool + (unsigned)((k) * HZ_TPB * 4) + (unsigned)threadIdx.x * 4u)))
     int *stack = reinterpret_cast<int *>(smem + p.pre_bytes);
     const float4 *top = reinterpret_cast<const float4 *>(smem + p.pre_bytes + p.stack_bytes);
     const int tid = threadIdx.x;
@@ -119,9 +131,13 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
     // launch-local cell number: the only per-cell address state kept across the traversal (the output pointer
     // and the certificate row are rebuilt from it at every refill: 1 VGPR instead of 2 + 2)
     const unsigned cert = in_dom ? (unsigned)(i - p.row_begin) * (unsigned)p.dim_in_1 + (unsigned)j : 0u;
-    float *const hori0 = p.hori + (size_t)p.row_begin * p.dim_in_1 * (size_t)t.azim_num;   // first cell of this launch
+    // (the certificate monitor -- a counting launch NEXT TO the production launch, hz_api.hip -- stores into one scratch row: the
+    //  rows of `hori` belong to the production launch)
+    const bool to_scratch = COUNT && p.scratch_row != nullptr;
+    float *const hori0 = to_scratch ? p.scratch_row : p.hori + (size_t)p.row_begin * p.dim_in_1 * (size_t)t.azim_num;   // first cell of this launch
+    const unsigned cell_stride = to_scratch ? 0u : 1u;
     Sink out;
-    out.hori = hori0 + (size_t)cert * (size_t)t.azim_num;
+    out.hori = COUNT ? hori0 + (size_t)(cert * cell_stride) * (size_t)t.azim_num : hori0 + (size_t)cert * (size_t)t.azim_num;
     out.dist = nullptr; out.dist_hit = 0.0f;
     out.stage = reinterpret_cast<float *>(smem) + tid;   // only touched when STAGE
     out.stride = HZ_TPB;
@@ -138,7 +154,8 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
         while (m) {
             const int src = __ffsll((long long)m) - 1;
             m &= m - 1;
-            float *row = hori0 + (size_t)__shfl((int)cert, src) * (size_t)t.azim_num;
+            float *row = COUNT ? hori0 + (size_t)((unsigned)__shfl((int)cert, src) * cell_stride) * (size_t)t.azim_num
+                               : hori0 + (size_t)__shfl((int)cert, src) * (size_t)t.azim_num;
             for (int k = lane; k < t.azim_num; k += 64) row[k] = p.hori_fill;
         }
     }
@@ -157,6 +174,7 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
             r01 = north_x; r02 = norm_x;
             r11 = north_y; r12 = norm_y;
             r21 = north_z; r22 = norm_z;
+            if (POOLK) { HZ_POOL_AT(0) = ox; HZ_POOL_AT(1) = oy; HZ_POOL_AT(2) = oz; }
 #ifdef HZ_V_EAST_REG
             e00 = north_y * norm_z - north_z * norm_y;
             e10 = north_z * norm_x - north_x * norm_z;
@@ -166,7 +184,9 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
     }
     // (the origin in the scene-centred frame is formed from (ox, oy, oz) where it is needed -- three subtractions per ray
     //  instead of three more registers that live through the traversal; the empty asm stops the compiler from hoisting them)
-#define HZ_OC(ocx, ocy, ocz) float ocx, ocy, ocz; { float ax_ = ox, ay_ = oy, az_ = oz; asm volatile("" : "+v"(ax_), "+v"(ay_), "+v"(az_)); \
+#define HZ_OC(ocx, ocy, ocz) float ocx, ocy, ocz; { float ax_, ay_, az_; \
+        if (POOLK) { ax_ = HZ_POOL_AT(0); ay_ = HZ_POOL_AT(1); az_ = HZ_POOL_AT(2); } \
+        else { ax_ = ox; ay_ = oy; az_ = oz; asm volatile("" : "+v"(ax_), "+v"(ay_), "+v"(az_)); } \
         ocx = ax_ - p.sv.cx; ocy = ay_ - p.sv.cy; ocz = az_ - p.sv.cz; }
     const float tfar = p.dist;
 
@@ -175,6 +195,9 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
     s.lim_up = 0; s.lim_low = 0; s.elev_samp = 0; s.ev = 0;
     unsigned rays = 0, guards = 0, w_adv = 0;
     TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.w_nodes = 0; tc.w_leaves = 0;   // COUNT only
+#ifdef HZ_PROBE_Q1
+    tc.q1 = 0; tc.blk = 0; tc.fin = 0;
+#endif
     const unsigned cells_cnt = (in_dom && !done) ? 1u : 0u;
     bool ray_active = false, last_hit = false;
     float dx = 0, dy = 0, dz = 1;
@@ -202,7 +225,7 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
             //  reloads with a full memory wait each: vector-memory instructions are what this kernel is short of)
             unsigned cert_r = cert;
             asm volatile("" : "+v"(cert_r));
-            out.hori = hori0 + (size_t)cert_r * (size_t)t.azim_num;
+            out.hori = COUNT ? hori0 + (size_t)(cert_r * cell_stride) * (size_t)t.azim_num : hori0 + (size_t)cert_r * (size_t)t.azim_num;
             if (advance<ALG, STAGE>(s, last_hit, t, out, guards)) {
                 // local direction (east, north, up) and rotation: horizon_comp.cpp:357-361, :55-62
                 // every load of the new ray is issued before the first one is used: the table entries, and the certificate of
@@ -229,6 +252,7 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
                 dx = (r00 * rx + r01 * ry) + r02 * rz;
                 dy = (r10 * rx + r11 * ry) + r12 * rz;
                 dz = (r20 * rx + r21 * ry) + r22 * rz;
+                if (POOLK) { HZ_POOL_AT(3) = dx; HZ_POOL_AT(4) = dy; HZ_POOL_AT(5) = dz; }
                 tn = (s.ind >= near_i) ? near_rad : p.neg_tau;    // no certificate: the box tests start at -tau (hz_common.h)
                 if (COUNT && tn > 0.0f) shortened++;
                 if (COUNT) want_v = p.verify_near && tn > 0.0f && (((rays + cert) & p.verify_mask) == 0u);
@@ -247,13 +271,17 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
         // ---- traversal (hz_common.h: speculative while-while, one postponed leaf per lane) ------
         bool start_v = false, viol = false;
         if (ray_active) {
-            const int r = hz_trace<HZ_TPB, COUNT, HZ_QLEN, NODELET, LEVELSTACK>(p.sv.nodes, p.sv.prims, top, ntop, stack, tid, ox, oy, oz,
+            int r;
+            if (POOLK) r = hz_trace<HZ_TPB, COUNT, HZ_QLEN, NODELET, LEVELSTACK, POOLK>(p.sv.nodes, p.sv.prims, top, ntop, stack, tid, 0.0f, 0.0f, 0.0f,
+                                                 0.0f, 0.0f, 0.0f, tfar, p.dist_box, rb, ts, p.regroup, p.leaf_bias, tc, p.stack_cap, overflow, pool);
+            else r = hz_trace<HZ_TPB, COUNT, HZ_QLEN, NODELET, LEVELSTACK>(p.sv.nodes, p.sv.prims, top, ntop, stack, tid, ox, oy, oz,
                                                  dx, dy, dz, tfar, p.dist_box, rb, ts, p.regroup, p.leaf_bias, tc, p.stack_cap, overflow);
             if (r == 0 && second) {                      // nothing in the cached subtree: full traversal
                 second = false; hz_trav_reset(ts);
             } else if (COUNT && want_v && r != 2) {
                 // the shortened ray is done: trace it again over its full length and compare the decisions
                 want_v = false; verifying = true; first_result = (r == 1); start_v = true;
+                if (POOLK) { dx = HZ_POOL_AT(3); dy = HZ_POOL_AT(4); dz = HZ_POOL_AT(5); }
                 HZ_OC(ocx, ocy, ocz)
                 rb = hz_raybox(ocx + p.neg_tau * dx, ocy + p.neg_tau * dy, ocz + p.neg_tau * dz, dx, dy, dz);
                 hz_trav_reset(ts);
@@ -305,6 +333,13 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
             atomicAdd(&p.counters[5], wn); atomicAdd(&p.counters[6], wl); atomicAdd(&p.counters[7], wa);
         }
     }
+#ifdef HZ_PROBE_Q1
+    if (COUNT) {
+        unsigned long long a = tc.q1, b = tc.blk, c = tc.fin;
+        for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); c += __shfl_xor(c, off); }
+        if (lane == 0) { atomicAdd(&p.counters[22], a); atomicAdd(&p.counters[23], b); atomicAdd(&p.counters[21], c); }   // (21: the verify tally, unused in this probe)
+    }
+#endif
     if (COUNT) {
         // when did the last wave of each XCD finish?  (counters[12 + xcc] = latest end, counters[20] = ~earliest start, on
         // the 100 MHz real-time counter; HZ_XCD_TRACE=1 prints the spans: the 8 XCDs own fixed regions of the tile)
@@ -385,7 +420,12 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
     // keeps it for the scene.  Shallow trees whose worst case fits never need the second kernel.
     const int stage = ((a.azim_num & 3) == 0 && (reinterpret_cast<size_t>(a.hori) & 15) == 0) ? 4 * HZ_TPB * 4 : 0;
     // (two rows: a lane that has popped its sentinel but still has queued leaves reads the two rows below the stack)
-    const int pre = stage ? stage : 2 * HZ_TPB * 4;
+#ifdef HZ_LEAF_POOL
+    const int pool_bytes = (a.level_stack > 0) ? 0 : 7 * HZ_TPB * 4;      // ray pool + item tables in front of the fast stack
+#else
+    const int pool_bytes = 0;
+#endif
+    const int pre = (stage ? stage : 2 * HZ_TPB * 4) + pool_bytes;
     const int height = std::max(sc->hdr.height, 1);
     // (a.level_stack < 0: test hook, the fast discipline with that many entries)
     // (with the opt-in LDS nodelet the fast stack gives up the entries the nodelet's bytes need, so that 5 workgroups stay resident)
@@ -409,14 +449,16 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
     top = std::min(top, std::max(0, (80 * 1024 - (p.stack_bytes + p.pre_bytes)) / (int)sizeof(Node)));
     top = std::min(top, sc->hdr.n_top);
     p.top_nodes = top;
-    // defaults from the sweep on the 3601^2 tile: refill when fewer than 40 lanes
-    // are traversing; leaf step when 24 n_leaf > 16 n_node.  opts.regroup = threshold | bias << 8.
+    // defaults from the sweep on the 3601^2 tile: refill when fewer than 36 lanes
+    // are traversing (40 until round 5: re-swept after the loop rewrite, profiles/r05/ab_tri_fma_and_regroup_sweep.log: 32 - 36
+    // beat 40 by 1.2 %, 28 and 40 tie, 16 costs 7 %); leaf step when 24 n_leaf > 16 n_node.  opts.regroup = threshold | bias << 8.
     // (<= 0: the default -- a zeroed hz_opts must not switch the ray compaction off: 2.9 s instead of 2.15 s per tile)
-    p.regroup = (a.regroup <= 0) ? 40 : std::min(a.regroup & 0xff, 64);
+    p.regroup = (a.regroup <= 0) ? 36 : std::min(a.regroup & 0xff, 64);
     p.leaf_bias = (a.regroup >= 256) ? (a.regroup >> 8) : 24;      // (20 until round 4: re-swept after the node step lost 18 instructions, profiles/r04/regroup_sweep.log)
     p.hit_cache = (a.hit_cache != 0) ? 1 : 0;
     p.near_idx = a.near_idx; p.near_r = a.near_r;
     p.verify_near = (a.verify_near > 0 && a.near_idx != nullptr) ? 1 : 0;
+    p.scratch_row = a.count_work ? a.scratch_row : nullptr;
     {   // one of every N shortened rays, N rounded up to a power of two (1: all)
         unsigned n = a.verify_near > 1 ? (unsigned)a.verify_near : 1u, m = 1u;
         while (m < n && m < (1u << 30)) m <<= 1;
@@ -581,7 +623,16 @@ __global__ __launch_bounds__(256, HZ_TOPO_WG) void k_topo(const float *__restric
             // hv < atan(x)  <=>  sin < x cos: the tilted plane hides the horizon (:444 takes the larger angle)
             if (!(sn >= (double)xf * cs)) {
                 const float hp = atanf(xf);
-                if (!(hv >= hp)) { he = (double)hp; hz_sincos_halfpi(he, sn, cs); }
+                // Round 5: sine and cosine of the plane's horizon come from its tangent (cos = 1 / sqrt(1 + x^2), sin = x cos) in
+                // float32 -- 5 instructions instead of a second float64 sine / cosine pair (25 float64 instructions that nearly
+                // every wave executed at nearly every azimuth: on sloped terrain some lane always looks uphill).  The value
+                // enters a float32 accumulator (:446) with weight <= 1: a relative 1e-7 here is 1e-7 / azim_num in the result
+                // (the bar is 1e-5; measured against the reference fixtures in tests/test_gpu_prep.py).
+                if (!(hv >= hp)) {
+                    he = (double)hp;
+                    const float rc = __builtin_amdgcn_rsqf(1.0f + xf * xf);
+                    cs = (double)rc; sn = (double)(xf * rc);
+                }
             }
             if (KIND == 0) {
                 agg = (float)((double)agg + ((double)(tx * as + ty * ac) * ((half_pi - he) - sn * cs)

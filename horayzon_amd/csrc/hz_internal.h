@@ -130,6 +130,8 @@ struct HorizonArgs {
     const unsigned short *near_idx;      // near-field certificates of rows [row_begin, row_end) (hz_near.hip) or null
     const float *near_r;
     int verify_near;                     // counting instantiation: N >= 1 re-traces one of every N shortened rays from parameter 0 (1: all)
+    float *scratch_row;                  // counting instantiation only: null, or a device row of azim_num floats that takes EVERY store of the launch instead of
+                                         // `hori` (the certificate monitor runs next to the production launch and must not write its rows)
     unsigned long long *counters;        // device u64[24] + int[HZ_REDO_CAP] (tiles to redo, count in [8]): [0] rays, [1] guards, [2] nodes, [3] tris, [4] cells,
                                          // [5..7] wave iterations, [8] waves whose fast-discipline stack overflowed,
                                          // [9] rays shortened by a certificate, [10] certificate violations (verify), [11] cells with a guard event,

@@ -42,12 +42,13 @@ for rep in range(args.reps):
     t = time.time()
     hori, azim = hz.horizon.horizon_gridded(g["vert_grid"], n, n, vec_norm, vec_north, off, off,
                                             args.dist, azim_num=args.azim, ray_algorithm=args.alg,
-                                            scene=sc, _top_nodes=args.top, _regroup=args.regroup, _hit_cache=args.hit_cache, _near_skip=not args.no_near, _verify_near=(args.verify_sample if args.verify_sample else args.verify_near), count_work=args.count_all or (args.count and rep == args.reps - 1))
+                                            scene=sc, _top_nodes=args.top, _regroup=args.regroup, _hit_cache=args.hit_cache, _near_skip=not args.no_near, _level_stack=(-args.stack if args.stack > 0 else False), _verify_near=(args.verify_sample if args.verify_sample else args.verify_near), count_work=args.count_all or (args.count and rep == args.reps - 1))
     st = hz.horizon.last_stats
     print("rep %d wall %.2fs kernel %.3fs rays %d rays/(cell*az) %.2f Mray/s %.1f cells/s %.0f nodes/ray %.1f tris/ray %.1f"
           % (rep, time.time() - t, st["t_kernel_s"], st["num_rays"], st["num_rays"] / (w * w * args.azim),
              st["num_rays"] / st["t_kernel_s"] / 1e6, w * w / st["t_kernel_s"],
              st["nodes_visited"] / max(st["num_rays"], 1), st["tris_tested"] / max(st["num_rays"], 1)), flush=True)
+    print("      stack redo blocks %d  fallbacks %d" % (st.get("stack_redo_blocks", -1), st.get("stack_fallbacks", -1)), flush=True)
     print("      near pre-pass %.4fs  rays shortened %.3f  violations %d  re-traced %d" % (st["t_near_s"], st["rays_shortened"] / max(st["num_rays"], 1), st["near_violations"], st["near_verified"]), flush=True)
 if args.count or args.count_all:
     print("SIMT efficiency: node step %.3f  leaf step %.3f  refill %.3f   (wave iters: node %.3g leaf %.3g refill %.3g)"

@@ -515,6 +515,19 @@ def test_triangle_test_sensitivity_variants(orc):
         orc.horizon_gridded(**h, dist_search=10.0, azim_num=8, rows=(80, 100), slab_only=True)
         n_e, flips_e = orc.tri_compare_counts()
         assert n_mt == n_e and flips_mt > 100 * max(flips_e, 1)
+        # "plain_fma" -- the CPU side of the product's build-time switch -DHZ_TRI_FMA (tests/test_gpu_tri_fma.py holds the GPU
+        # side to it bit for bit): fused cross / dot products only; it sits as close to the contract as the full Embree variant
+        orc.set_tri_compare("plain_fma")
+        again, _ = orc.horizon_gridded(**kw, **par)
+        n_f, flips_f = orc.tri_compare_counts()
+        orc.set_tri_compare(None)
+        assert np.array_equal(again, base) and n_f == so["rays"] and flips_f <= 5e-6 * n_f + 2, (flips_f, n_f)
+        orc.set_tri_mode("plain_fma")
+        var, _, sv = orc.horizon_gridded(**kw, **par, return_stats=True, mode=orc.MODE_BVH)
+        brute, _, sb = orc.horizon_gridded(**kw, **par, return_stats=True, mode=orc.MODE_BRUTE)
+        orc.set_tri_mode("plain")
+        assert np.array_equal(var, brute) and sv["rays"] == sb["rays"]      # the tree is as transparent for this test as for the contract
+        assert (var != base).mean() <= 1e-4
     finally:
         orc.set_tri_compare(None)
         orc.set_tri_mode("plain")
