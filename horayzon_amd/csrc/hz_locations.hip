@@ -15,7 +15,8 @@ namespace hz {
 
 #define HZ_TPB 256
 #ifndef HZ_LOC_REGROUP
-#define HZ_LOC_REGROUP 40      // refill when fewer lanes than this are still traversing (the gridded kernel's value)
+#define HZ_LOC_REGROUP 16      // refill when fewer lanes than this are still traversing (40, the gridded kernel's value, until round 5; swept 40 ... 16:
+                               // monotonic, -6 % at 16 -- a refill here starts a whole binary search, profiles/r05/ab_shadow_and_locations_thresholds.log)
 #endif
 #ifndef HZ_LOC_FAST_CAP
 #define HZ_LOC_FAST_CAP 27     // entries of the fast stack: (27 + 2) x 1 KiB of LDS per workgroup, 5 resident

@@ -233,7 +233,8 @@ __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
 #define HZ_SHADOW_FAST_CAP_DEFAULT 19   // 21 KiB of LDS per workgroup: 7 resident; round 4: level stack 1.074 -> fast stack 0.964 ms per position at 5 workgroups (profiles/r04/ab_shadow_fast_stack.log)
 #endif
 #ifndef HZ_SHADOW_REGROUP
-#define HZ_SHADOW_REGROUP 40      // refill when fewer lanes than this are still traversing
+#define HZ_SHADOW_REGROUP 16      // refill when fewer lanes than this are still traversing (40 until round 5; re-swept 40 ... 8 after the loop rewrite:
+                                  // 16 - 20 is the flat optimum, -0.5 % without and -7.7 % with refraction, profiles/r05/ab_shadow_and_locations_thresholds.log)
 #endif
 // FAST: the fast stack discipline of hz_trace (every pending sibling its own entry, written for the fewest instructions;
 // `stack_cap` entries behind two padding rows).  A ray that runs out of entries is traced again, to completion, with the

@@ -60,6 +60,12 @@ def test_plain_bench_gpus_2_starts_two_ranks_and_shards_the_tile(tmp_path):
     assert c["gathered_svf_finite"] is True and len(c["t_ranks_s"]) == 2
     assert c["job_s_incl_bcast"] >= d["ms_per_step"] * 1e-3 and c["scene_bcast"] == "blob" and c["scene_bcast_bytes"] == c["scene_bytes"]
     assert d["roofline"]["kernel_ms_per_launch"] > 0
+    # the sharded line carries the one-GPU emulation of its own partition next to what it measured
+    sp = c["scaling_prediction"]
+    assert "error" not in sp, sp
+    assert len(sp["slab_ms_one_gpu"]) == 2 and sp["whole_tile_ms_one_gpu"] > 0
+    assert 0.2 < c["predicted_efficiency"] <= 1.25 and c["predicted_efficiency"] == sp["predicted_efficiency"]
+    assert sp["measured_efficiency_same_run"] > 0
     # one rank through the same sharded code path (HZ_FORCE_DIST) and the plain N = 1 line: the same SVF, bit for bit
     env1 = dict(os.environ, HZ_FORCE_DIST="1", HZ_DIST_BACKEND="gloo", MASTER_ADDR="127.0.0.1", MASTER_PORT="29626")
     dump1 = str(tmp_path / "one.npy")
@@ -77,6 +83,11 @@ def test_plain_bench_gpus_2_starts_two_ranks_and_shards_the_tile(tmp_path):
     d0 = json.loads(r.stdout.strip().splitlines()[-1])
     assert d0["n_gpus"] == 1 and d0["scaling"] == "strong" and d0["config"]["cells_per_step"] == cells
     assert np.array_equal(a, np.load(dump0))
+    # ... whose extras predict the N = 2 / 4 / 8 points of the strong-scaling curve from the slabs timed one by one
+    pr = d0["extras"]["scaling_prediction"]
+    assert "error" not in pr, pr
+    for key, n_r in (("n2", 2), ("n4", 4), ("n8", 8)):
+        assert len(pr[key]["slab_ms"]) == n_r and 0.1 < pr[key]["predicted_efficiency"] <= 1.25
 
 
 def test_plain_bench_gpus_8_world_of_eight_on_one_gpu(tmp_path):
