@@ -5,8 +5,8 @@
  * correctly rounded (0.25 % / 2 % of the arguments this path uses are off by one float ulp, measured by
  * tests/test_oracle.py::test_crmath_*), they come in FMA and non-FMA builds selected at run time, and other
  * platforms ship other routines -- there is no single "reference value" to be bit-equal to.  The contract
- * here is the CORRECTLY ROUNDED float result.  Each function evaluates in float64 with plain + - * / sqrt in
- * a fixed order (both users compile with -ffp-contract=off) to a relative error < 1e-14 and rounds once, so
+ * here is the CORRECTLY ROUNDED float result.  Each function evaluates in float64 with + - * / sqrt and explicit
+ * fused multiply-adds in a fixed order (both users compile with -ffp-contract=off) to a relative error < 1e-14 and rounds once, so
  *   - the HIP kernels and the CPU oracle, which both include this header, agree bit for bit by construction;
  *   - the result is the correctly rounded float except when the exact value lies within 1e-14 (relative) of a
  *     rounding boundary (about 1 argument in 1e7).
@@ -20,6 +20,17 @@
 #define HZ_CRM __host__ __device__ static inline
 #else
 #define HZ_CRM static inline
+#endif
+
+/* Round 5: the polynomial kernels below run their Horner steps as fused multiply-adds (one rounding per step instead of two:
+ * the error bounds stated with each kernel only get smaller; both users -- the HIP kernels and the CPU oracle -- include this
+ * header, so they still agree bit for bit, and tests/test_oracle.py::test_crmath_* check the results against long double). */
+#ifndef HZ_CRM_FMA      /* (-DHZ_CRM_UNFUSED: the two-rounding Horner steps of rounds 2-4, for A/Bs) */
+#ifdef HZ_CRM_UNFUSED
+#define HZ_CRM_FMA(a, b, c) ((a) * (b) + (c))
+#else
+#define HZ_CRM_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#endif
 #endif
 
 #define HZ_CRM_PI_HI 3.141592653589793116      /* double nearest to pi          */
@@ -37,17 +48,17 @@ HZ_CRM double hz_crm_sin_k(double r) {
     double p;
     if (z <= 0.0009765625) {                                 /* |r| <= 2^-5 */
         p = -1.0 / 362880.0;                                   /* -1/9!  */
-        p = p * z + 1.0 / 5040.0;                              /*  1/7!  */
-        p = p * z - 1.0 / 120.0;                               /* -1/5!  */
-        p = p * z + 1.0 / 6.0;                                 /*  1/3!  */
+        p = HZ_CRM_FMA(p, z, 1.0 / 5040.0);                              /*  1/7!  */
+        p = HZ_CRM_FMA(p, z, -1.0 / 120.0);                               /* -1/5!  */
+        p = HZ_CRM_FMA(p, z, 1.0 / 6.0);                                 /*  1/3!  */
         return r - (r * z) * p;
     }
     p = 1.58969099521155010221e-10;
-    p = p * z - 2.50507602534068634195e-08;
-    p = p * z + 2.75573137070700676789e-06;
-    p = p * z - 1.98412698298579493134e-04;
-    p = p * z + 8.33333333332248946124e-03;
-    p = p * z - 1.66666666666666324348e-01;
+    p = HZ_CRM_FMA(p, z, -2.50507602534068634195e-08);
+    p = HZ_CRM_FMA(p, z, 2.75573137070700676789e-06);
+    p = HZ_CRM_FMA(p, z, -1.98412698298579493134e-04);
+    p = HZ_CRM_FMA(p, z, 8.33333333332248946124e-03);
+    p = HZ_CRM_FMA(p, z, -1.66666666666666324348e-01);
     return r + (r * z) * p;
 }
 HZ_CRM double hz_crm_cos_k(double r) {
@@ -55,19 +66,19 @@ HZ_CRM double hz_crm_cos_k(double r) {
     double p;
     if (z <= 0.0009765625) {
         p = -1.0 / 3628800.0;                                  /* -1/10! */
-        p = p * z + 1.0 / 40320.0;                             /*  1/8!  */
-        p = p * z - 1.0 / 720.0;                               /* -1/6!  */
-        p = p * z + 1.0 / 24.0;                                /*  1/4!  */
-        p = p * z - 0.5;                                       /* -1/2!  */
+        p = HZ_CRM_FMA(p, z, 1.0 / 40320.0);                             /*  1/8!  */
+        p = HZ_CRM_FMA(p, z, -1.0 / 720.0);                               /* -1/6!  */
+        p = HZ_CRM_FMA(p, z, 1.0 / 24.0);                                /*  1/4!  */
+        p = HZ_CRM_FMA(p, z, -0.5);                                       /* -1/2!  */
         return 1.0 + z * p;
     }
     p = -1.13596475577881948265e-11;
-    p = p * z + 2.08757232129817482790e-09;
-    p = p * z - 2.75573143513906633035e-07;
-    p = p * z + 2.48015872894767294178e-05;
-    p = p * z - 1.38888888888741095749e-03;
-    p = p * z + 4.16666666666666019037e-02;
-    p = p * z - 0.5;
+    p = HZ_CRM_FMA(p, z, 2.08757232129817482790e-09);
+    p = HZ_CRM_FMA(p, z, -2.75573143513906633035e-07);
+    p = HZ_CRM_FMA(p, z, 2.48015872894767294178e-05);
+    p = HZ_CRM_FMA(p, z, -1.38888888888741095749e-03);
+    p = HZ_CRM_FMA(p, z, 4.16666666666666019037e-02);
+    p = HZ_CRM_FMA(p, z, -0.5);
     return 1.0 + z * p;
 }
 
@@ -91,18 +102,18 @@ HZ_CRM float hz_crm_tanf(float xf) {
 HZ_CRM double hz_crm_asin_k(double t) {
     const double z = t * t;
     double p = 0.034553784590501055;
-    p = p * z - 0.02364695072174073;
-    p = p * z + 0.023283466983300003;
-    p = p * z + 0.0031765613418358813;
-    p = p * z + 0.010889791739128478;
-    p = p * z + 0.011384931937545141;
-    p = p * z + 0.013981803080779488;
-    p = p * z + 0.017351599310672417;
-    p = p * z + 0.022372210988752014;
-    p = p * z + 0.030381943060510043;
-    p = p * z + 0.044642857161844712;
-    p = p * z + 0.074999999999905781;
-    p = p * z + 0.16666666666666666;
+    p = HZ_CRM_FMA(p, z, -0.02364695072174073);
+    p = HZ_CRM_FMA(p, z, 0.023283466983300003);
+    p = HZ_CRM_FMA(p, z, 0.0031765613418358813);
+    p = HZ_CRM_FMA(p, z, 0.010889791739128478);
+    p = HZ_CRM_FMA(p, z, 0.011384931937545141);
+    p = HZ_CRM_FMA(p, z, 0.013981803080779488);
+    p = HZ_CRM_FMA(p, z, 0.017351599310672417);
+    p = HZ_CRM_FMA(p, z, 0.022372210988752014);
+    p = HZ_CRM_FMA(p, z, 0.030381943060510043);
+    p = HZ_CRM_FMA(p, z, 0.044642857161844712);
+    p = HZ_CRM_FMA(p, z, 0.074999999999905781);
+    p = HZ_CRM_FMA(p, z, 0.16666666666666666);
     return t + (t * z) * p;
 }
 
@@ -136,7 +147,7 @@ HZ_CRM double hz_crm_log(double x) {
     const double s = (m - 1.0) / (m + 1.0);
     const double z = s * s;
     double p = 1.0 / 37.0;
-    for (int n = 35; n >= 3; n -= 2) p = p * z + 1.0 / (double)n;
+    for (int n = 35; n >= 3; n -= 2) p = HZ_CRM_FMA(p, z, 1.0 / (double)n);
     const double lm = 2.0 * (s + (s * z) * p);
     return ((double)e * HZ_CRM_LN2_HI + lm) + (double)e * HZ_CRM_LN2_LO;
 }
