@@ -5,8 +5,8 @@
  * correctly rounded (0.25 % / 2 % of the arguments this path uses are off by one float ulp, measured by
  * tests/test_oracle.py::test_crmath_*), they come in FMA and non-FMA builds selected at run time, and other
  * platforms ship other routines -- there is no single "reference value" to be bit-equal to.  The contract
- * here is the CORRECTLY ROUNDED float result.  Each function evaluates in float64 with + - * / sqrt and explicit
- * fused multiply-adds in a fixed order (both users compile with -ffp-contract=off) to a relative error < 1e-14 and rounds once, so
+ * here is the CORRECTLY ROUNDED float result.  Each function evaluates in float64 with plain + - * / sqrt in
+ * a fixed order (both users compile with -ffp-contract=off) to a relative error < 1e-14 and rounds once, so
  *   - the HIP kernels and the CPU oracle, which both include this header, agree bit for bit by construction;
  *   - the result is the correctly rounded float except when the exact value lies within 1e-14 (relative) of a
  *     rounding boundary (about 1 argument in 1e7).
@@ -22,16 +22,32 @@
 #define HZ_CRM static inline
 #endif
 
-/* Round 5: the polynomial kernels below run their Horner steps as fused multiply-adds (one rounding per step instead of two:
- * the error bounds stated with each kernel only get smaller; both users -- the HIP kernels and the CPU oracle -- include this
- * header, so they still agree bit for bit, and tests/test_oracle.py::test_crmath_* check the results against long double). */
-#ifndef HZ_CRM_FMA      /* (-DHZ_CRM_UNFUSED: the two-rounding Horner steps of rounds 2-4, for A/Bs) */
-#ifdef HZ_CRM_UNFUSED
-#define HZ_CRM_FMA(a, b, c) ((a) * (b) + (c))
-#else
+/* Horner steps.  -DHZ_CRM_FUSED (both users, together) runs them as fused multiply-adds: one rounding per step instead of two,
+ * the error bounds stated with each kernel only get smaller.  Measured in round 5 and NOT the default: 35 fewer float64
+ * instructions per cell, but hipcc then keeps the coefficients in registers across the traversal loop of k_shadow_refill --
+ * 105 spilled VGPRs instead of 29 at the 72 registers of 7 workgroups per CU -- and config 4 with refraction got 24 % SLOWER
+ * (1.24 against 0.994 ms per sun position, profiles/r05/ab_crmath_fused_horner.log). */
+#ifndef HZ_CRM_FMA
+#ifdef HZ_CRM_FUSED
 #define HZ_CRM_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#else
+#define HZ_CRM_FMA(a, b, c) ((a) * (b) + (c))
 #endif
 #endif
+
+/* x / c for a CONSTANT c with rc = the double nearest to 1 / c: q = x rc, r = x - c q (exact: one fused multiply-add),
+ * q + r rc (+ the sign of x) -- four instructions instead of the eleven of a float64 division (v_div_scale x 2, v_rcp_f64, four Newton FMAs,
+ * v_mul, v_fma, v_div_fmas, v_div_fixup).  This IS the correctly rounded quotient (Markstein's correction step with a correctly
+ * rounded reciprocal), which is what the reference's `/ 180.0` and `/ M_PI` produce (deg2rad / rad2deg, shadow_comp.cpp:43-62:
+ * float in, double arithmetic).  Only the HIP kernels use it; the oracle divides.  Not taken on trust:
+ * tests/test_oracle.py::test_division_by_a_constant_is_the_ieee_quotient compares it with the IEEE division for EVERY finite
+ * float x (the arguments are floats promoted to double) and both constants.  x = +-inf gives NaN here and +-inf there: the
+ * refraction branch turns either into NaN directions (cos / sin of a non-finite angle) and the same shadow code. */
+HZ_CRM double hz_crm_div_const(double x, double c, double rc) {
+    const double q = x * rc;
+    const double r = __builtin_fma(-c, q, x);
+    return __builtin_copysign(__builtin_fma(r, rc, q), x);     /* (c > 0.  The sign: x = -0 would come out as +0 -- the only float the sweep found) */
+}
 
 #define HZ_CRM_PI_HI 3.141592653589793116      /* double nearest to pi          */
 #define HZ_CRM_PI_LO 1.2246467991473532e-16    /* pi - HZ_CRM_PI_HI             */

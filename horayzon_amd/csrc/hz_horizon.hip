@@ -261,7 +261,18 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
                 hz_trav_reset(ts);
                 // a ray below the previous azimuth's horizon is expected to be blocked near the same ridge
                 second = p.hit_cache && (cache != 0) && (s.ind <= s.pazim) && (s.k > 0);
-                if (second) ts.node = cache;
+                if (second) {
+                    ts.node = cache;
+#ifndef HZ_V_CACHE_RESTART
+                    // Fast stack (round 5): the ROOT waits in entry 1, below the cached subtree.  A cache walk that finds nothing
+                    // pops it and carries on with the full traversal inside hz_trace -- the same node visits and triangle tests
+                    // as leaving the loop with "miss" and coming back with a reset state (which is what `second` still does for
+                    // the level stack, whose entries cannot name the root), but the lane does not idle until its wave leaves.
+                    // Depth: the walk below the cached node needs <= 3 * anc_levels entries above this one, far below the
+                    // root traversal's own maximum, so no launch overflows that did not before.
+                    if (!LEVELSTACK) { ts.sp = 1; stack[HZ_TPB + tid] = 0; second = false; }
+#endif
+                }
                 ray_active = true;
                 rays++;
             } else {

@@ -45,8 +45,19 @@ __device__ __forceinline__ float f_cos(float x) { return hz_crm_cosf(x); }
 __device__ __forceinline__ float f_sin(float x) { return hz_crm_sinf(x); }
 __device__ __forceinline__ float f_pow(float x, float y) { return hz_crm_powf(x, y); }
 
+// shadow_comp.cpp:43-62: float in, double arithmetic, float out.  The divisions by the two constants are the correctly rounded
+// quotients in four instructions each (hz_crmath.h: hz_crm_div_const; -DHZ_V_IEEE_CONST_DIV: plain divisions, for A/Bs)
+#ifdef HZ_V_IEEE_CONST_DIV
 __device__ __forceinline__ float deg2rad_f(float a) { return (float)(((double)a / 180.0) * 3.14159265358979323846); }
 __device__ __forceinline__ float rad2deg_f(float a) { return (float)(((double)a / 3.14159265358979323846) * 180.0); }
+#else
+__device__ __forceinline__ float deg2rad_f(float a) {
+    return (float)(hz_crm_div_const((double)a, 180.0, 1.0 / 180.0) * 3.14159265358979323846);
+}
+__device__ __forceinline__ float rad2deg_f(float a) {
+    return (float)(hz_crm_div_const((double)a, 3.14159265358979323846, 1.0 / 3.14159265358979323846) * 180.0);
+}
+#endif
 
 // shadow_comp.cpp:96-106
 __device__ __forceinline__ void vec_unit(float &x, float &y, float &z) {

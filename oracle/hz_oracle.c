@@ -91,6 +91,24 @@ void orc_crmath_sweep(int which, float lo, float hi, float y, uint64_t *out) {
     }
     out[0] = n; out[1] = bad_d; out[2] = bad_f;
 }
+/* hz_crm_div_const(x, c, RN(1 / c)) (hz_crmath.h: what the HIP kernels evaluate for `/ 180.0` and `/ M_PI`) against the IEEE
+ * division, for every float x whose bit pattern lies in [lo_bits, hi_bits] promoted to double; out[0] = values, out[1] = results
+ * that differ (NaN = NaN) */
+void orc_div_const_sweep(double c, uint32_t lo_bits, uint32_t hi_bits, uint64_t *out) {
+    const double rc = 1.0 / c;
+    uint64_t n = 0, bad = 0;
+#pragma omp parallel for reduction(+ : n, bad)
+    for (int64_t u = (int64_t)lo_bits; u <= (int64_t)hi_bits; u++) {
+        const uint32_t uu = (uint32_t)u;
+        float xf;
+        memcpy(&xf, &uu, 4);
+        const double x = (double)xf;
+        const double a = hz_crm_div_const(x, c, rc), b = x / c;
+        n++;
+        if (memcmp(&a, &b, 8) != 0 && !(a != a && b != b)) bad++;
+    }
+    out[0] = n; out[1] = bad;
+}
 #ifdef _OPENMP
 #include <omp.h>
 #endif

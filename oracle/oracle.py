@@ -156,6 +156,17 @@ def crmath_sweep(which, lo, hi, y=0.0):
     return int(out[0]), int(out[1]), int(out[2])
 
 
+def div_const_sweep(c, lo_bits, hi_bits):
+    """hz_crmath.h's four-instruction division by the constant c > 0 against the IEEE division, for every float whose bit pattern
+    lies in [lo_bits, hi_bits] (promoted to double).  Returns (values, differing results)."""
+    out = np.zeros(2, np.uint64)
+    f = lib().orc_div_const_sweep
+    f.argtypes = [C.c_double, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)]
+    f.restype = None
+    f(float(c), int(lo_bits), int(hi_bits), out.ctypes.data_as(C.POINTER(C.c_uint64)))
+    return int(out[0]), int(out[1])
+
+
 def tables(azim_num, hori_acc, elev_ang_low_lim, dist_search):
     """Trig tables exactly as horizon_comp.cpp:711-731 builds them."""
     L = lib()

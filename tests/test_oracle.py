@@ -354,6 +354,20 @@ def test_crmath_is_the_correctly_rounded_float(orc):
     assert orc.crmath_sweep("pow", 0.0, 0.0, 5.25)[1] == 0
 
 
+def test_division_by_a_constant_is_the_ieee_quotient(orc):
+    """The HIP kernels form deg2rad / rad2deg's `/ 180.0` and `/ M_PI` (shadow_comp.cpp:43-62) as x rc + fma corrections
+    (hz_crmath.h: hz_crm_div_const, four instructions instead of the eleven of a float64 division).  The arguments are floats promoted to
+    double, so the claim "this is the IEEE quotient" is checked for EVERY finite float, both signs, both constants."""
+    import math
+    for c in (180.0, math.pi):
+        for lo, hi in ((0x00000000, 0x7f7fffff), (0x80000000, 0xff7fffff)):     # +0 ... FLT_MAX, -0 ... -FLT_MAX
+            n, bad = orc.div_const_sweep(c, lo, hi)
+            assert n == 0x7f800000 and bad == 0, (c, hex(lo), n, bad)
+        # (NaNs stay NaNs; +-inf gives NaN instead of +-inf -- see the header: no finite angle reaches it)
+        assert orc.div_const_sweep(c, 0x7fc00000, 0x7fc00000) == (1, 0)
+        assert orc.div_const_sweep(c, 0x7f800000, 0x7f800000) == (1, 1)
+
+
 def test_crmath_equals_the_oracles_own_long_double_evaluation(orc):
     """The shared header against the oracle's OWN evaluation of the contract (long double libm rounded once, set_libm(2)):
     same shadow codes and the same sw_dir_cor bits over a day of sun positions on config 2 -- the CPU-side twin of
