@@ -22,16 +22,33 @@
 #define HZ_CRM static inline
 #endif
 
-/* Horner steps.  -DHZ_CRM_FUSED (both users, together) runs them as fused multiply-adds: one rounding per step instead of two,
- * the error bounds stated with each kernel only get smaller.  Measured in round 5 and NOT the default: 35 fewer float64
- * instructions per cell, but hipcc then keeps the coefficients in registers across the traversal loop of k_shadow_refill --
- * 105 spilled VGPRs instead of 29 at the 72 registers of 7 workgroups per CU -- and config 4 with refraction got 24 % SLOWER
- * (1.24 against 0.994 ms per sun position, profiles/r05/ab_crmath_fused_horner.log). */
+/* Horner steps: HZ_CRM_FMA(p, z, c) = p z + c with two roundings (the contract).  HZ_CRM_FMAK is the same step for a coefficient
+ * that is a literal: in the HIP kernels the coefficient is materialised into a scalar register pair AT the step (an empty asm
+ * with an "s" constraint).  hipcc otherwise hoists the ~60 coefficients of the refraction branch out of k_shadow_refill's cell
+ * loop into vector registers that live through the traversal -- 29 spilled VGPRs at the 72 registers of 7 workgroups per CU;
+ * pinned: 1 -- and config 4 with refraction runs 3.6 % faster (140.6 -> 135.5 ms per 144 sun positions,
+ * profiles/r05/ab_crmath_sgpr_pin.log).  Same instructions on the same values: results unchanged (-DHZ_CRM_NO_PIN: off, for A/Bs).
+ *
+ * -DHZ_CRM_FUSED (both users, together) runs the steps as fused multiply-adds: one rounding per step instead of two, the error
+ * bounds stated with each kernel only get smaller.  Measured in round 5 and NOT the default: unpinned it made the spills worse
+ * (105 VGPRs: config 4 with refraction 24 % SLOWER, profiles/r05/ab_crmath_fused_horner.log); pinned (-DHZ_CRM_FUSED
+ * -DHZ_CRM_FUSED_SGPR) it gains another 0.6 % over the pinned two-rounding steps -- not worth a change of the contract. */
 #ifndef HZ_CRM_FMA
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(HZ_CRM_NO_PIN)
+#define HZ_CRM_PINNED(c_) asm volatile("" : "+s"(c_))
+#else
+#define HZ_CRM_PINNED(c_) ((void)0)
+#endif
 #ifdef HZ_CRM_FUSED
 #define HZ_CRM_FMA(a, b, c) __builtin_fma((a), (b), (c))
+#if defined(HZ_CRM_FUSED_SGPR)
+#define HZ_CRM_FMAK(a, b, c) ({ double c_ = (c); HZ_CRM_PINNED(c_); __builtin_fma((a), (b), c_); })
+#else
+#define HZ_CRM_FMAK(a, b, c) __builtin_fma((a), (b), (c))
+#endif
 #else
 #define HZ_CRM_FMA(a, b, c) ((a) * (b) + (c))
+#define HZ_CRM_FMAK(a, b, c) ({ double c_ = (c); HZ_CRM_PINNED(c_); (a) * (b) + c_; })
 #endif
 #endif
 
@@ -64,17 +81,17 @@ HZ_CRM double hz_crm_sin_k(double r) {
     double p;
     if (z <= 0.0009765625) {                                 /* |r| <= 2^-5 */
         p = -1.0 / 362880.0;                                   /* -1/9!  */
-        p = HZ_CRM_FMA(p, z, 1.0 / 5040.0);                              /*  1/7!  */
-        p = HZ_CRM_FMA(p, z, -1.0 / 120.0);                               /* -1/5!  */
-        p = HZ_CRM_FMA(p, z, 1.0 / 6.0);                                 /*  1/3!  */
+        p = HZ_CRM_FMAK(p, z, 1.0 / 5040.0);                              /*  1/7!  */
+        p = HZ_CRM_FMAK(p, z, -1.0 / 120.0);                               /* -1/5!  */
+        p = HZ_CRM_FMAK(p, z, 1.0 / 6.0);                                 /*  1/3!  */
         return r - (r * z) * p;
     }
     p = 1.58969099521155010221e-10;
-    p = HZ_CRM_FMA(p, z, -2.50507602534068634195e-08);
-    p = HZ_CRM_FMA(p, z, 2.75573137070700676789e-06);
-    p = HZ_CRM_FMA(p, z, -1.98412698298579493134e-04);
-    p = HZ_CRM_FMA(p, z, 8.33333333332248946124e-03);
-    p = HZ_CRM_FMA(p, z, -1.66666666666666324348e-01);
+    p = HZ_CRM_FMAK(p, z, -2.50507602534068634195e-08);
+    p = HZ_CRM_FMAK(p, z, 2.75573137070700676789e-06);
+    p = HZ_CRM_FMAK(p, z, -1.98412698298579493134e-04);
+    p = HZ_CRM_FMAK(p, z, 8.33333333332248946124e-03);
+    p = HZ_CRM_FMAK(p, z, -1.66666666666666324348e-01);
     return r + (r * z) * p;
 }
 HZ_CRM double hz_crm_cos_k(double r) {
@@ -82,19 +99,19 @@ HZ_CRM double hz_crm_cos_k(double r) {
     double p;
     if (z <= 0.0009765625) {
         p = -1.0 / 3628800.0;                                  /* -1/10! */
-        p = HZ_CRM_FMA(p, z, 1.0 / 40320.0);                             /*  1/8!  */
-        p = HZ_CRM_FMA(p, z, -1.0 / 720.0);                               /* -1/6!  */
-        p = HZ_CRM_FMA(p, z, 1.0 / 24.0);                                /*  1/4!  */
-        p = HZ_CRM_FMA(p, z, -0.5);                                       /* -1/2!  */
+        p = HZ_CRM_FMAK(p, z, 1.0 / 40320.0);                             /*  1/8!  */
+        p = HZ_CRM_FMAK(p, z, -1.0 / 720.0);                               /* -1/6!  */
+        p = HZ_CRM_FMAK(p, z, 1.0 / 24.0);                                /*  1/4!  */
+        p = HZ_CRM_FMAK(p, z, -0.5);                                       /* -1/2!  */
         return 1.0 + z * p;
     }
     p = -1.13596475577881948265e-11;
-    p = HZ_CRM_FMA(p, z, 2.08757232129817482790e-09);
-    p = HZ_CRM_FMA(p, z, -2.75573143513906633035e-07);
-    p = HZ_CRM_FMA(p, z, 2.48015872894767294178e-05);
-    p = HZ_CRM_FMA(p, z, -1.38888888888741095749e-03);
-    p = HZ_CRM_FMA(p, z, 4.16666666666666019037e-02);
-    p = HZ_CRM_FMA(p, z, -0.5);
+    p = HZ_CRM_FMAK(p, z, 2.08757232129817482790e-09);
+    p = HZ_CRM_FMAK(p, z, -2.75573143513906633035e-07);
+    p = HZ_CRM_FMAK(p, z, 2.48015872894767294178e-05);
+    p = HZ_CRM_FMAK(p, z, -1.38888888888741095749e-03);
+    p = HZ_CRM_FMAK(p, z, 4.16666666666666019037e-02);
+    p = HZ_CRM_FMAK(p, z, -0.5);
     return 1.0 + z * p;
 }
 
@@ -118,18 +135,18 @@ HZ_CRM float hz_crm_tanf(float xf) {
 HZ_CRM double hz_crm_asin_k(double t) {
     const double z = t * t;
     double p = 0.034553784590501055;
-    p = HZ_CRM_FMA(p, z, -0.02364695072174073);
-    p = HZ_CRM_FMA(p, z, 0.023283466983300003);
-    p = HZ_CRM_FMA(p, z, 0.0031765613418358813);
-    p = HZ_CRM_FMA(p, z, 0.010889791739128478);
-    p = HZ_CRM_FMA(p, z, 0.011384931937545141);
-    p = HZ_CRM_FMA(p, z, 0.013981803080779488);
-    p = HZ_CRM_FMA(p, z, 0.017351599310672417);
-    p = HZ_CRM_FMA(p, z, 0.022372210988752014);
-    p = HZ_CRM_FMA(p, z, 0.030381943060510043);
-    p = HZ_CRM_FMA(p, z, 0.044642857161844712);
-    p = HZ_CRM_FMA(p, z, 0.074999999999905781);
-    p = HZ_CRM_FMA(p, z, 0.16666666666666666);
+    p = HZ_CRM_FMAK(p, z, -0.02364695072174073);
+    p = HZ_CRM_FMAK(p, z, 0.023283466983300003);
+    p = HZ_CRM_FMAK(p, z, 0.0031765613418358813);
+    p = HZ_CRM_FMAK(p, z, 0.010889791739128478);
+    p = HZ_CRM_FMAK(p, z, 0.011384931937545141);
+    p = HZ_CRM_FMAK(p, z, 0.013981803080779488);
+    p = HZ_CRM_FMAK(p, z, 0.017351599310672417);
+    p = HZ_CRM_FMAK(p, z, 0.022372210988752014);
+    p = HZ_CRM_FMAK(p, z, 0.030381943060510043);
+    p = HZ_CRM_FMAK(p, z, 0.044642857161844712);
+    p = HZ_CRM_FMAK(p, z, 0.074999999999905781);
+    p = HZ_CRM_FMAK(p, z, 0.16666666666666666);
     return t + (t * z) * p;
 }
 
