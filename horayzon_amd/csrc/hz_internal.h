@@ -13,9 +13,11 @@
 
 #define HZ_MAX_TOP_NODES 2047   // upper bound of BFS-ordered top nodes (LDS staging)
 #define HZ_MAX_STACK 40         // tree levels (= LDS stack entries per lane) the traversal kernels accept
-// hit cache: levels between a leaf and its cached ancestor (measured 1..9 on the 3601^2 tile: 5-6 best)
+// hit cache: levels between a leaf and its cached ancestor.  Measured 1..9 on the 3601^2 tile in round 1 (5-6 best) and again in
+// round 5 after a cache walk that finds nothing stopped costing a trip through the caller (hz_horizon.hip: the root waits below the
+// cached subtree): 3 and 4 tie, 0.7 % ahead of 5, 6 loses 1.6 %; discrete_sampling +7 % with 4 (profiles/r05/sweep_regroup_anc_after_cache_fix.log)
 #ifndef HZ_ANC_LEVELS
-#define HZ_ANC_LEVELS 5
+#define HZ_ANC_LEVELS 4
 #endif
 
 namespace hz {

@@ -73,7 +73,7 @@ __device__ __forceinline__ float o2f(int i) { return __int_as_float(i >= 0 ? i :
 template <int W>
 __host__ __device__ constexpr int near_per_wave_words(int A) {
     constexpr int NV = 2 * W + 1, NVERT = NV * NV, NEDGE = 2 * NV * (NV - 1) + (NV - 1) * (NV - 1);
-    return NVERT * 5 + A + 4 + 2 * NEDGE + NEDGE + 1 + 10 * NEDGE + HZ_NEAR_MAXT / 4;
+    return NVERT * 5 + NVERT * 3 + A + 4 + 2 * NEDGE + NEDGE + 1 + 8 * NEDGE + HZ_NEAR_MAXT / 4;
 }
 
 template <int W>
@@ -82,17 +82,18 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
     constexpr int NHOR = NV * (NV - 1), NDIAG = (NV - 1) * (NV - 1), NEDGE = 2 * NHOR + NDIAG;
     constexpr int NSEG = 8 * W;        // boundary segments of the window polygon
     static_assert(NVERT <= 64 && NSEG <= 64, "one lane per window vertex / boundary segment");
-    constexpr int NEC = 10;            // per-edge constants kept in LDS: a_e a_n a_z b_e b_n b_z r_a r_b x_a x_b
+    constexpr int NEC = 8;             // per-edge constants kept in LDS: a_e a_n a_z b_e b_n b_z r_a r_b
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_near[];
     const int A = p.azim_num;
     // LDS: [ (sin phi_k, cos phi_k) pairs : 2 A floats, shared ] then per wave
-    //      [ q: NVERT x 5 | E: A | flags: 4 | first azimuth bin, bins per edge: 2 NEDGE | task prefix: NEDGE + 1 |
+    //      [ q: NVERT x 5 | vp: NVERT x 3 | E: A | flags: 4 | first azimuth bin, bins per edge: 2 NEDGE | task prefix: NEDGE + 1 |
     //        edge constants: NEC x NEDGE | task -> edge map: HZ_NEAR_MAXT bytes ]
     const int per_wave = near_per_wave_words<W>(A);
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     float *tab = reinterpret_cast<float *>(smem_near);
     float *q = tab + 2 * A + (size_t)wave * per_wave;               // [NVERT][5]: e, n, z, world dx, dy
-    int *E = reinterpret_cast<int *>(q + NVERT * 5);                // [A]
+    float *vp = q + NVERT * 5;                                      // [NVERT][3]: horizontal distance r, azimuth, bound x of the vertex seen in a plane
+    int *E = reinterpret_cast<int *>(vp + NVERT * 3);               // [A]
     int *flags = E + A;                                             // [0]: certificate unusable
     int *ek = flags + 4;                                            // [NEDGE][2]
     int *pre = ek + 2 * NEDGE;                                      // [NEDGE + 1]
@@ -115,10 +116,22 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
         const int a = lane / NV - W, b = lane % NV - W;
         const float *w = p.verts + 3 * ((size_t)(gi + a) * p.d1 + (size_t)(gj + b));
         const float rx = w[0] - ox, ry = w[1] - oy, rz = w[2] - oz;
-        q[5 * lane + 0] = (rx * ex + ry * ey) + rz * ez;
-        q[5 * lane + 1] = (rx * tx + ry * ty) + rz * tz;
-        q[5 * lane + 2] = (rx * nx + ry * ny) + rz * nz;
+        const float qe = (rx * ex + ry * ey) + rz * ez, qn = (rx * tx + ry * ty) + rz * tz, qz = (rx * nx + ry * ny) + rz * nz;
+        q[5 * lane + 0] = qe;
+        q[5 * lane + 1] = qn;
+        q[5 * lane + 2] = qz;
         q[5 * lane + 3] = rx; q[5 * lane + 4] = ry;
+        // Polar form of the vertex, once per vertex (round 5; rounds 2-4 formed it per edge end, i.e. ~4 times): horizontal
+        // distance, azimuth clockwise from north, and the bound of z / r for a vertex that lies IN a half-plane (|d| <= tol):
+        // it is then seen at r in [r sqrt(1 - (tol / r)^2), r], the larger of z / r over that range (tol / r <= 0.126
+        // because the azimuth tolerance of its edges is <= 0.25).  Vertices within 1 mm of the axis: refused by their edges.
+        const float vr = __builtin_sqrtf(qe * qe + qn * qn);
+        float vx = 0.0f;
+        if (vr > 1.0e-3f) {
+            const float vt = (1.0e-3f * vr + 0.01f) / vr;
+            vx = qz > 0.0f ? qz / (vr * __builtin_sqrtf(1.0f - vt * vt)) : qz / vr;
+        }
+        vp[3 * lane + 0] = vr; vp[3 * lane + 1] = atan2f(qe, qn); vp[3 * lane + 2] = vx;
     }
     // HZ_BLOB_BAD_MAP (hz_common.h): the distance bound near_r (row R of DESIGN.md section 4.3) holds for this cell if no
     // bad quad and no TIN triangle projects into the window's (x, y) bounding box.  Those have marked the scene's coarse
@@ -183,11 +196,11 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
             if (ia != CENTRE && ib != CENTRE) {                      // spokes: see the header
                 const float ae = q[5 * ia], an = q[5 * ia + 1], az = q[5 * ia + 2];
                 const float be = q[5 * ib], bn = q[5 * ib + 1], bz = q[5 * ib + 2];
-                const float ra = __builtin_sqrtf(ae * ae + an * an), rb = __builtin_sqrtf(be * be + bn * bn);
+                const float ra = vp[3 * ia], rb = vp[3 * ib];
                 const float rmin = __builtin_fminf(ra, rb);
                 if (!(rmin > 1.0e-3f)) atomicOr(&flags[0], HZ_NR_VERTEX_ON_AXIS);                 // a vertex (almost) above / below the origin
                 else {
-                    const float pa = atan2f(ae, an), pb = atan2f(be, bn);   // azimuth clockwise from north
+                    const float pa = vp[3 * ia + 1], pb = vp[3 * ib + 1];   // azimuth clockwise from north
                     float dl = pb - pa;
                     if (dl > 3.14159265f) dl -= 6.2831853f;
                     if (dl < -3.14159265f) dl += 6.2831853f;
@@ -201,13 +214,8 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
                         else {
                             k_lo = (int)__builtin_floorf((lo - m_az) / dphi);
                             bins = (int)__builtin_ceilf((lo + span + m_az) / dphi) - k_lo + 1;
-                            // an end point that lies in the plane (|d| <= tol) is seen at r in [r sqrt(1 - (tol / r)^2), r]:
-                            // the larger of z / r over that range, once per edge (tol / r <= 0.126 because m_az <= 0.25)
-                            const float ta = (1.0e-3f * ra + 0.01f) / ra, tb = (1.0e-3f * rb + 0.01f) / rb;
                             float *c = ec + NEC * e;
                             c[0] = ae; c[1] = an; c[2] = az; c[3] = be; c[4] = bn; c[5] = bz; c[6] = ra; c[7] = rb;
-                            c[8] = az > 0.0f ? az / (ra * __builtin_sqrtf(1.0f - ta * ta)) : az / ra;
-                            c[9] = bz > 0.0f ? bz / (rb * __builtin_sqrtf(1.0f - tb * tb)) : bz / rb;
                         }
                     }
                 }
@@ -245,7 +253,6 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
             const int e = (int)tmap[c];
             const float *cc = ec + NEC * e;
             const float ae = cc[0], an = cc[1], az = cc[2], be = cc[3], bn = cc[4], bz = cc[5], ra = cc[6], rb = cc[7];
-            const float xa = cc[8], xb = cc[9];
             const float rmin = __builtin_fminf(ra, rb);
             const float tol_a = 1.0e-3f * ra + 0.01f, tol_b = 1.0e-3f * rb + 0.01f;
             const int first = ek[2 * e] + (c - pre[e]) * CH, last = min(first + CH, ek[2 * e] + ek[2 * e + 1]);
@@ -264,9 +271,8 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
                 const float sp = sc.x, cp = sc.y;
                 const float da = ae * cp - an * sp, db = be * cp - bn * sp;     // signed distances from the plane
                 const float fa = ae * sp + an * cp, fb = be * sp + bn * cp;     // along the azimuth (r of the end points)
-                const bool in_a = __builtin_fabsf(da) <= tol_a, in_b = __builtin_fabsf(db) <= tol_b;
-                float cand = (in_a && fa > 0.5f * ra) ? xa : ninf;
-                cand = __builtin_fmaxf(cand, (in_b && fb > 0.5f * rb) ? xb : ninf);
+                // (end points that lie IN the plane -- within the tolerance -- bound themselves: the vertex phase below)
+                float cand = ninf;
                 if ((da < 0.0f) != (db < 0.0f)) {
                     // The edge crosses the plane at parameter t = da / (da - db).  da and db are differences of two
                     // rounded products: |error| <= 4 * 2^-24 * r each, so |t - t_exact| <= dt (first order, a factor 1.6 in
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
                     const float dt = 4.0e-7f * r_big * __builtin_fabsf(rden) + 1.0e-6f;
                     if (!(dt <= 0.1f)) {
                         // both end points within rounding of the plane: the edge lies IN it; its end-point values bound it
-                        if (!(in_a && in_b)) atomicOr(&flags[0], HZ_NR_INPLANE_EDGE);
+                        if (!(__builtin_fabsf(da) <= tol_a && __builtin_fabsf(db) <= tol_b)) atomicOr(&flags[0], HZ_NR_INPLANE_EDGE);
                     } else {
                         const float t = da * rden, df = fb - fa;
                         const float r = fa + t * df, z = az + t * dz;
@@ -295,6 +301,29 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
                     }
                 }
                 if (cand > ninf) atomicMax(&E[k], f2o(cand));
+            }
+        }
+        // ---- vertices: a window vertex that lies IN the half-plane of azimuth k (|d| <= 1e-3 r + 1 cm: the sign tests of the
+        // crossings above cannot be trusted for it) on the ray's side of the axis bounds itself.  One lane per vertex, the few
+        // bins within the azimuth tolerance of the vertex (2e-3 + 0.02 / r >= 2 asin(tol / r): every bin in which the test can
+        // hold).  Rounds 2-4 ran this test for both end points of every edge in every bin of the edge: the same (vertex, bin)
+        // pairs pass -- the bins of an edge cover the tolerance of its end points -- at ~10 of the edge loop's 52 VALU instructions.
+        if (lane < NVERT && lane != CENTRE) {
+            const float ve = q[5 * lane], vn = q[5 * lane + 1];
+            const float vr = vp[3 * lane], pv = vp[3 * lane + 1], vx = vp[3 * lane + 2];
+            const float m_v = 2.0e-3f + 0.02f / vr;
+            if (vr > 1.0e-3f && !(m_v > 0.25f)) {       // (else: its edges have refused the cell)
+                const float tol = 1.0e-3f * vr + 0.01f, half_r = 0.5f * vr;
+                const int k0 = (int)__builtin_floorf((pv - m_v) / dphi), k1 = (int)__builtin_ceilf((pv + m_v) / dphi);
+                int k = k0;                                          // in (-A, 2 A): wrapped once, then stepped
+                if (k < 0) k += A;
+                if (k >= A) k -= A;
+                for (int kk = k0; kk <= k1; kk++, k = (k + 1 == A) ? 0 : k + 1) {
+#pragma clang fp contract(fast)
+                    const float2 sc = reinterpret_cast<const float2 *>(tab)[k];
+                    const float d = ve * sc.y - vn * sc.x, f = ve * sc.x + vn * sc.y;
+                    if (__builtin_fabsf(d) <= tol && f > half_r) atomicMax(&E[k], f2o(vx));
+                }
             }
         }
     }
