@@ -148,7 +148,7 @@ static int check_geom(const char *s) {
 
 // ---- stream pool --------------------------------------------------------------------------------
 // Streams are taken from a per-device pool and go back to it; the library NEVER calls hipStreamDestroy.
-// Reason (root cause of the "stray element" of round 1): with the HIP runtime of
+// Reason (root cause of the "stray element" of round 1, DESIGN_HISTORY.md section 2): with the HIP runtime of
 // ROCm 7.0 (libamdhip64 as bundled with PyTorch 2.10+rocm7.0) hipStreamDestroy() frees the ~920-byte stream
 // object while a completion callback of that stream can still be pending on the ROCr async-events thread;
 // the callback then decrements a counter at offset 152 and stores a 32-bit zero at offset 888 of the FREED

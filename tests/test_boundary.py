@@ -288,7 +288,7 @@ def test_row_slabs_balanced():
 
 def test_library_never_destroys_a_stream():
     """hipStreamDestroy of the ROCm 7.0 HIP runtime can free a stream object that a pending completion callback
-    still writes to: the library pools streams instead, so the symbol must not even be
+    still writes to (DESIGN_HISTORY.md section 2): the library pools streams instead, so the symbol must not even be
     imported."""
     import subprocess
     from horayzon_amd import _lib
