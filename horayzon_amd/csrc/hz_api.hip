@@ -348,7 +348,7 @@ struct NearMonitor {
         int rc;
         if (!st_mon && (rc = stream_acquire(device, &st_mon))) return rc;
         if (!ready) { HZ_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming)); HZ_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming)); }
-        const size_t cbytes = 24 * sizeof(unsigned long long) + HZ_REDO_CAP * sizeof(int);
+        const size_t cbytes = HZ_CNT_N * sizeof(unsigned long long) + HZ_REDO_CAP * sizeof(int);
         const size_t row_bytes = ((size_t)a.azim_num * sizeof(float) + 255) & ~(size_t)255;     // the scratch row its stores go to
         const size_t need = cbytes + row_bytes + pick.size() * sizeof(int);
         if (need > buf_bytes) {                               // (allocated once per call: the chunks of a call pick about as many blocks)
@@ -375,7 +375,7 @@ struct NearMonitor {
     }
     // the production stream waits for the monitor (later kernels read the rows it rewrote); tallies are added up
     int collect(hipStream_t st, unsigned long long *verified, unsigned long long *violations) {
-        unsigned long long c2[24] = {0};
+        unsigned long long c2[HZ_CNT_N] = {0};
         HZ_HIP(hipStreamWaitEvent(st, done, 0));
         HZ_HIP(hipMemcpyAsync(c2, cnt, sizeof(c2), hipMemcpyDeviceToHost, st_mon));
         HZ_HIP(hipStreamSynchronize(st_mon));
@@ -526,7 +526,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         if ((rc = d_azim.bind(azim_h.data(), (size_t)azim_num, st))) return rc;
     }
     DevIn<unsigned long long> d_cnt;
-    unsigned long long zeros[24] = {0};      // counters; behind them the list of tiles to redo (hz_horizon.hip)
+    unsigned long long zeros[HZ_CNT_N] = {0};      // counters; behind them the list of tiles to redo (hz_horizon.hip)
     void *cnt_dev = nullptr;
     HZ_HIP(hipMalloc(&cnt_dev, sizeof(zeros) + HZ_REDO_CAP * sizeof(int)));
     d_cnt.owned = cnt_dev;
@@ -716,7 +716,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
                     fallbacks++;
                     a.level_stack = 1;
                     if (ov <= HZ_REDO_CAP && ov * 4 <= tiles) {
-                        a.tile_list = reinterpret_cast<const int *>((unsigned long long *)cnt_dev + 24);
+                        a.tile_list = reinterpret_cast<const int *>((unsigned long long *)cnt_dev + HZ_CNT_N);
                         a.n_list = (int)ov;
                         redo_blocks += ov;
                         rc = horizon_launch(sc, a, st, &safe);
@@ -738,7 +738,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             (void)hipEventRecord(e.c, st);
             if (!rc && stream_out && n_chunk >= 1) rc = copy_out(n_chunk - 1);
             if (rc) return fail(rc);
-            unsigned long long c[24];
+            unsigned long long c[HZ_CNT_N];
             if (hipMemcpyAsync(c, cnt_dev, sizeof(c), hipMemcpyDeviceToHost, st) != hipSuccess ||
                 hipStreamSynchronize(st) != hipSuccess)
                 return fail(set_error(HZ_ERR_HIP, "horizon kernel failed: %s", hipGetErrorString(hipGetLastError())));

@@ -61,6 +61,8 @@ struct HorizonParams {
     const int *tile_list;          // null, or the n_list blocks (workgroup number * 4 + wave, of the full launch) to repeat
     int n_list;
     int *redo_list;                // !LEVELSTACK: waves whose stack overflowed append their block here (count: counters[8])
+    int persist;                   // 1: persistent waves -- the launch has as many workgroups as are resident at once and every WAVE pulls 8 x 8
+    unsigned *queue;               //    blocks from the queue of its XCD (queue[x] = blocks of XCD x handed out so far) until all are empty
 };
 
 // LDS: [ per-lane stacks int[depth][256] | output staging float[4][256] | top-of-tree nodelet Node[top_nodes] ]
@@ -76,7 +78,21 @@ template <int ALG, bool COUNT, bool STAGE, bool NODELET, bool LEVELSTACK>
 #ifndef HZ_WG_PER_CU
 #define HZ_WG_PER_CU 5     // resident workgroups per CU the register allocation is held to (6: 80 VGPRs, measured slower)
 #endif
-__global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) void k_horizon(HorizonParams p) {
+__global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) void k_horizon(HorizonParams p_arg) {
+    // The parameters are read through the kernel-argument segment (constant address space: scalar loads), and -- see the block loop
+    // below -- through a pointer the compiler cannot see through at the top of every pass: with the plain by-value argument every
+    // parameter load and everything derived from parameters only was hoisted out of the block loop and then lived through the
+    // traversal loop (66 spilled SGPRs, 25 v_readlane per node / leaf step, 7 VGPRs in scratch; one block per launch: 15 / 0 / 0).
+    typedef const __attribute__((address_space(4))) HorizonParams *hz_kparams;
+    hz_kparams pk = (hz_kparams)__builtin_amdgcn_kernarg_segment_ptr();
+    // (the host pass of hipcc only parses this body; it has no constant address space to copy from)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define HZ_LOAD_PARAMS(dst) dst = *pk
+#else
+#define HZ_LOAD_PARAMS(dst) dst = p_arg
+#endif
+    HorizonParams p;
+    HZ_LOAD_PARAMS(p);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 #ifdef HZ_CODE_SHIFT   // measurement probe: moves everything below by 4 * HZ_CODE_SHIFT bytes (does the position of the traversal loop matter?)
 #pragma unroll
@@ -106,10 +122,38 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
 
     // wave -> 8 x 8 block of cells: quadrant `wave` of the tile of workgroup blockIdx.x, or -- in a launch that repeats
     // blocks whose fast stack overflowed -- the block the list names (entry = workgroup number * 4 + quadrant)
-    int ti = 0, tj = 0;
     const int wave = tid >> 6, lane = tid & 63;
+    // Persistent waves (round 5, p.persist): a workgroup's slot -- its LDS -- is only free again when the SLOWEST of its four waves
+    // has finished its block, so with one tile per workgroup 6 - 9 % of the wave slots stood empty in the middle of a launch
+    // (profiles/r05/wg_trace_wpb4_slab447.json: wave lifetimes 29 ... 38 ms around a mean of 33).  Now the launch has only as many
+    // workgroups as are resident at once, and every wave, on its own, pulls the next 8 x 8 block from the queue of the XCD it
+    // runs on (the order inside an XCD is the order of the tile map: the waves resident on an XCD still work on one compact
+    // piece of the DEM), then from the other XCDs' queues.  A block is computed exactly as before: results cannot change.
+    const int xcc_own = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);      // HW_REG_XCC_ID, bits 3:0
+    int xcc_off = 0;                 // queues xcc_own .. xcc_own + xcc_off - 1 (mod 8) were found empty
+  for (;;) {                         // one 8 x 8 block per pass (exactly one pass without p.persist)
+    asm volatile("" : "+s"(pk));
+    HZ_LOAD_PARAMS(p);
+    // (what the traversal loop and the refill read stays in registers: the compiler would otherwise re-load these from the
+    //  argument segment INSIDE those loops -- an s_load and its wait in front of every vote)
+#define HZ_KEEP(x) asm volatile("" : "+s"(x))
+    HZ_KEEP(p.leaf_bias); HZ_KEEP(p.regroup); HZ_KEEP(p.neg_tau); HZ_KEEP(p.sv.cx); HZ_KEEP(p.sv.cy); HZ_KEEP(p.sv.cz);
+    HZ_KEEP(p.near_idx); HZ_KEEP(p.near_r);
+#undef HZ_KEEP
+    int ti = 0, tj = 0;
     int blk = (int)blockIdx.x * HZ_WPB + wave;
-    if (p.tile_list) blk = (blk < p.n_list) ? p.tile_list[blk] : -1;
+    if (p.persist) {
+        blk = -1;
+        while (xcc_off < 8) {
+            const int x = (xcc_own + xcc_off) & 7;
+            int q = 0;
+            if (lane == 0) q = (int)atomicAdd(&p.queue[x], 1u);
+            q = __builtin_amdgcn_readfirstlane(q);
+            if (q < p.tm.per_xcd * 4) { blk = (((q >> 2) * 8 + x) << 2) | (q & 3); break; }
+            xcc_off++;
+        }
+        if (blk < 0) break;
+    } else if (p.tile_list) blk = (blk < p.n_list) ? p.tile_list[blk] : -1;
     else if (HZ_WPB != 4) {
         // fewer than 4 waves per workgroup: the 4 / HZ_WPB workgroups of one tile follow each other ON THE SAME XCD
         // (workgroup b runs on XCD b % 8), so the tile -> XCD mapping is that of the 4-wave kernel
@@ -309,8 +353,8 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
     }
 
 #ifdef HZ_WG_TRACE
-    if (lane == 0 && hz_wg_trace_buf != nullptr && !p.tile_list) {
-        const size_t w = (size_t)blockIdx.x * HZ_WPB + wave;
+    if (lane == 0 && hz_wg_trace_buf != nullptr && !p.tile_list && blk >= 0) {
+        const size_t w = (size_t)blk;
         hz_wg_trace_buf[2 * w] = trace_t0;
         hz_wg_trace_buf[2 * w + 1] = (unsigned long long)wall_clock64() | ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) << 60);
     }
@@ -327,13 +371,13 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
     }
     // !LEVELSTACK: a wave in which a ray ran out of stack entries does not count; its block is computed again by the
     // one-entry-per-level kernel (horizon_run), which overwrites everything this wave wrote
-    if (!LEVELSTACK && __ballot(overflow) != 0ull) {
+    const bool wave_overflowed = !LEVELSTACK && __ballot(overflow) != 0ull;
+    if (wave_overflowed) {
         if (lane == 0) {
             const unsigned long long slot = atomicAdd(&p.counters[8], 1ull);
             if (slot < (unsigned long long)HZ_REDO_CAP) p.redo_list[slot] = blk;
         }
-        return;
-    }
+    } else {
     const int guard_cells = __popcll(__ballot(guards != 0u));   // cells where the reference's search would not terminate
     if (lane == 0) {
         if (r) atomicAdd(&p.counters[0], r);
@@ -369,12 +413,37 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
             if (w_verified) atomicAdd(&p.counters[21], (unsigned long long)w_verified);
         }
     }
+    }   // (!wave_overflowed)
+    if (!p.persist) break;
+  }     // next block of this wave
 }
 
 template <int ALG, bool COUNT, bool STAGE, bool NODELET, bool LEVELSTACK>
-static int launch_one(const HorizonParams &p, int grid, size_t lds, hipStream_t st) {
+static int launch_one(const HorizonParams &p_in, int grid, size_t lds, hipStream_t st) {
     HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_horizon<ALG, COUNT, STAGE, NODELET, LEVELSTACK>),
                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HorizonParams p = p_in;
+    if (p.persist) {
+        // persistent waves: as many workgroups as this instantiation keeps resident (registers and this launch's LDS), each
+        // wave pulls blocks until the queues are empty.  A launch with fewer tiles than that stays one tile per workgroup.
+        int per_cu = 0, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_horizon<ALG, COUNT, STAGE, NODELET, LEVELSTACK>),
+                                                         HZ_TPB, lds) != hipSuccess || per_cu <= 0 ||
+            hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) {
+            (void)hipGetLastError();
+            p.persist = 0;
+        } else {
+            // (HZ_PERSIST_GRID=n: test hook -- n workgroups, so that small grids run several blocks per wave too)
+            static const int grid_env = []() { const char *e = getenv("HZ_PERSIST_GRID"); return e ? atoi(e) : 0; }();
+            const long long resident = grid_env > 0 ? (long long)grid_env : (long long)per_cu * prop.multiProcessorCount;
+            if ((long long)grid <= resident) p.persist = 0;
+            else {
+                grid = (int)resident;
+                HZ_HIP(hipMemsetAsync(p.queue, 0, 8 * sizeof(unsigned), st));
+            }
+        }
+    }
     hipLaunchKernelGGL((k_horizon<ALG, COUNT, STAGE, NODELET, LEVELSTACK>), dim3(grid), dim3(HZ_TPB), lds, st, p);
     HZ_HIP(hipGetLastError());
     return HZ_OK;
@@ -477,7 +546,11 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
     }
     p.counters = a.counters;
     p.tile_list = a.tile_list; p.n_list = a.n_list;
-    p.redo_list = reinterpret_cast<int *>(a.counters + 24);
+    p.redo_list = reinterpret_cast<int *>(a.counters + HZ_CNT_N);
+    // persistent waves (k_horizon): the default for full launches; HZ_PERSIST=0 restores one tile per workgroup (same-box A/Bs)
+    static const bool persist_env = []() { const char *e = getenv("HZ_PERSIST"); return !(e && e[0] == '0'); }();
+    p.persist = (persist_env && a.tile_list == nullptr && HZ_WPB == 4) ? 1 : 0;
+    p.queue = reinterpret_cast<unsigned *>(a.counters + 24);
     const size_t lds = (size_t)p.pre_bytes + (size_t)p.stack_bytes + (size_t)top * sizeof(Node);
     const int grid = a.tile_list ? (a.n_list + HZ_WPB - 1) / HZ_WPB : p.tm.per_xcd * 8 * (4 / HZ_WPB);
     if (grid <= 0) return HZ_OK;

@@ -134,11 +134,13 @@ struct HorizonArgs {
     int verify_near;                     // counting instantiation: N >= 1 re-traces one of every N shortened rays from parameter 0 (1: all)
     float *scratch_row;                  // counting instantiation only: null, or a device row of azim_num floats that takes EVERY store of the launch instead of
                                          // `hori` (the certificate monitor runs next to the production launch and must not write its rows)
-    unsigned long long *counters;        // device u64[24] + int[HZ_REDO_CAP] (tiles to redo, count in [8]): [0] rays, [1] guards, [2] nodes, [3] tris, [4] cells,
+    unsigned long long *counters;        // device u64[HZ_CNT_N] + int[HZ_REDO_CAP] (tiles to redo, count in [8]): [0] rays, [1] guards, [2] nodes, [3] tris, [4] cells,
                                          // [5..7] wave iterations, [8] waves whose fast-discipline stack overflowed,
                                          // [9] rays shortened by a certificate, [10] certificate violations (verify), [11] cells with a guard event,
-                                         // [21] shortened rays that were re-traced (verify)
+                                         // [21] shortened rays that were re-traced (verify);
+                                         // [24..27] = unsigned[8]: the per-XCD block queues of a persistent launch (hz_horizon.hip; zeroed by horizon_launch)
 };
+#define HZ_CNT_N 32                      // u64 words in front of the redo list
 #define HZ_REDO_CAP 16384                // 8 x 8 blocks of one launch that can be repeated one by one after a stack overflow
 int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *used_level_stack = nullptr);
 int horizon_num_blocks(const HorizonArgs &a);

@@ -724,3 +724,23 @@ def test_near_field_certificates_with_an_outer_tin_are_per_cell(hip, orc):
     h_cpu, _ = orc.horizon_gridded(**kw, dist_search=6.0, azim_num=24, vert_simp=vs, num_vert_simp=nvs,
                                    tri_ind_simp=ts, num_tri_simp=nts)
     assert np.array_equal(h, h_cpu)
+
+
+@pytest.mark.parametrize("grid", ("1", "3"))
+def test_persistent_waves_on_small_grids(grid):
+    """Round 5: a full launch of k_horizon has as many workgroups as are resident at once and every wave pulls 8 x 8 blocks from
+    the queue of its XCD, then from the other XCDs' queues (hz_horizon.hip).  Small grids have fewer tiles than that and run one
+    tile per workgroup; HZ_PERSIST_GRID forces 1 / 3 workgroups, so that the parity tests against the oracle run the block loop
+    with many passes per wave (the variable is read once per process, hence the subprocess)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HZ_PERSIST_GRID=grid)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_gpu_parity.py"), "-k",
+                        "c2_gaussian_hill or rough_tilted or mask_and_fill or outer_tin or row_slab or odd_parameters or "
+                        "traversal_stack or near_field_certificates or streamed_host_output"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
