@@ -122,7 +122,7 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
 
     // wave -> 8 x 8 block of cells: quadrant `wave` of the tile of workgroup blockIdx.x, or -- in a launch that repeats
     // blocks whose fast stack overflowed -- the block the list names (entry = workgroup number * 4 + quadrant)
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // (a scalar register: it lives through the block loop)
     // Persistent waves (round 5, p.persist): a workgroup's slot -- its LDS -- is only free again when the SLOWEST of its four waves
     // has finished its block, so with one tile per workgroup 6 - 9 % of the wave slots stood empty in the middle of a launch
     // (profiles/r05/wg_trace_wpb4_slab447.json: wave lifetimes 29 ... 38 ms around a mean of 33).  Now the launch has only as many
@@ -134,6 +134,11 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
   for (;;) {                         // one 8 x 8 block per pass (exactly one pass without p.persist)
     asm volatile("" : "+s"(pk));
     HZ_LOAD_PARAMS(p);
+    // (the same for what is derived from the thread number -- lane, lane >> 3, lane & 7, LDS addresses: formed again in every pass
+    //  from a copy the compiler cannot see through, or they are hoisted out of the block loop and live through the traversal)
+    int tid_b = tid;
+    asm volatile("" : "+v"(tid_b));
+    const int lane = tid_b & 63;
     // (what the traversal loop and the refill read stays in registers: the compiler would otherwise re-load these from the
     //  argument segment INSIDE those loops -- an s_load and its wait in front of every vote)
 #define HZ_KEEP(x) asm volatile("" : "+s"(x))
@@ -160,6 +165,7 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
         const int b = (int)blockIdx.x, x = b & 7, t = b >> 3, per = 4 / HZ_WPB;
         blk = (((t / per) * 8 + x) * 4) + (t % per) * HZ_WPB + wave;
     }
+    blk = __builtin_amdgcn_readfirstlane(blk);       // (wave uniform on every path: keep it out of the vector registers)
     const bool has_tile = blk >= 0 && hz_tile_of_block(p.tm, blk >> 2, &ti, &tj);
     const int i = p.row_begin + ti * 16 + ((blk >> 1) & 1) * 8 + (lane >> 3);
     const int j = tj * 16 + (blk & 1) * 8 + (lane & 7);
@@ -183,7 +189,7 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
     Sink out;
     out.hori = COUNT ? hori0 + (size_t)(cert * cell_stride) * (size_t)t.azim_num : hori0 + (size_t)cert * (size_t)t.azim_num;
     out.dist = nullptr; out.dist_hit = 0.0f;
-    out.stage = reinterpret_cast<float *>(smem) + tid;   // only touched when STAGE
+    out.stage = reinterpret_cast<float *>(smem) + tid_b;   // only touched when STAGE
     out.stride = HZ_TPB;
     float ox = 0, oy = 0, oz = 0;
     float r01 = 0, r02 = 0, r11 = 0, r12 = 0, r21 = 0, r22 = 0;
