@@ -197,6 +197,7 @@ static void scene_free(Scene *sc) {
     (void)hipSetDevice(sc->device);
     stream_release(sc->device, sc->stream);
     if (sc->near_buf) (void)hipFree(sc->near_buf);
+    if (sc->left_buf) (void)hipFree(sc->left_buf);
     if (sc->owns_blob && sc->blob) (void)hipFree(sc->blob);
     delete sc;
 }
@@ -597,6 +598,24 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             sc->near_bytes = need;
         }
     }
+    // Leftover cells (hz_horizon.hip): a block of a production launch ends when at most HZ_LEFT_MIN (default 16; 0: off) of its cells
+    // are unfinished -- a lane whose cell is done idles until its block's slowest cell is (12 % of the lane time, profiles/r05/
+    // probe_done_lanes.log) -- and a second launch finishes the cells handed over, 64 per wave.  One 64 B record per cell; the
+    // buffer has room for every cell of the largest chunk (a cell is handed over at most once) and is kept with the scene.
+    static const int left_min_env = []() { const char *e = getenv("HZ_LEFT_MIN"); return e ? atoi(e) : 16; }();
+    const bool use_left = left_min_env > 0 && !(opts && opts->count_work);
+    if (use_left) {
+        const size_t cells = (size_t)std::min(chunk_rows, row_end - row_begin) * dim_in_1;
+        const size_t need = cells * HZ_LEFT_WORDS * sizeof(unsigned);
+        if (sc->left_bytes < need) {
+            if (sc->left_buf) (void)hipFree(sc->left_buf);
+            sc->left_buf = nullptr; sc->left_bytes = 0;
+            if (hipMalloc(&sc->left_buf, need) != hipSuccess) { (void)hipGetLastError(); sc->left_buf = nullptr; }     // (no room: the blocks run to their end)
+            else sc->left_bytes = need;
+        }
+    }
+    a.left_min = (use_left && sc->left_buf) ? std::min(left_min_env, 32) : 0;
+    a.left_rec = (use_left && sc->left_buf) ? (unsigned *)sc->left_buf : nullptr;
     // HZ_NEAR_REASONS=1: histogram of why cells got no certificate, printed to stderr at the end of the call
     unsigned *near_reasons = nullptr;
     struct ReasonsFree { unsigned **p; ~ReasonsFree() { if (*p) (void)hipFree(*p); } } reasons_free{&near_reasons};
@@ -636,6 +655,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     };
     auto fail = [&](int code) { (void)hipStreamSynchronize(st); if (st_copy) (void)hipStreamSynchronize(st_copy); free_events(); return code; };
     int n_chunk = 0;
+    unsigned long long left_cells = 0;
     for (int rb = row_begin; rb < row_end; rb += chunk_rows, n_chunk++) {
         const int re = std::min(rb + chunk_rows, row_end);
         // the kernels index hori by global cell: shift the (slab- or chunk-local) buffer back
@@ -730,6 +750,19 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
                     }
                 }
             }
+            if (!rc && a.left_rec != nullptr) {
+                // the cells the blocks handed over: finished by a second launch (one entry per level: nothing can overflow there)
+                unsigned n_left = 0;
+                if (hipMemcpyAsync(&n_left, (unsigned long long *)cnt_dev + 28, sizeof(n_left), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                    hipStreamSynchronize(st) != hipSuccess)
+                    return fail(set_error(HZ_ERR_HIP, "horizon kernel failed: %s", hipGetErrorString(hipGetLastError())));
+                if (n_left != 0) {
+                    HorizonArgs b = a;
+                    b.left_mode = 1; b.left_n = n_left; b.level_stack = 1; b.tile_list = nullptr; b.n_list = 0;
+                    left_cells += n_left;
+                    rc = horizon_launch(sc, b, st, nullptr);
+                }
+            }
             if (!rc && mon.active) rc = mon.collect(st, &n_verified, &n_mon_violations);
             (void)hipEventRecord(e.b, st);
             if (!rc && want_svf)
@@ -760,6 +793,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             }
         }
     }
+    if (left_cells && getenv("HZ_LEFT_TRACE")) fprintf(stderr, "hz leftover cells: %llu\n", left_cells);
     Timer t_d2h; t_d2h.start();
     if (stream_out) {
         rc = copy_out(n_chunk - 1);

@@ -61,6 +61,12 @@ struct HorizonParams {
     const int *tile_list;          // null, or the n_list blocks (workgroup number * 4 + wave, of the full launch) to repeat
     int n_list;
     int *redo_list;                // !LEVELSTACK: waves whose stack overflowed append their block here (count: counters[8])
+    // Leftover cells (round 5): a block of a production launch ENDS when at most left_min of its cells are unfinished; those lanes
+    // append their cell's state to left_rec (HZ_LEFT_WORDS words per cell, count in left_cnt[0], room for left_cap cells) and a
+    // second launch (left_mode = 1: 64 records per wave instead of an 8 x 8 block; such blocks run to the end) finishes them.
+    int left_min, left_mode;
+    unsigned left_cap, left_n;     // left_n (left_mode): records to process
+    unsigned *left_rec, *left_cnt;
     int persist;                   // 1: persistent waves -- the launch has as many workgroups as are resident at once and every WAVE pulls 8 x 8
     unsigned *queue;               //    blocks from the queue of its XCD (queue[x] = blocks of XCD x handed out so far) until all are empty
 };
@@ -74,7 +80,22 @@ struct HorizonParams {
 #ifdef HZ_WG_TRACE   // measurement probe (scripts/build_variant.sh trace -DHZ_WG_TRACE): start / end of every wave on the 100 MHz clock
 __device__ unsigned long long *hz_wg_trace_buf = nullptr;      // [waves of the launch][2]
 #endif
-template <int ALG, bool COUNT, bool STAGE, bool NODELET, bool LEVELSTACK>
+// One leftover record (a real call: it runs once per handed-over cell, at the end of a block, and must not weigh on the kernel's
+// register allocation).  (row, column) come from the launch-local cell number.
+__device__ __forceinline__ void hz_left_write(unsigned *w, unsigned cert, unsigned dim_in_1, unsigned row_begin, unsigned k, unsigned flags,
+                                                        unsigned ind, unsigned prev, unsigned pazim, unsigned count, float lim_up, float lim_low,
+                                                        float elev_samp, float ev, unsigned cache, float st0, float st1, float st2) {
+    const unsigned di = cert / dim_in_1, dj = cert - di * dim_in_1;
+    w[0] = (di + row_begin) | (dj << 16);
+    w[1] = k; w[2] = flags; w[3] = ind; w[4] = prev; w[5] = pazim; w[6] = count;
+    w[7] = __float_as_uint(lim_up); w[8] = __float_as_uint(lim_low); w[9] = __float_as_uint(elev_samp); w[10] = __float_as_uint(ev);
+    w[11] = cache; w[12] = __float_as_uint(st0); w[13] = __float_as_uint(st1); w[14] = __float_as_uint(st2); w[15] = 0u;
+}
+
+// LEFT: the leftover instantiation (p.left_mode): a wave takes 64 records of cells that production blocks left unfinished instead of
+// an 8 x 8 block.  A template parameter and not a run-time switch: the restore code in front of the main loop cost the production
+// kernel 5 % (two rematerialised instructions in the node step, scratch reloads in the refill) although it never ran there.
+template <int ALG, bool COUNT, bool STAGE, bool NODELET, bool LEVELSTACK, bool LEFT = false>
 #ifndef HZ_WG_PER_CU
 #define HZ_WG_PER_CU 5     // resident workgroups per CU the register allocation is held to (6: 80 VGPRs, measured slower)
 #endif
@@ -166,9 +187,15 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
         blk = (((t / per) * 8 + x) * 4) + (t % per) * HZ_WPB + wave;
     }
     blk = __builtin_amdgcn_readfirstlane(blk);       // (wave uniform on every path: keep it out of the vector registers)
-    const bool has_tile = blk >= 0 && hz_tile_of_block(p.tm, blk >> 2, &ti, &tj);
-    const int i = p.row_begin + ti * 16 + ((blk >> 1) & 1) * 8 + (lane >> 3);
-    const int j = tj * 16 + (blk & 1) * 8 + (lane & 7);
+    bool has_tile = blk >= 0 && (LEFT || hz_tile_of_block(p.tm, blk >> 2, &ti, &tj));
+    int i = p.row_begin + ti * 16 + ((blk >> 1) & 1) * 8 + (lane >> 3);
+    int j = tj * 16 + (blk & 1) * 8 + (lane & 7);
+    const unsigned *rec = nullptr;                   // left_mode: this lane's record
+    if (LEFT) {
+        const unsigned idx = (unsigned)blk * 64u + (unsigned)lane;
+        has_tile = blk >= 0 && idx < p.left_n;
+        if (has_tile) { rec = p.left_rec + (size_t)idx * HZ_LEFT_WORDS; i = (int)(rec[0] & 0xffffu); j = (int)(rec[0] >> 16); }
+    }
     const bool in_dom = has_tile && (i < p.row_end) && (j < p.dim_in_1);
 
     const Tables &t = p.tb;
@@ -248,7 +275,7 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
 #ifdef HZ_PROBE_Q1
     tc.q1 = 0; tc.blk = 0; tc.fin = 0;
 #endif
-    const unsigned cells_cnt = (in_dom && !done) ? 1u : 0u;
+    const unsigned cells_cnt = (in_dom && !done && !LEFT) ? 1u : 0u;
     bool ray_active = false, last_hit = false;
     float dx = 0, dy = 0, dz = 1;
     RayBox rb = hz_raybox(0, 0, 0, 0, 0, 1);
@@ -265,8 +292,56 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
     unsigned w_verified = 0, w_violations = 0;     // wave-uniform
     bool verifying = false, first_result = false, want_v = false;
     float tn = 0.0f;
+    bool had_guard = false;          // left_mode: the cell was counted as a guard cell by the launch that started it
+    if (LEFT && !done) {
+        // a cell another wave left unfinished: its search state, its hit cache, the output values it had staged -- and the ray that
+        // was in flight, issued again here from (s.ind, s.k) over its full length from the root (the decision cannot differ: no
+        // certificate, no cache walk, section 4 of DESIGN.md); it was counted when it was issued first
+        s.k = (int)rec[1]; s.phase = (int)(rec[2] & 0xffu); s.ind = (int)rec[3]; s.prev = (int)rec[4]; s.pazim = (int)rec[5]; s.count = (int)rec[6];
+        s.lim_up = __uint_as_float(rec[7]); s.lim_low = __uint_as_float(rec[8]); s.elev_samp = __uint_as_float(rec[9]); s.ev = __uint_as_float(rec[10]);
+        cache = (int)rec[11];
+        last_hit = (rec[2] & 0x100u) != 0u;
+        had_guard = (rec[2] & 0x400u) != 0u;
+        if (STAGE) { out.stage[0] = __uint_as_float(rec[12]); out.stage[out.stride] = __uint_as_float(rec[13]); out.stage[2 * out.stride] = __uint_as_float(rec[14]); }
+        if (rec[2] & 0x200u) {
+            const float ec = t.elev_cos[s.ind], es = t.elev_sin[s.ind];
+            const float rx = ec * t.azim_sin[s.k], ry = ec * t.azim_cos[s.k], rz = es;
+            const float r00 = r11 * r22 - r21 * r12, r10 = r21 * r02 - r01 * r22, r20 = r01 * r12 - r11 * r02;      // east = north x norm
+            dx = (r00 * rx + r01 * ry) + r02 * rz;
+            dy = (r10 * rx + r11 * ry) + r12 * rz;
+            dz = (r20 * rx + r21 * ry) + r22 * rz;
+            if (POOLK) { HZ_POOL_AT(3) = dx; HZ_POOL_AT(4) = dy; HZ_POOL_AT(5) = dz; }
+            HZ_OC(ocx, ocy, ocz)
+            rb = hz_raybox(ocx + p.neg_tau * dx, ocy + p.neg_tau * dy, ocz + p.neg_tau * dz, dx, dy, dz);
+            hz_trav_reset(ts);
+            ray_active = true;
+        }
+    }
 
+    // (a block that starts with few cells -- the ragged rim of the domain -- is not worth a hand-over)
+    const int left_min = (COUNT || LEFT || __popcll(__ballot(!done)) <= 2 * p.left_min) ? 0 : p.left_min;
     while (__ballot(!done) != 0ull) {
+        if (!COUNT && !LEFT && left_min > 0 && __popcll(__ballot(!done)) <= left_min) {
+        // cells still unfinished (<= left_min of them): they go to the leftover launch (the buffer has room for every cell of the
+        // launch: a cell is handed over at most once).  A wave whose fast stack overflowed hands nothing over: its block is computed again.
+        const unsigned long long um = __ballot(!done);
+        if (um != 0ull && !(!LEVELSTACK && __ballot(overflow) != 0ull)) {
+            const int n = __popcll(um);
+            unsigned base = 0u;
+            if (lane == 0) base = atomicAdd(&p.left_cnt[0], (unsigned)n);
+            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+            if (!done) {
+                const unsigned rank = (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
+                const unsigned flags = (unsigned)s.phase | (last_hit ? 0x100u : 0u) | (ray_active ? 0x200u : 0u) | ((guards != 0u) ? 0x400u : 0u);
+                hz_left_write(p.left_rec + (size_t)(base + rank) * HZ_LEFT_WORDS, cert, (unsigned)p.dim_in_1, (unsigned)p.row_begin, (unsigned)s.k, flags,
+                              (unsigned)s.ind, (unsigned)s.prev, (unsigned)s.pazim, (unsigned)s.count, s.lim_up, s.lim_low, s.elev_samp, s.ev, (unsigned)cache,
+                              STAGE ? out.stage[0] : 0.0f, STAGE ? out.stage[out.stride] : 0.0f, STAGE ? out.stage[2 * out.stride] : 0.0f);
+                done = true;
+            }
+        }
+    }
+
+        if (__ballot(!done) == 0ull) break;
         // ---- refill: lanes without a ray take the next sample of their search -----------------
         if (!done && !ray_active) {
             if (COUNT) HZ_WAVE_TICK(w_adv, lane);
@@ -357,7 +432,6 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
             w_violations += (unsigned)__popcll(__ballot(viol));
         }
     }
-
 #ifdef HZ_WG_TRACE
     if (lane == 0 && hz_wg_trace_buf != nullptr && !p.tile_list && blk >= 0) {
         const size_t w = (size_t)blk;
@@ -384,7 +458,7 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
             if (slot < (unsigned long long)HZ_REDO_CAP) p.redo_list[slot] = blk;
         }
     } else {
-    const int guard_cells = __popcll(__ballot(guards != 0u));   // cells where the reference's search would not terminate
+    const int guard_cells = __popcll(__ballot(guards != 0u && !(LEFT && had_guard)));   // cells where the reference's search would not terminate (a leftover cell: counted once)
     if (lane == 0) {
         if (r) atomicAdd(&p.counters[0], r);
         if (g) { atomicAdd(&p.counters[1], g); atomicAdd(&p.counters[11], (unsigned long long)guard_cells); }
@@ -455,9 +529,19 @@ static int launch_one(const HorizonParams &p_in, int grid, size_t lds, hipStream
     return HZ_OK;
 }
 
+template <int ALG, bool STAGE>
+static int launch_left(const HorizonParams &p, int grid, size_t lds, hipStream_t st) {
+    HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_horizon<ALG, false, STAGE, false, true, true>),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL((k_horizon<ALG, false, STAGE, false, true, true>), dim3(grid), dim3(HZ_TPB), lds, st, p);
+    HZ_HIP(hipGetLastError());
+    return HZ_OK;
+}
+
 template <int ALG>
 static int launch_alg(const HorizonParams &p, int grid, size_t lds, bool count, bool level_stack, hipStream_t st) {
     const bool stage = p.stage_bytes != 0;
+    if (p.left_mode) return stage ? launch_left<ALG, true>(p, grid, lds, st) : launch_left<ALG, false>(p, grid, lds, st);
     if (ALG == ALG_GUESS && !count && p.top_nodes > 0) {    // opt-in LDS nodelet variant (opts.top_nodes > 0)
         if (!level_stack) return stage ? launch_one<ALG_GUESS, false, true, true, false>(p, grid, lds, st)
                                        : launch_one<ALG_GUESS, false, false, true, false>(p, grid, lds, st);
@@ -553,12 +637,17 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
     p.counters = a.counters;
     p.tile_list = a.tile_list; p.n_list = a.n_list;
     p.redo_list = reinterpret_cast<int *>(a.counters + HZ_CNT_N);
+    p.left_mode = a.left_mode ? 1 : 0; p.left_n = a.left_n;
+    p.left_rec = a.left_rec; p.left_cnt = reinterpret_cast<unsigned *>(a.counters + 28);
+    p.left_min = (a.left_rec != nullptr && !a.tile_list && !a.count_work && !a.left_mode) ? std::max(a.left_min, 0) : 0;
+    p.left_cap = 0;
     // persistent waves (k_horizon): the default for full launches; HZ_PERSIST=0 restores one tile per workgroup (same-box A/Bs)
     static const bool persist_env = []() { const char *e = getenv("HZ_PERSIST"); return !(e && e[0] == '0'); }();
-    p.persist = (persist_env && a.tile_list == nullptr && HZ_WPB == 4) ? 1 : 0;
+    p.persist = (persist_env && a.tile_list == nullptr && !a.left_mode && HZ_WPB == 4) ? 1 : 0;
     p.queue = reinterpret_cast<unsigned *>(a.counters + 24);
     const size_t lds = (size_t)p.pre_bytes + (size_t)p.stack_bytes + (size_t)top * sizeof(Node);
-    const int grid = a.tile_list ? (a.n_list + HZ_WPB - 1) / HZ_WPB : p.tm.per_xcd * 8 * (4 / HZ_WPB);
+    const int grid = a.left_mode ? (int)(((a.left_n + 63u) / 64u + HZ_WPB - 1) / HZ_WPB)
+                     : a.tile_list ? (a.n_list + HZ_WPB - 1) / HZ_WPB : p.tm.per_xcd * 8 * (4 / HZ_WPB);
     if (grid <= 0) return HZ_OK;
     const bool count = a.count_work != 0;
 #ifdef HZ_WG_TRACE

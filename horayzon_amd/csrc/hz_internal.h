@@ -56,6 +56,9 @@ struct Scene {
     // scratch of the near-field certificates, grown on demand and kept with the scene (hz_api.hip; guarded by run_mu)
     mutable void *near_buf = nullptr;
     mutable size_t near_bytes = 0;
+    // records of the cells a production launch of k_horizon left unfinished (hz_horizon.hip: leftover cells; guarded by run_mu)
+    mutable void *left_buf = nullptr;
+    mutable size_t left_bytes = 0;
     BlobHeader hdr;
     const float *verts() const { return (const float *)((const char *)blob + hdr.off_verts); }
     const Node *nodes() const { return (const Node *)((const char *)blob + hdr.off_nodes); }
@@ -134,13 +137,19 @@ struct HorizonArgs {
     int verify_near;                     // counting instantiation: N >= 1 re-traces one of every N shortened rays from parameter 0 (1: all)
     float *scratch_row;                  // counting instantiation only: null, or a device row of azim_num floats that takes EVERY store of the launch instead of
                                          // `hori` (the certificate monitor runs next to the production launch and must not write its rows)
+    int left_min = 0;                    // production launches: a block ends when at most this many of its cells are unfinished and hands them to
+    unsigned *left_rec = nullptr;        //   left_rec (HZ_LEFT_WORDS words per cell, room for every cell of the launch; count: counters word 28); 0 / null: off
+    int left_mode = 0;                   // 1: this launch finishes the left_n cells recorded in left_rec (64 per wave)
+    unsigned left_n = 0;
     unsigned long long *counters;        // device u64[HZ_CNT_N] + int[HZ_REDO_CAP] (tiles to redo, count in [8]): [0] rays, [1] guards, [2] nodes, [3] tris, [4] cells,
                                          // [5..7] wave iterations, [8] waves whose fast-discipline stack overflowed,
                                          // [9] rays shortened by a certificate, [10] certificate violations (verify), [11] cells with a guard event,
                                          // [21] shortened rays that were re-traced (verify);
-                                         // [24..27] = unsigned[8]: the per-XCD block queues of a persistent launch (hz_horizon.hip; zeroed by horizon_launch)
+                                         // [24..27] = unsigned[8]: the per-XCD block queues of a persistent launch (hz_horizon.hip; zeroed by horizon_launch);
+                                         // [28] (low word): cells handed to the leftover launch
 };
 #define HZ_CNT_N 32                      // u64 words in front of the redo list
+#define HZ_LEFT_WORDS 16                 // 32-bit words per leftover record
 #define HZ_REDO_CAP 16384                // 8 x 8 blocks of one launch that can be repeated one by one after a stack overflow
 int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *used_level_stack = nullptr);
 int horizon_num_blocks(const HorizonArgs &a);
