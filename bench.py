@@ -696,7 +696,12 @@ def roofline(args, stats, steps, cw, peaks, A, n, rps):
     rays_launch = stats.num_rays / max(steps, 1)
     cells_launch = stats.num_cells / max(steps, 1)
     b_io = (12 + 12 + 12 + 1 + 12 + 4) * cells_launch + 4.0 * A * cells_launch
-    r = {"kernel": "hz::k_horizon<2,false,true,false,false> (guess_constant, staged output, fast stack discipline)", "kernel_ms_per_launch": 1e3 * k_launch_s,
+    left_s = getattr(stats, "t_left_s", 0.0) / max(steps, 1)
+    r = {"kernel": "hz::k_horizon<2,false,true,false,false,false> (guess_constant, staged output, fast stack discipline, persistent waves) + its leftover "
+                   "launch hz::k_horizon<2,false,true,false,true,true> (the cells that blocks handed over when <= 16 of their 64 were unfinished)",
+         "kernel_ms_per_launch": 1e3 * k_launch_s,
+         "kernel_ms_production_launch": 1e3 * (k_launch_s - left_s), "kernel_ms_leftover_launch": 1e3 * left_s,
+         "leftover_cells_per_launch": getattr(stats, "left_cells", 0) / max(steps, 1),
          "mray_per_s_kernel": rays_launch / k_launch_s / 1e6 if k_launch_s else None,
          "svf_kernel_ms_per_launch": 1e3 * stats.t_svf_s / max(steps, 1)}
     model, mix0, mnotes = load_valu_model()

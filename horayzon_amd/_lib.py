@@ -43,7 +43,8 @@ class hz_stats(C.Structure):
                 ("t_svf_s", C.c_double), ("stack_fallbacks", C.c_uint64),
                 ("rays_shortened", C.c_uint64), ("near_violations", C.c_uint64), ("t_near_s", C.c_double),
                 ("stack_redo_blocks", C.c_uint64), ("guard_cells", C.c_uint64),
-                ("height_field", C.c_int32), ("near_used", C.c_int32), ("near_verified", C.c_uint64)]
+                ("height_field", C.c_int32), ("near_used", C.c_int32), ("near_verified", C.c_uint64),
+                ("t_left_s", C.c_double), ("left_cells", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

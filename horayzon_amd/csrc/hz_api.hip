@@ -574,7 +574,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     unsigned long long redo_blocks = 0;
 
     // HIP events on the kernels' stream: horizon kernel and SVF kernel are timed separately
-    struct Ev { hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr; };
+    struct Ev { hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr, l = nullptr; };
     std::vector<Ev> evs;          // one per launch attempt
     std::vector<size_t> ev_of;    // chunk -> its final attempt
     hipStream_t st_copy = nullptr;
@@ -584,6 +584,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             if (e.b) (void)hipEventDestroy(e.b);
             if (e.c) (void)hipEventDestroy(e.c);
             if (e.d) (void)hipEventDestroy(e.d);
+            if (e.l) (void)hipEventDestroy(e.l);
         }
         if (st_copy) { stream_release(sc->device, st_copy); st_copy = nullptr; }
     };
@@ -656,6 +657,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     auto fail = [&](int code) { (void)hipStreamSynchronize(st); if (st_copy) (void)hipStreamSynchronize(st_copy); free_events(); return code; };
     int n_chunk = 0;
     unsigned long long left_cells = 0;
+    float ms_left = 0.0f;
     for (int rb = row_begin; rb < row_end; rb += chunk_rows, n_chunk++) {
         const int re = std::min(rb + chunk_rows, row_end);
         // the kernels index hori by global cell: shift the (slab- or chunk-local) buffer back
@@ -757,6 +759,8 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
                     hipStreamSynchronize(st) != hipSuccess)
                     return fail(set_error(HZ_ERR_HIP, "horizon kernel failed: %s", hipGetErrorString(hipGetLastError())));
                 if (n_left != 0) {
+                    if (hipEventCreate(&evs.back().l) != hipSuccess) return fail(set_error(HZ_ERR_HIP, "hipEventCreate failed"));
+                    (void)hipEventRecord(evs.back().l, st);
                     HorizonArgs b = a;
                     b.left_mode = 1; b.left_n = n_left; b.level_stack = 1; b.tile_list = nullptr; b.n_list = 0;
                     left_cells += n_left;
@@ -779,6 +783,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             (void)hipEventElapsedTime(&m1, e.a, e.b);
             (void)hipEventElapsedTime(&m2, e.b, e.c);
             ms += m1; ms_svf += m2;
+            if (evs.back().l) { float m3 = 0.0f; (void)hipEventElapsedTime(&m3, evs.back().l, e.b); ms_left += m3; }
             for (int k = 0; k < 16; k++) cnt[k] += c[k];
             n_verified += c[21];
 #ifdef HZ_PROBE_Q1
@@ -820,6 +825,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         stats->stack_fallbacks += (uint64_t)fallbacks; stats->stack_redo_blocks += redo_blocks;
         stats->rays_shortened += cnt[9]; stats->near_violations += cnt[10] + n_mon_violations; stats->t_near_s += (double)ms_near * 1e-3;
         stats->guard_cells += cnt[11]; stats->near_verified += n_verified;
+        stats->t_left_s += (double)ms_left * 1e-3; stats->left_cells += left_cells;
         stats->height_field = height_field ? 1 : 0; stats->near_used = use_near ? 1 : 0;
     }
     if (near_reasons) {
@@ -955,7 +961,7 @@ extern "C" {
 
 const char *hz_last_error(void) { return g_error.c_str(); }
 
-int hz_abi_version(void) { return 4; }
+int hz_abi_version(void) { return 5; }
 
 int hz_abi_struct_sizes(int *opts_bytes, int *stats_bytes) {
     if (opts_bytes) *opts_bytes = (int)sizeof(hz_opts);

@@ -115,12 +115,14 @@ typedef struct hz_stats {
     int32_t height_field;  /* 1: the scene's DEM mesh is a height field over the world (x, y) plane                      */
     int32_t near_used;     /* 1: the near-field certificates were active in this call                                    */
     uint64_t near_verified;/* opts.verify_near: shortened rays that were traced a second time over their full length     */
+    double t_left_s;       /* leftover launch: part of t_kernel_s spent finishing the cells that blocks of the production     */
+    uint64_t left_cells;   /*   launch handed over when <= HZ_LEFT_MIN of their 64 cells were unfinished (hz_horizon.hip)        */
 } hz_stats;
 
 const char *hz_last_error(void);
 /* sizeof(hz_opts), sizeof(hz_stats) as compiled: lets a binding verify its mirror */
 int hz_abi_struct_sizes(int *opts_bytes, int *stats_bytes);
-/* ABI revision.  4 (round 4): hz_stats.near_verified appended; opts.verify_near is a sampling period (1 = every ray, as   */
+/* ABI revision.  5 (round 5): hz_stats.t_left_s, left_cells appended.  4 (round 4): hz_stats.near_verified appended; opts.verify_near is a sampling period (1 = every ray, as   */
 /* before).  3 (round 3): {row_begin > 0, row_end = 0} is rejected (was "to the end": use row_end = -1); opts.regroup <= 0 */
 /* means the default threshold (was: 0 = ray compaction off; 64 | bias << 8 still disables the early exit in effect)     */
 int hz_abi_version(void);

@@ -26,7 +26,7 @@ FAST = ("v_mul_f32", "v_fma_f32", "v_fmac_f32", "v_add_f32", "v_sub_f32", "v_sub
         "v_and_b32", "v_or_b32", "v_xor_b32", "v_not_b32", "v_add_u32", "v_sub_u32", "v_subrev_u32", "v_add_co_u32",
         "v_addc_co_u32", "v_sub_co_u32", "v_subb_co_u32", "v_cndmask_b32", "v_lshlrev_b32", "v_lshrrev_b32",
         "v_ashrrev_i32", "v_bfe_u32", "v_bfe_i32", "v_and_or_b32", "v_or3_b32", "v_mul_u32_u24", "v_mad_u32_u24")
-KERNEL = "_ZN2hz9k_horizonILi2ELb0ELb1ELb0ELb0EEEvNS_13HorizonParamsE"
+KERNEL = "_ZN2hz9k_horizonILi2ELb0ELb1ELb0ELb0ELb0EEEvNS_13HorizonParamsE"     # <ALG_GUESS, !COUNT, STAGE, !NODELET, !LEVELSTACK, !LEFT>
 
 
 def classify(lines):

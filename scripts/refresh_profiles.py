@@ -22,7 +22,7 @@ try:      # config 4
     shutil.copy("gpurun_out/%s_c4kt_bench.json" % pre, "profiles/%s/bench_c4_under_rocprof.json" % rnd)
 except (ValueError, OSError):
     pass
-KERNEL = "k_horizon<2, false, true, false"
+KERNEL = "k_horizon<2, false, true, false, false, false>"      # the production instantiation (not its leftover launch <..., true, true>)
 
 
 def per_kernel(d, names):

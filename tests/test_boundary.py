@@ -31,11 +31,11 @@ def test_abi_revision_and_struct_mirrors():
     the ctypes mirrors have the compiled sizes, and the Cython declaration in INTEGRATION.md lists every hz_opts field."""
     import ctypes as C
     L = _lib.lib()
-    assert L.hz_abi_version() == 4
+    assert L.hz_abi_version() == 5
     a, b = C.c_int(0), C.c_int(0)
     assert L.hz_abi_struct_sizes(C.byref(a), C.byref(b)) == 0
     assert a.value == C.sizeof(_lib.hz_opts) and b.value == C.sizeof(_lib.hz_stats)
-    assert _lib.hz_stats._fields_[-1][0] == "near_verified"
+    assert _lib.hz_stats._fields_[-1][0] == "left_cells"
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for name, _ in _lib.hz_opts._fields_:
         assert re.search(r"\b%s\b" % name, doc), name
