@@ -2,6 +2,8 @@
 seeded inputs.  Hit decisions are float32-deterministic on both sides, so horizon
 arrays, ray counts and shadow codes must be IDENTICAL (not merely close); the
 north-star tolerance (1e-4 rad / 1e-5 SVF) is the outer bound asserted as well."""
+import os
+
 import numpy as np
 import pytest
 
@@ -744,3 +746,38 @@ def test_persistent_waves_on_small_grids(grid):
                        cwd=root, env=env, capture_output=True, text=True, timeout=1200)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_blocks_that_run_to_their_end_without_the_hand_over():
+    """Round 5: a block of a production launch ends when at most HZ_LEFT_MIN (16) of its cells are unfinished and a second launch
+    finishes the cells it handed over (hz_horizon.hip: leftover cells) -- every other test of this file runs that way.  With
+    HZ_LEFT_MIN=0 the blocks run to their end as before: the same parity tests against the oracle (the variable is read once per
+    process, hence the subprocess)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HZ_LEFT_MIN="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider",
+                        os.path.join(root, "tests", "test_gpu_parity.py"), "-k",
+                        "c2_gaussian_hill or rough_tilted or mask_and_fill or row_slab or near_field_certificates"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_leftover_cells_are_reported(hip):
+    """hz_stats.left_cells / t_left_s (ABI 5): a grid with full 8 x 8 blocks hands cells over and says so; the counting
+    instantiation never does."""
+    import horayzon_amd as hz
+    from horayzon_amd import synth
+    g = synth.gaussian_hill(n=200, dx=50.0, height=1500.0, sigma=1500.0, offset=10)
+    kw = {k: g[k] for k in ("vert_grid", "dem_dim_0", "dem_dim_1", "vec_norm", "vec_north", "offset_0", "offset_1")}
+    h0, _ = hz.horizon.horizon_gridded(**kw, dist_search=10.0, azim_num=36)
+    st = dict(hz.horizon.last_stats)
+    h1, _ = hz.horizon.horizon_gridded(**kw, dist_search=10.0, azim_num=36, count_work=True)
+    sc = dict(hz.horizon.last_stats)
+    assert np.array_equal(h0, h1) and st["num_rays"] == sc["num_rays"]
+    if os.environ.get("HZ_LEFT_MIN", "16") != "0":
+        assert 0 < st["left_cells"] <= st["num_cells"] and st["t_left_s"] > 0.0
+    assert sc["left_cells"] == 0
