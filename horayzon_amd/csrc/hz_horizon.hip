@@ -7,12 +7,16 @@
 //   one lane      = one inner-domain grid cell; it walks ALL azimuth sectors
 //                   sequentially (guess_constant carries the elevation index from
 //                   one azimuth to the next, horizon_comp.cpp:431-496)
-//   one wavefront = an 8 x 8 tile of cells -> neighbouring lanes shoot nearly
+//   one wavefront = an 8 x 8 block of cells -> neighbouring lanes shoot nearly
 //                   parallel rays and fetch the same BVH nodes (coalesced by the TA)
-//   one workgroup = 4 wavefronts = a 16 x 16 tile; per-lane traversal stacks and the output
+//   one workgroup = 4 wavefronts; per-lane traversal stacks and the output
 //                   staging (4 azimuths -> one 16 B store) live in LDS
-//   blockIdx      -> tile mapping is XCD aware: each of the 8 XCDs owns a compact region of
-//                   tiles so that one XCD's L2 sees one region of the BVH
+//   blocks        -> the launch has as many workgroups as are resident at once and every WAVE pulls
+//                   8 x 8 blocks from the queue of the XCD it runs on (persistent waves, round 5); the order
+//                   of a queue is that of the XCD-aware tile map: each of the 8 XCDs walks compact patches
+//                   of 16 x 16 tiles, so that one XCD's L2 sees one region of the BVH.  (Launches with fewer
+//                   tiles than that, redo launches and the counting monitor: workgroup b = tile b, wave = quadrant.)
+//   leftover cells: a block ends when at most 16 of its cells are unfinished; a second launch (LEFT) finishes those.
 //
 // Per lane a small state machine (Search) produces the next elevation sample as
 // soon as the previous occlusion query finishes; lanes never wait for an azimuth
@@ -80,8 +84,7 @@ struct HorizonParams {
 #ifdef HZ_WG_TRACE   // measurement probe (scripts/build_variant.sh trace -DHZ_WG_TRACE): start / end of every wave on the 100 MHz clock
 __device__ unsigned long long *hz_wg_trace_buf = nullptr;      // [waves of the launch][2]
 #endif
-// One leftover record (a real call: it runs once per handed-over cell, at the end of a block, and must not weigh on the kernel's
-// register allocation).  (row, column) come from the launch-local cell number.
+// One leftover record (written once per handed-over cell, at the end of a block).  (row, column) come from the launch-local cell number.
 __device__ __forceinline__ void hz_left_write(unsigned *w, unsigned cert, unsigned dim_in_1, unsigned row_begin, unsigned k, unsigned flags,
                                                         unsigned ind, unsigned prev, unsigned pazim, unsigned count, float lim_up, float lim_low,
                                                         float elev_samp, float ev, unsigned cache, float st0, float st1, float st2) {
@@ -322,24 +325,24 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
     const int left_min = (COUNT || LEFT || __popcll(__ballot(!done)) <= 2 * p.left_min) ? 0 : p.left_min;
     while (__ballot(!done) != 0ull) {
         if (!COUNT && !LEFT && left_min > 0 && __popcll(__ballot(!done)) <= left_min) {
-        // cells still unfinished (<= left_min of them): they go to the leftover launch (the buffer has room for every cell of the
-        // launch: a cell is handed over at most once).  A wave whose fast stack overflowed hands nothing over: its block is computed again.
-        const unsigned long long um = __ballot(!done);
-        if (um != 0ull && !(!LEVELSTACK && __ballot(overflow) != 0ull)) {
-            const int n = __popcll(um);
-            unsigned base = 0u;
-            if (lane == 0) base = atomicAdd(&p.left_cnt[0], (unsigned)n);
-            base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-            if (!done) {
-                const unsigned rank = (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
-                const unsigned flags = (unsigned)s.phase | (last_hit ? 0x100u : 0u) | (ray_active ? 0x200u : 0u) | ((guards != 0u) ? 0x400u : 0u);
-                hz_left_write(p.left_rec + (size_t)(base + rank) * HZ_LEFT_WORDS, cert, (unsigned)p.dim_in_1, (unsigned)p.row_begin, (unsigned)s.k, flags,
-                              (unsigned)s.ind, (unsigned)s.prev, (unsigned)s.pazim, (unsigned)s.count, s.lim_up, s.lim_low, s.elev_samp, s.ev, (unsigned)cache,
-                              STAGE ? out.stage[0] : 0.0f, STAGE ? out.stage[out.stride] : 0.0f, STAGE ? out.stage[2 * out.stride] : 0.0f);
-                done = true;
+            // cells still unfinished (<= left_min of them): they go to the leftover launch (the buffer has room for every cell of the
+            // launch: a cell is handed over at most once).  A wave whose fast stack overflowed hands nothing over: its block is computed again.
+            const unsigned long long um = __ballot(!done);
+            if (um != 0ull && !(!LEVELSTACK && __ballot(overflow) != 0ull)) {
+                const int n = __popcll(um);
+                unsigned base = 0u;
+                if (lane == 0) base = atomicAdd(&p.left_cnt[0], (unsigned)n);
+                base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
+                if (!done) {
+                    const unsigned rank = (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
+                    const unsigned flags = (unsigned)s.phase | (last_hit ? 0x100u : 0u) | (ray_active ? 0x200u : 0u) | ((guards != 0u) ? 0x400u : 0u);
+                    hz_left_write(p.left_rec + (size_t)(base + rank) * HZ_LEFT_WORDS, cert, (unsigned)p.dim_in_1, (unsigned)p.row_begin, (unsigned)s.k, flags,
+                                  (unsigned)s.ind, (unsigned)s.prev, (unsigned)s.pazim, (unsigned)s.count, s.lim_up, s.lim_low, s.elev_samp, s.ev, (unsigned)cache,
+                                  STAGE ? out.stage[0] : 0.0f, STAGE ? out.stage[out.stride] : 0.0f, STAGE ? out.stage[2 * out.stride] : 0.0f);
+                    done = true;
+                }
             }
         }
-    }
 
         if (__ballot(!done) == 0ull) break;
         // ---- refill: lanes without a ray take the next sample of their search -----------------
