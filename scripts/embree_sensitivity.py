@@ -15,7 +15,11 @@ For every workload and variant it reports
                       runs with the variant (a flipped ray moves the search, so this is not the same number)
   out_max_abs_diff    largest horizon difference [rad] (bounded by the table logic: one flip moves a result by one
                       search step)
-CPU only (OpenMP oracle); writes profiles/r03/embree_sensitivity.json.
+Round 6 adds a third column, "published_test": the whole computation with the two clauses the contract gained in round 5
+switched off (orc.set_den_noise(0): Embree's published `den != 0`; orc.set_box_start(0): box tests over [0, tfar]) -- the
+published robust test against the shipped one (tests/test_oracle.py::test_round5_contract_clauses_move_no_baseline_result is
+the committed form of the same comparison).  Whole-run figures only (the per-ray comparison hook knows the two variants above).
+CPU only (OpenMP oracle); writes profiles/r06/embree_sensitivity.json (round 3: profiles/r03/).
 """
 import argparse
 import json
@@ -62,6 +66,15 @@ def horizon_case(name, kw, **par):
         out["variants"][v] = {"rays_compared": n, "ray_flips": flips, "ray_flips_per_1e6": 1e6 * flips / max(n, 1),
                               "out_mismatch": int((diff > 0).sum()), "out_mismatch_frac": float((diff > 0).mean()),
                               "out_max_abs_diff_rad": float(diff.max()), "rays_of_variant_run": sv["rays"]}
+    try:      # the published test: den != 0, box tests from 0 (the contract of rounds 1-4)
+        orc.set_den_noise(0.0); orc.set_box_start(0.0)
+        var, _, sv = orc.horizon_gridded(**kw, **par, return_stats=True)
+    finally:
+        orc.set_den_noise(); orc.set_box_start()
+    diff = np.abs(var - base)
+    out["variants"]["published_test"] = {"out_mismatch": int((diff > 0).sum()), "out_mismatch_frac": float((diff > 0).mean()),
+                                         "out_max_abs_diff_rad": float(diff.max()), "rays_of_variant_run": sv["rays"],
+                                         "guards_of_variant_run": sv["guards"], "guards": so["guards"]}
     out["seconds"] = time.time() - t0
     print(json.dumps(out), flush=True)
     return out
@@ -74,7 +87,7 @@ def shadow_case(name, g, n, off, bands, suns, refrac):
     elev = np.ascontiguousarray(g["z"][off:off + in0, off:off + in1])
     mask = np.ones((in0, in1), np.uint8)
     out = {"workload": name, "values": 0, "rays": 0,
-           "variants": {v: {"rays_compared": 0, "ray_flips": 0, "out_mismatch": 0, "sw_dir_cor_mismatch": 0} for v in VARIANTS}}
+           "variants": {v: {"rays_compared": 0, "ray_flips": 0, "out_mismatch": 0, "sw_dir_cor_mismatch": 0} for v in VARIANTS + ("published_test",)}}
     t0 = time.time()
     for rb in bands:
         sl = slice(rb, rb + 8)
@@ -96,7 +109,15 @@ def shadow_case(name, g, n, off, bands, suns, refrac):
                 r = out["variants"][v]
                 r["rays_compared"] += nn; r["ray_flips"] += fl
                 r["out_mismatch"] += int((a != b).sum()); r["sw_dir_cor_mismatch"] += int((f != h).sum())
-    for v in VARIANTS:
+            try:
+                b = np.empty_like(a); h = np.empty_like(f)
+                orc.set_den_noise(0.0); orc.set_box_start(0.0)
+                tc.shadow(s, b); tc.sw_dir_cor(s, h)
+            finally:
+                orc.set_den_noise(); orc.set_box_start()
+            r = out["variants"]["published_test"]
+            r["out_mismatch"] += int((a != b).sum()); r["sw_dir_cor_mismatch"] += int((f != h).sum())
+    for v in VARIANTS + ("published_test",):
         r = out["variants"][v]
         r["ray_flips_per_1e6"] = 1e6 * r["ray_flips"] / max(r["rays_compared"], 1)
         r["out_mismatch_frac"] = r["out_mismatch"] / max(out["values"], 1)
@@ -108,7 +129,7 @@ def shadow_case(name, g, n, off, bands, suns, refrac):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--c3-rows", type=int, default=4)
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r03", "embree_sensitivity.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "r06", "embree_sensitivity.json"))
     ap.add_argument("--quick", action="store_true")
     args = ap.parse_args()
     res = {"threads": orc.num_threads(), "variants": list(VARIANTS), "cases": []}
@@ -150,10 +171,10 @@ def main():
         json.dump(res, f, indent=1)
     # summary table
     for c in res["cases"]:
-        for v in VARIANTS:
+        for v in VARIANTS + ("published_test",):
             r = c["variants"][v]
             print("%-34s %-17s rays %11d  flips/1e6 %9.3f  output mismatch %.3e%s" % (
-                c["workload"], v, r["rays_compared"], r["ray_flips_per_1e6"], r["out_mismatch_frac"],
+                c["workload"], v, r.get("rays_compared", 0), r.get("ray_flips_per_1e6", float("nan")), r["out_mismatch_frac"],
                 ("  max |d hori| %.2e rad" % r["out_max_abs_diff_rad"]) if "out_max_abs_diff_rad" in r else ""))
 
 

@@ -208,6 +208,57 @@ def test_known_counter_example_grazing_ray_at_its_origin(orc):
         orc.set_box_start()
 
 
+def _contract_old_vs_shipped(orc, kw, **par):
+    """horizon + ray / guard counts under the shipped contract and under the published Embree test (den != 0, box tests from 0)."""
+    new, _, sn = orc.horizon_gridded(**kw, **par, return_stats=True)
+    try:
+        orc.set_den_noise(0.0); orc.set_box_start(0.0)
+        old, _, so = orc.horizon_gridded(**kw, **par, return_stats=True)
+    finally:
+        orc.set_den_noise(); orc.set_box_start()
+    return new, sn, old, so
+
+
+def test_round5_contract_clauses_move_no_baseline_result(orc):
+    """Round 5 gave the numerical contract two clauses, on the product's and the oracle's side at once:
+    the triangle test's parallel check is |den| > 2^-20 sum|n_i d_i| instead of Embree's published den != 0, and the tree's box
+    tests run over [-tau, tfar + tau] instead of [0, tfar].  Both exist to make tree == brute force on adversarial inputs (the
+    counter-example above); neither may change what the published test decides on the BASELINE inputs.  Here: config 2 with the
+    three algorithms, the large-coordinate and the tilted-frame cases, and rows of config 3 -- every horizon value, ray count and
+    guard count equal with the two clauses switched off (orc.set_den_noise(0), orc.set_box_start(0))."""
+    total = 0
+    g = cases.c2_hill()
+    for alg in ("guess_constant", "binary_search", "discrete_sampling"):
+        new, sn, old, so = _contract_old_vs_shipped(orc, cases.grid_kwargs(g), dist_search=10.0, azim_num=36, ray_algorithm=alg)
+        assert np.array_equal(new, old) and sn["rays"] == so["rays"] and sn["guards"] == so["guards"], alg
+        total += new.size
+    g = cases.c2_hill(height=1500.0)            # (the guard-event variant of config 2)
+    new, sn, old, so = _contract_old_vs_shipped(orc, cases.grid_kwargs(g), dist_search=10.0, azim_num=36)
+    assert np.array_equal(new, old) and sn["rays"] == so["rays"] and sn["guards"] == so["guards"] > 0
+    g = cases.rough_terrain(80, 90, seed=11, dx=25.0, dy=25.0, offset=5, origin=(668000.0, 172000.0))   # (tests/test_gpu_parity.py::test_large_coordinates)
+    for alg in ("guess_constant", "binary_search", "discrete_sampling"):
+        new, sn, old, so = _contract_old_vs_shipped(orc, cases.grid_kwargs(g), dist_search=1.5, azim_num=30, elev_ang_low_lim=-70.0,
+                                                   ray_algorithm=alg)
+        assert np.array_equal(new, old) and sn["rays"] == so["rays"] and sn["guards"] == so["guards"], alg
+        total += new.size
+    g = cases.rough_terrain(93, 117, seed=7, offset=6, tilt_frames=True)
+    for alg in ("guess_constant", "binary_search", "discrete_sampling"):
+        new, sn, old, so = _contract_old_vs_shipped(orc, cases.grid_kwargs(g), dist_search=2.0, azim_num=24, elev_ang_low_lim=-60.0,
+                                                   ray_algorithm=alg)
+        assert np.array_equal(new, old) and sn["rays"] == so["rays"] and sn["guards"] == so["guards"], alg
+        total += new.size
+    assert total > 1.5e6
+
+
+def test_round5_contract_clauses_move_no_config3_row(orc):
+    """The same on BASELINE config 3 (3601^2 synthetic tile, 360 azimuths, 50 km): inner-domain rows 1777-1778 (two of the five rows
+    tests/test_gpu_fullsize.py compares with the GPU; the host here has 8 cores)."""
+    g = synth.fractal_tile(n=3601, offset=16)
+    new, sn, old, so = _contract_old_vs_shipped(orc, cases.grid_kwargs(g), dist_search=50.0, azim_num=360, rows=(1777, 1779), slab_only=True)
+    assert new.shape == (2, 3569, 360) and not np.isnan(new).any()
+    assert np.array_equal(new, old) and sn["rays"] == so["rays"] and sn["guards"] == so["guards"]
+
+
 def test_horizon_bvh_equals_brute_force_and_tin(orc):
     g = cases.rough_terrain(34, 38, seed=15, offset=3, relief=500.0)
     kw = cases.grid_kwargs(g)
