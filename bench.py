@@ -77,6 +77,8 @@ def parse():
     ap.add_argument("--no-e2e", action="store_true", help="c3: skip the untimed NumPy-in / NumPy-out call of horizon_gridded")
     ap.add_argument("--no-c5-extra", action="store_true",
                     help="c3, one rank: skip the config-5 job (14401^2 mosaic, ~2 min incl. synthesis) among the untimed extras")
+    ap.add_argument("--c5-tile", type=int, default=14401, help="--gpus N > 1: DEM size of the config-5 job run over the same ranks after the c3 steps (extras.c5)")
+    ap.add_argument("--dump-c5-path", default="", help="--gpus N > 1: .npy file for the gathered SVF of the extras.c5 job (tests)")
     ap.add_argument("--no-extras", action="store_true",
                     help="c3, one rank: skip the untimed extras (whole-tile binary_search / discrete_sampling, the curved tile, c4)")
     ap.add_argument("--suns", type=int, default=144, help="c4: sun positions per step")
@@ -245,6 +247,32 @@ def main():
     fn = {"c3": (lambda c: run_sharded(c, "c3")) if strong_c3 else run_c3, "c4": run_c4,
           "c5": lambda c: run_sharded(c, "c5")}[args.workload]
     out = fn(ctx)
+    if strong_c3 and world > 1 and not args.no_extras and not args.no_c5_extra:
+        # BASELINE config 5 (the 4 x 4 mosaic, SVF-fused) over the SAME ranks: the config north_star names for 1 / 2 / 4 / 8 scaling.
+        # `value` stays the c3 shard (its N = 1 point is the plain bench line); the c5 job is one untimed-by-the-contract step
+        # with its own clock (barrier + synchronize on both sides, max over ranks: run_sharded).
+        import copy
+        a5 = copy.copy(args)
+        a5.steps, a5.warmup, a5.tile, a5.emulate_ranks = 1, 1, args.c5_tile, 0
+        a5.dump_svf_rows, a5.dump_path = ("all", args.dump_c5_path) if args.dump_c5_path else ("", "")
+        torch.cuda.empty_cache()
+        t5 = time.perf_counter()
+        o5 = run_sharded(dict(ctx, args=a5), "c5")
+        if rank == 0 and out is not None:
+            c = o5["config"]
+            out.setdefault("extras", {})["c5"] = {
+                "metric": o5["metric"], "cells_per_s": o5["value"], "mray_per_s": o5["mray_per_s"], "n_gpus": o5["n_gpus"],
+                "scaling": o5["scaling"], "job_s": o5["ms_per_step"] * 1e-3, "job_s_incl_bcast": c["job_s_incl_bcast"],
+                "cells_per_s_incl_bcast": c["cells_per_s_incl_bcast"], "scene_bcast_s": c["scene_bcast_s"],
+                "scene_bcast_bytes": c["scene_bcast_bytes"], "scene_bytes": c["scene_bytes"], "bvh_build_s": c["bvh_build_s"],
+                "slabs": c["slabs"], "t_ranks_s": c["t_ranks_s"], "load_imbalance_max_over_mean": c["load_imbalance_max_over_mean"],
+                "load_imbalance_predicted": c["load_imbalance_predicted"] if c["load_imbalance_predicted"] is not None else
+                    (max(e - b for b, e in c["slabs"]) * len(c["slabs"]) / max(sum(e - b for b, e in c["slabs"]), 1) if c["slabs"] else None),
+                "kernel_s_rank0": c["kernel_s_rank0"],
+                "gathered_svf_finite": c["gathered_svf_finite"], "workload": c["workload"],
+                "wall_s_incl_synthesis": time.perf_counter() - t5,
+                "note": "BASELINE config 5 over the same %d ranks, after the c3 steps: one step = the whole inner domain, row slabs "
+                        "balanced by %s; outside `value`" % (world, "sampled cost" if args.balance == "cost" else "cell count")}
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -580,12 +608,23 @@ def c3_extras(ctx, L, scene, step_args, peaks, g):
                            refrac_cor=refrac, scene=scene)
         for which, fn, dt in (("shadow", terrain.shadow_batch, torch.uint8), ("sw_dir_cor", terrain.sw_dir_cor_batch, torch.float32)):
             o = torch.empty((S, in0, in1), dtype=dt, device=dev)
+            cw4 = None
+            if not args.no_count:       # counter pass (untimed): node visits / triangle tests / wave iterations of all positions
+                terrain.count_work(True)
+                fn(suns, o)
+                cw4 = dict(terrain.last_stats)
+                terrain.count_work(False)
             fn(suns, o)
             fn(suns, o)
             ks = terrain.last_stats["t_kernel_s"]
+            r4 = c4_roofline(n, S, in0 * in1, which == "shadow", ks, cw4, refrac, peaks, (peaks or {}).get("class_rates"))
             c4["%s_refrac_%d" % (which, int(refrac))] = {"ms_per_sun_position": 1e3 * ks / S, "kernel_ms_per_step": 1e3 * ks,
                                                         "cells_per_s": S * in0 * in1 / ks,
-                                                        "mray_per_s": terrain.last_stats["num_rays"] / ks / 1e6}
+                                                        "mray_per_s": terrain.last_stats["num_rays"] / ks / 1e6,
+                                                        "roofline": {k: r4.get(k) for k in (
+                                                            "bound", "achieved", "peak", "unit", "frac", "frac_8d_hbm_model", "binding_resource",
+                                                            "frac_valu_counter_floor", "frac_model_raw", "frac_uniform_4_cycle", "nodes_per_ray",
+                                                            "tris_per_ray", "lane_utilisation_node_leaf_steps", "valu_winst_per_step_model")}}
             del o
         del terrain
     c4["note"] = "Terrain.shadow_batch / sw_dir_cor_batch over %d diurnal sun positions in one launch, outputs resident in HBM" % S
@@ -1068,6 +1107,61 @@ def emulate_ranks(ctx, in0, in1, run_slab, probe, n_samples, blob_bytes):
                          "frac": None, "traffic": None, "note": "load-balance probe, see the c3 line for the kernel"}}
 
 
+def c4_roofline(n, S, cells, shadow, k_step, cw, refrac, peaks, cr):
+    """Section 8(d) figures of one step (S sun positions, one launch) of k_shadow_refill: algorithmic bytes / kernel time / HBM peak
+    (`frac`, cache-served), and -- with a counting pass `cw` (and the machine calibration `peaks`, `cr`) -- the VALU-issue
+    bracket that actually binds (counter floor, class model), as for k_horizon.  shadow_comp.cpp:386-605."""
+    V = n * n
+    out_b = 1 if shadow else 4
+    # SURVEY 8(d) "shadow bytes": 12 V + 33 C once at initialise, 1 C (shadow) / 4 C (sw_dir_cor) per sun position;
+    # B_trav = rays x (node visits x 32 B + triangle tests x 24 B) from the counting pass -- served by the caches
+    b_io = S * out_b * cells + (12.0 * V + 33.0 * cells)
+    b_trav = (cw["nodes_visited"] * NODE_BYTES + cw["tris_tested"] * 24.0) if cw else 0.0
+    alg = (b_io + b_trav) / k_step / 1e9 if k_step else None
+    roof = {"kernel": "hz::k_shadow_refill<false> (all sun positions of a step in one launch, lane refill)",
+            "kernel_ms_per_step": 1e3 * k_step, "traffic": None,
+            "hbm": {"peak_gbs": HBM_PEAK_GBS, "alg_bytes_per_step": b_io + b_trav, "io_bytes_per_step": b_io,
+                    "alg_gbs_cache_served": alg,
+                    "note": "algorithmic bytes (SURVEY 8d) are almost all node re-reads served by L1 / L2: the figure may exceed "
+                            "the HBM peak and is not an HBM utilisation; the compulsory bytes are io_bytes_per_step"}}
+    if cw:
+        # VALU port as the bound, as for k_horizon: the traversal is the same hz_trace (147 / 218 wave instructions per node /
+        # leaf step, class mix of those sections); the per-cell set-up (ray, self-shading test, refraction) is priced with
+        # SETUP wave instructions per 64 cells handed out (calibrated on SQ_INSTS_VALU, profiles/r03/pmc_shadow_refill.json)
+        n_it, l_it = cw["wave_node_iters"], cw["wave_leaf_iters"]
+        rounds = S * cells / 64.0
+        vm, vmix, vnotes = load_valu_model()
+        # (calibrated with the traversal constants on the shadow kernel's own SQ_INSTS_VALU when the profiles are current;
+        #  refraction adds the round-3 difference of the two built-in figures)
+        setup = vm.pop("shadow_setup", SHADOW_SETUP_WINST[0]) + (SHADOW_SETUP_WINST[1] - SHADOW_SETUP_WINST[0]) * int(bool(refrac))
+        winst = vm["node_iter"] * n_it + vm["leaf_iter"] * l_it + setup * rounds
+        roof.update({"nodes_per_ray": cw["nodes_visited"] / max(cw["num_rays"], 1), "tris_per_ray": cw["tris_tested"] / max(cw["num_rays"], 1),
+                     "wave_node_iters": n_it, "wave_leaf_iters": l_it,
+                     "lane_utilisation_node_leaf_steps": (cw["nodes_visited"] + cw["tris_tested"] / 2.0) / max(64.0 * (n_it + l_it), 1.0),
+                     "valu_winst_per_step_model": winst})
+        if peaks:
+            cr = cr or {"fast_cycles": 2.4, "slow_cycles": 4.15}
+            cyc = lambda f: f * cr["fast_cycles"] + (1.0 - f) * cr["slow_cycles"]
+            need = (vm["node_iter"] * n_it * cyc(vmix["node_step"])
+                    + vm["leaf_iter"] * l_it * cyc(vmix["leaf_step"]) + setup * rounds * cyc(0.7))
+            have = peaks["simds"] * peaks["clock_ghz"] * 1e9 * k_step
+            roof["valu"] = {"binding": True, "achieved": need / k_step / 1e9, "peak": peaks["simds"] * peaks["clock_ghz"],
+                            "unit": "G SIMD-cycles/s (VALU busy)", "frac_model_raw": need / have,
+                            "frac_valu_counter_floor": 2.0 * winst / have, "frac_uniform_4_cycle": 4.0 * winst / have,
+                            "class_rates_cycles_per_wave_inst": cr, "valu_model": vnotes["valu_model"], "valu_model_constants": vm,
+                            "class_mix_fast_fraction": vmix,
+                            "note": "as for k_horizon (c3 line): frac_model_raw = the class model at mean-priced issue rates, reported "
+                                    "raw (no cap: above 1 means the model's mix or rates are off by that much); "
+                                    "frac_valu_counter_floor = wave-level VALU instructions x 2 cycles / SIMD cycles of the launch"}
+            for k in ("frac_model_raw", "frac_valu_counter_floor", "frac_uniform_4_cycle"):
+                roof[k] = roof["valu"][k]
+    # contract fields as SURVEY 8(d) writes them (algorithmic bytes, cache-served; see hbm.note); the binding resource is the VALU port
+    roof.update({"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s (algorithmic, cache-served, see hbm.note)",
+                 "frac": alg / HBM_PEAK_GBS if alg else None, "frac_8d_hbm_model": alg / HBM_PEAK_GBS if alg else None,
+                 "binding_resource": "valu_issue" if "valu" in roof else "unknown (no counter pass)"})
+    return roof
+
+
 # ------------------------------------------------------------------------------------------------
 # config 4: shadow mask over one day of sun positions on the c3 tile
 # ------------------------------------------------------------------------------------------------
@@ -1119,59 +1213,13 @@ def run_c4(ctx):
         return None
     cells = in0 * in1
     k_step = t_kernel / max(steps, 1)
-    V = n * n
-    out_b = 1 if shadow else 4
-    # SURVEY 8(d) "shadow bytes": 12 V + 33 C once at initialise, 1 C (shadow) / 4 C (sw_dir_cor) per sun position;
-    # B_trav = rays x (node visits x 32 B + triangle tests x 24 B) from the counting pass -- served by the caches
-    b_io = S * out_b * cells + (12.0 * V + 33.0 * cells)
-    b_trav = (cw["nodes_visited"] * NODE_BYTES + cw["tris_tested"] * 24.0) if cw else 0.0
-    alg = (b_io + b_trav) / k_step / 1e9 if k_step else None
     codes = None
     if shadow:
         o = out[S // 2].cpu().numpy()
         codes = [float((o == c).mean()) for c in range(4)]
-    roof = {"kernel": "hz::k_shadow_refill<false> (all sun positions of a step in one launch, lane refill)",
-            "kernel_ms_per_step": 1e3 * k_step, "traffic": None,
-            "hbm": {"peak_gbs": HBM_PEAK_GBS, "alg_bytes_per_step": b_io + b_trav, "io_bytes_per_step": b_io,
-                    "alg_gbs_cache_served": alg,
-                    "note": "algorithmic bytes (SURVEY 8d) are almost all node re-reads served by L1 / L2: the figure may exceed "
-                            "the HBM peak and is not an HBM utilisation; the compulsory bytes are io_bytes_per_step"}}
-    if cw:
-        # VALU port as the bound, as for k_horizon: the traversal is the same hz_trace (147 / 218 wave instructions per node /
-        # leaf step, class mix of those sections); the per-cell set-up (ray, self-shading test, refraction) is priced with
-        # SETUP wave instructions per 64 cells handed out (calibrated on SQ_INSTS_VALU, profiles/r03/pmc_shadow_refill.json)
-        n_it, l_it = cw["wave_node_iters"], cw["wave_leaf_iters"]
-        rounds = S * cells / 64.0
-        vm, vmix, vnotes = load_valu_model()
-        # (calibrated with the traversal constants on the shadow kernel's own SQ_INSTS_VALU when the profiles are current;
-        #  refraction adds the round-3 difference of the two built-in figures)
-        setup = vm.pop("shadow_setup", SHADOW_SETUP_WINST[0]) + (SHADOW_SETUP_WINST[1] - SHADOW_SETUP_WINST[0]) * int(bool(args.refrac))
-        winst = vm["node_iter"] * n_it + vm["leaf_iter"] * l_it + setup * rounds
-        roof.update({"nodes_per_ray": cw["nodes_visited"] / max(cw["num_rays"], 1), "tris_per_ray": cw["tris_tested"] / max(cw["num_rays"], 1),
-                     "wave_node_iters": n_it, "wave_leaf_iters": l_it,
-                     "lane_utilisation_node_leaf_steps": (cw["nodes_visited"] + cw["tris_tested"] / 2.0) / max(64.0 * (n_it + l_it), 1.0),
-                     "valu_winst_per_step_model": winst})
-        peaks = machine_peaks(_lib.lib(), ctx["local_rank"]) if not args.no_peaks else None
-        if peaks:
-            cr = inst_class_rates(_lib.lib(), ctx["local_rank"])
-            cyc = lambda f: f * cr["fast_cycles"] + (1.0 - f) * cr["slow_cycles"]
-            need = (vm["node_iter"] * n_it * cyc(vmix["node_step"])
-                    + vm["leaf_iter"] * l_it * cyc(vmix["leaf_step"]) + setup * rounds * cyc(0.7))
-            have = peaks["simds"] * peaks["clock_ghz"] * 1e9 * k_step
-            roof["valu"] = {"binding": True, "achieved": need / k_step / 1e9, "peak": peaks["simds"] * peaks["clock_ghz"],
-                            "unit": "G SIMD-cycles/s (VALU busy)", "frac_model_raw": need / have,
-                            "frac_valu_counter_floor": 2.0 * winst / have, "frac_uniform_4_cycle": 4.0 * winst / have,
-                            "class_rates_cycles_per_wave_inst": cr, "valu_model": vnotes["valu_model"], "valu_model_constants": vm,
-                            "class_mix_fast_fraction": vmix,
-                            "note": "as for k_horizon (c3 line): frac_model_raw = the class model at mean-priced issue rates, reported "
-                                    "raw (no cap: above 1 means the model's mix or rates are off by that much); "
-                                    "frac_valu_counter_floor = wave-level VALU instructions x 2 cycles / SIMD cycles of the launch"}
-            for k in ("frac_model_raw", "frac_valu_counter_floor", "frac_uniform_4_cycle"):
-                roof[k] = roof["valu"][k]
-    # contract fields as SURVEY 8(d) writes them (algorithmic bytes, cache-served; see hbm.note); the binding resource is the VALU port
-    roof.update({"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s (algorithmic, cache-served, see hbm.note)",
-                 "frac": alg / HBM_PEAK_GBS if alg else None, "frac_8d_hbm_model": alg / HBM_PEAK_GBS if alg else None,
-                 "binding_resource": "valu_issue" if "valu" in roof else "unknown (no counter pass)"})
+    peaks = machine_peaks(_lib.lib(), ctx["local_rank"]) if (cw and not args.no_peaks) else None
+    cr = inst_class_rates(_lib.lib(), ctx["local_rank"]) if peaks else None
+    roof = c4_roofline(n, S, cells, shadow, k_step, cw, bool(args.refrac), peaks, cr)
     res = {
         "metric": "grid_cells_per_s (Terrain.%s, %d sun positions, 3601^2 SRTM-like tile)" % (args.which, S),
         "value": world * steps * S * cells / elapsed, "unit": "cells/s",

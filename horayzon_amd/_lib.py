@@ -28,7 +28,8 @@ class hz_opts(C.Structure):
                 ("skip_hori", C.c_int32), ("chunk_rows", C.c_int32),
                 ("level_stack", C.c_int32), ("hori_is_slab", C.c_int32),
                 ("no_near_skip", C.c_int32), ("verify_near", C.c_int32),
-                ("inputs_are_slab", C.c_int32), ("no_host_pin", C.c_int32)]
+                ("inputs_are_slab", C.c_int32), ("no_host_pin", C.c_int32),
+                ("left_min", C.c_int32), ("persist_grid", C.c_int32), ("left_cap_test", C.c_int32)]
 
 
 class hz_stats(C.Structure):
@@ -44,7 +45,8 @@ class hz_stats(C.Structure):
                 ("rays_shortened", C.c_uint64), ("near_violations", C.c_uint64), ("t_near_s", C.c_double),
                 ("stack_redo_blocks", C.c_uint64), ("guard_cells", C.c_uint64),
                 ("height_field", C.c_int32), ("near_used", C.c_int32), ("near_verified", C.c_uint64),
-                ("t_left_s", C.c_double), ("left_cells", C.c_uint64)]
+                ("t_left_s", C.c_double), ("left_cells", C.c_uint64),
+                ("left_again", C.c_uint64), ("scratch_bytes", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -476,6 +476,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     // traced, so the D2H time hides behind the kernel and the output may be larger than HBM.
     int chunk_rows = row_end - row_begin;
     void *tmp_hori = nullptr, *tmp_hori2 = nullptr;
+    size_t tmp_bytes = 0;         // chunk buffers of a host / skipped hori_buffer (hz_stats.scratch_bytes)
     struct TmpFree { void **p; ~TmpFree() { if (*p) (void)hipFree(*p); } } tmp_free{&tmp_hori}, tmp_free2{&tmp_hori2};
     const size_t row_bytes = (size_t)dim_in_1 * azim_num * 4;
     const bool stream_out = !skip_hori && !is_device_ptr(hori_slab_host);
@@ -516,7 +517,8 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             if (fixed || target <= ((size_t)1 << 30)) return set_error(HZ_ERR_HIP, "hipMalloc of the horizon chunk (%zu bytes) failed", (size_t)chunk_rows * row_bytes);
             target >>= 1;
         }
-        if (stream_out && chunk_rows < row_end - row_begin) HZ_HIP(hipMalloc(&tmp_hori2, (size_t)chunk_rows * row_bytes));
+        tmp_bytes = (size_t)chunk_rows * row_bytes;
+        if (stream_out && chunk_rows < row_end - row_begin) { HZ_HIP(hipMalloc(&tmp_hori2, (size_t)chunk_rows * row_bytes)); tmp_bytes *= 2; }
     } else {
         if ((rc = d_hori.bind(hori_slab_host, slab_cells * (size_t)azim_num))) return rc;
     }
@@ -599,24 +601,54 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             sc->near_bytes = need;
         }
     }
-    // Leftover cells (hz_horizon.hip): a block of a production launch ends when at most HZ_LEFT_MIN (default 16; 0: off) of its cells
-    // are unfinished -- a lane whose cell is done idles until its block's slowest cell is (12 % of the lane time, profiles/r05/
-    // probe_done_lanes.log) -- and a second launch finishes the cells handed over, 64 per wave.  One 64 B record per cell; the
-    // buffer has room for every cell of the largest chunk (a cell is handed over at most once) and is kept with the scene.
-    static const int left_min_env = []() { const char *e = getenv("HZ_LEFT_MIN"); return e ? atoi(e) : 16; }();
-    const bool use_left = left_min_env > 0 && !(opts && opts->count_work);
-    if (use_left) {
-        const size_t cells = (size_t)std::min(chunk_rows, row_end - row_begin) * dim_in_1;
-        const size_t need = cells * HZ_LEFT_WORDS * sizeof(unsigned);
-        if (sc->left_bytes < need) {
+    // Leftover cells (hz_horizon.hip): a block of a production launch ends when at most t[0] (default 16; opts.left_min) of its cells are
+    // unfinished -- a lane whose cell is done idles until its block's slowest cell is (12 % of the lane time, profiles/r05/
+    // probe_done_lanes.log) -- and follow-up launches finish the cells handed over, 64 per wave, sorted by the azimuths they have left
+    // and by position (left_sort); a wave of follow-up launch l may hand over again at t[l], the last one runs to the end.  How many
+    // records a level got is only known on the device: keys, sort and follow-up launches are sized by the region's capacity and read
+    // the counts there, the host never waits between them.  One 64 B record per hand-over; region l is sized from what the level
+    // above can hand over at most; a region that still runs out of room stops the hand-over (hz_horizon.hip).  Kept with the scene.
+    int left_t[HZ_LEFT_LEVELS] = {0, 0, 0, 0};
+    int n_left_launches = 0;
+    {
+        const int pack = opts ? opts->left_min : 0;
+        const unsigned upack = pack == 0 ? HZ_LEFT_DEFAULT : (pack < 0 ? 0u : (unsigned)pack);
+        for (int l = 0; l < HZ_LEFT_LEVELS; l++) {
+            left_t[l] = (int)std::min((upack >> (8 * l)) & 0xffu, 56u);
+            if (left_t[l] == 0) break;      // (a level that does not hand over is the last one)
+            n_left_launches = l + 1;
+        }
+        if (opts && opts->count_work) n_left_launches = 0;
+    }
+    if (n_left_launches > 0) {
+        const int rows_max = std::min(chunk_rows, row_end - row_begin);
+        const TileMap tm = make_tile_map((rows_max + 15) / 16, (dim_in_1 + 15) / 16);
+        unsigned long long units = (unsigned long long)tm.per_xcd * 8ull * 4ull;      // 8 x 8 blocks, then groups of 64 records
+        unsigned long long total = 0, cap_max = 0;
+        for (int l = 0; l < n_left_launches; l++) {
+            unsigned long long cap = ((units * (unsigned long long)left_t[l] + 63ull) & ~63ull) + 64ull;
+            if (opts && opts->left_cap_test > 0) cap = std::min<unsigned long long>(cap, ((unsigned long long)opts->left_cap_test + 63ull) & ~63ull);
+            a.left_base[l] = (unsigned)total; a.left_cap[l] = (unsigned)cap;
+            total += cap; cap_max = std::max(cap_max, cap);
+            units = cap / 64ull;
+        }
+        const size_t rec_bytes = (size_t)total * HZ_LEFT_WORDS * sizeof(unsigned);
+        const size_t sort_words = 4 * (size_t)cap_max + sort_temp_elems((size_t)cap_max) + 64;
+        const size_t need = rec_bytes + sort_words * sizeof(uint32_t);
+        const bool fits = total < (1ull << 31) && (unsigned long long)rows_max * (unsigned long long)dim_in_1 < 0xffffffffull;
+        if (fits && sc->left_bytes < need) {
             if (sc->left_buf) (void)hipFree(sc->left_buf);
             sc->left_buf = nullptr; sc->left_bytes = 0;
             if (hipMalloc(&sc->left_buf, need) != hipSuccess) { (void)hipGetLastError(); sc->left_buf = nullptr; }     // (no room: the blocks run to their end)
             else sc->left_bytes = need;
         }
+        if (!fits || !sc->left_buf) n_left_launches = 0;
+        else { a.left_sort = (uint32_t *)((char *)sc->left_buf + rec_bytes); a.left_cap_max = (unsigned)cap_max; }
     }
-    a.left_min = (use_left && sc->left_buf) ? std::min(left_min_env, 32) : 0;
-    a.left_rec = (use_left && sc->left_buf) ? (unsigned *)sc->left_buf : nullptr;
+    a.left_min = n_left_launches > 0 ? left_t[0] : 0;
+    a.left_rec = n_left_launches > 0 ? (unsigned *)sc->left_buf : nullptr;
+    a.persist_grid = (opts && opts->persist_grid > 0) ? opts->persist_grid : 0;
+    a.no_persist = (opts && opts->persist_grid < 0) ? 1 : 0;
     // HZ_NEAR_REASONS=1: histogram of why cells got no certificate, printed to stderr at the end of the call
     unsigned *near_reasons = nullptr;
     struct ReasonsFree { unsigned **p; ~ReasonsFree() { if (*p) (void)hipFree(*p); } } reasons_free{&near_reasons};
@@ -656,7 +688,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     };
     auto fail = [&](int code) { (void)hipStreamSynchronize(st); if (st_copy) (void)hipStreamSynchronize(st_copy); free_events(); return code; };
     int n_chunk = 0;
-    unsigned long long left_cells = 0;
+    unsigned long long left_cells = 0, left_again = 0;
     float ms_left = 0.0f;
     for (int rb = row_begin; rb < row_end; rb += chunk_rows, n_chunk++) {
         const int re = std::min(rb + chunk_rows, row_end);
@@ -723,11 +755,26 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
                 // workgroup lifetime, ~0.1 s, however small the sample).  Its stores go to a scratch row (HorizonArgs::scratch_row).
                 if ((rc = mon.launch(sc, a, verify_n, rb, st))) return fail(rc);
             }
+            // production launch + the follow-up launches of the cells it leaves unfinished (no host wait in between)
+            auto launch_chunk = [&](int *safe_out) -> int {
+                int r = horizon_launch(sc, a, st, safe_out);
+                if (r || n_left_launches == 0) return r;
+                if (!evs.back().l && hipEventCreate(&evs.back().l) != hipSuccess) return set_error(HZ_ERR_HIP, "hipEventCreate failed");
+                (void)hipEventRecord(evs.back().l, st);
+                for (int l = 1; l <= n_left_launches && !r; l++) {
+                    if ((r = left_sort(a, l - 1, st))) break;
+                    HorizonArgs b = a;
+                    b.left_mode = l; b.left_min = l < n_left_launches ? left_t[l] : 0;
+                    b.level_stack = 1; b.tile_list = nullptr; b.n_list = 0;      // (one entry per level: nothing can overflow there)
+                    r = horizon_launch(sc, b, st, nullptr);
+                }
+                return r;
+            };
             int safe = 0;
-            rc = horizon_launch(sc, a, st, &safe);
+            rc = launch_chunk(&safe);
             if (!rc && !safe) {
-                // fast stack discipline: did a wave run out of entries?  Its 8 x 8 block does not count and is computed
-                // again with the one-entry-per-level kernel: block by block when they are few (deep trees overflow in a
+                // fast stack discipline: did a wave run out of entries?  Its 8 x 8 block does not count (and handed nothing over) and is
+                // computed again with the one-entry-per-level kernel: block by block when they are few (deep trees overflow in a
                 // few places only), the whole launch -- and every later launch on this scene -- when they are many
                 unsigned long long ov = 0;
                 if (hipMemcpyAsync(&ov, (unsigned long long *)cnt_dev + 8, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
@@ -748,23 +795,8 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
                         if (hipMemcpyAsync(cnt_dev, zeros, sizeof(zeros), hipMemcpyHostToDevice, st) != hipSuccess)
                             return fail(set_error(HZ_ERR_HIP, "counter reset failed"));
                         (void)hipEventRecord(e.a, st);
-                        rc = horizon_launch(sc, a, st, &safe);
+                        rc = launch_chunk(&safe);
                     }
-                }
-            }
-            if (!rc && a.left_rec != nullptr) {
-                // the cells the blocks handed over: finished by a second launch (one entry per level: nothing can overflow there)
-                unsigned n_left = 0;
-                if (hipMemcpyAsync(&n_left, (unsigned long long *)cnt_dev + 28, sizeof(n_left), hipMemcpyDeviceToHost, st) != hipSuccess ||
-                    hipStreamSynchronize(st) != hipSuccess)
-                    return fail(set_error(HZ_ERR_HIP, "horizon kernel failed: %s", hipGetErrorString(hipGetLastError())));
-                if (n_left != 0) {
-                    if (hipEventCreate(&evs.back().l) != hipSuccess) return fail(set_error(HZ_ERR_HIP, "hipEventCreate failed"));
-                    (void)hipEventRecord(evs.back().l, st);
-                    HorizonArgs b = a;
-                    b.left_mode = 1; b.left_n = n_left; b.level_stack = 1; b.tile_list = nullptr; b.n_list = 0;
-                    left_cells += n_left;
-                    rc = horizon_launch(sc, b, st, nullptr);
                 }
             }
             if (!rc && mon.active) rc = mon.collect(st, &n_verified, &n_mon_violations);
@@ -785,6 +817,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             ms += m1; ms_svf += m2;
             if (evs.back().l) { float m3 = 0.0f; (void)hipEventElapsedTime(&m3, evs.back().l, e.b); ms_left += m3; }
             for (int k = 0; k < 16; k++) cnt[k] += c[k];
+            left_cells += c[28]; left_again += c[29];
             n_verified += c[21];
 #ifdef HZ_PROBE_Q1
             if (a.count_work) fprintf(stderr, "hz probe q1: leaf-step lanes with a second queued leaf %llu, node-step lanes blocked by a full queue %llu, node-step lanes with a decided ray %llu (lane-leaf-steps %llu = tris / 2, wave node iters %llu, wave leaf iters %llu)\n",
@@ -798,7 +831,6 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             }
         }
     }
-    if (left_cells && getenv("HZ_LEFT_TRACE")) fprintf(stderr, "hz leftover cells: %llu\n", left_cells);
     Timer t_d2h; t_d2h.start();
     if (stream_out) {
         rc = copy_out(n_chunk - 1);
@@ -825,7 +857,8 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         stats->stack_fallbacks += (uint64_t)fallbacks; stats->stack_redo_blocks += redo_blocks;
         stats->rays_shortened += cnt[9]; stats->near_violations += cnt[10] + n_mon_violations; stats->t_near_s += (double)ms_near * 1e-3;
         stats->guard_cells += cnt[11]; stats->near_verified += n_verified;
-        stats->t_left_s += (double)ms_left * 1e-3; stats->left_cells += left_cells;
+        stats->t_left_s += (double)ms_left * 1e-3; stats->left_cells += left_cells; stats->left_again += left_again;
+        stats->scratch_bytes = (uint64_t)((use_near ? sc->near_bytes : 0) + (n_left_launches > 0 ? sc->left_bytes : 0) + tmp_bytes);
         stats->height_field = height_field ? 1 : 0; stats->near_used = use_near ? 1 : 0;
     }
     if (near_reasons) {
@@ -961,7 +994,7 @@ extern "C" {
 
 const char *hz_last_error(void) { return g_error.c_str(); }
 
-int hz_abi_version(void) { return 5; }
+int hz_abi_version(void) { return 6; }
 
 int hz_abi_struct_sizes(int *opts_bytes, int *stats_bytes) {
     if (opts_bytes) *opts_bytes = (int)sizeof(hz_opts);

@@ -65,12 +65,18 @@ struct HorizonParams {
     const int *tile_list;          // null, or the n_list blocks (workgroup number * 4 + wave, of the full launch) to repeat
     int n_list;
     int *redo_list;                // !LEVELSTACK: waves whose stack overflowed append their block here (count: counters[8])
-    // Leftover cells (round 5): a block of a production launch ENDS when at most left_min of its cells are unfinished; those lanes
-    // append their cell's state to left_rec (HZ_LEFT_WORDS words per cell, count in left_cnt[0], room for left_cap cells) and a
-    // second launch (left_mode = 1: 64 records per wave instead of an 8 x 8 block; such blocks run to the end) finishes them.
+    // Leftover cells (rounds 5 - 6): a block ENDS when at most left_min of its cells are unfinished; those lanes append their cell's state
+    // (HZ_LEFT_WORDS words per cell) to the OUT region of left_rec (out_ctl[0] = slots allocated there), and a later launch (left_mode =
+    // level >= 1, the LEFT instantiation) finishes them, 64 records per wave -- and may hand over again, to the next level's region
+    // (left_min > 0 there too).  Between the two launches the records are SORTED (left_sort below: by azimuths still to do, then by
+    // position): a LEFT wave takes 64 consecutive entries of the sorted permutation left_perm -- cells with the same number of
+    // azimuths left, next to each other on the DEM -- so that its rays are coherent and its lanes finish together.  in_ctl[1] = valid
+    // records (written by the sort's key kernel), in_ctl[8 + x] = groups handed to XCD x.  A region out of room stops the hand-over.
     int left_min, left_mode;
-    unsigned left_cap, left_n;     // left_n (left_mode): records to process
-    unsigned *left_rec, *left_cnt;
+    unsigned left_in_base;                   // LEFT: first record of the region to finish
+    unsigned left_out_base, left_out_cap;    // left_min > 0: first record and capacity of the region this launch hands over to
+    unsigned *left_rec, *left_in_ctl, *left_out_ctl;
+    const unsigned *left_perm;               // LEFT: sorted record numbers (relative to left_in_base)
     int persist;                   // 1: persistent waves -- the launch has as many workgroups as are resident at once and every WAVE pulls 8 x 8
     unsigned *queue;               //    blocks from the queue of its XCD (queue[x] = blocks of XCD x handed out so far) until all are empty
 };
@@ -84,12 +90,13 @@ struct HorizonParams {
 #ifdef HZ_WG_TRACE   // measurement probe (scripts/build_variant.sh trace -DHZ_WG_TRACE): start / end of every wave on the 100 MHz clock
 __device__ unsigned long long *hz_wg_trace_buf = nullptr;      // [waves of the launch][2]
 #endif
-// One leftover record (written once per handed-over cell, at the end of a block).  (row, column) come from the launch-local cell number.
-__device__ __forceinline__ void hz_left_write(unsigned *w, unsigned cert, unsigned dim_in_1, unsigned row_begin, unsigned k, unsigned flags,
+// One leftover record (written once per hand-over of a cell, at the end of a block).  Word 0 is the launch-local cell number
+// (row - row_begin) * dim_in_1 + column (32 bits: the host switches the hand-over off for launches of 2^32 - 1 cells or more);
+// ~0u marks a slot that was reserved and never filled.
+__device__ __forceinline__ void hz_left_write(unsigned *w, unsigned cert, unsigned k, unsigned flags,
                                                         unsigned ind, unsigned prev, unsigned pazim, unsigned count, float lim_up, float lim_low,
                                                         float elev_samp, float ev, unsigned cache, float st0, float st1, float st2) {
-    const unsigned di = cert / dim_in_1, dj = cert - di * dim_in_1;
-    w[0] = (di + row_begin) | (dj << 16);
+    w[0] = cert;
     w[1] = k; w[2] = flags; w[3] = ind; w[4] = prev; w[5] = pazim; w[6] = count;
     w[7] = __float_as_uint(lim_up); w[8] = __float_as_uint(lim_low); w[9] = __float_as_uint(elev_samp); w[10] = __float_as_uint(ev);
     w[11] = cache; w[12] = __float_as_uint(st0); w[13] = __float_as_uint(st1); w[14] = __float_as_uint(st2); w[15] = 0u;
@@ -155,6 +162,7 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
     // piece of the DEM), then from the other XCDs' queues.  A block is computed exactly as before: results cannot change.
     const int xcc_own = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);      // HW_REG_XCC_ID, bits 3:0
     int xcc_off = 0;                 // queues xcc_own .. xcc_own + xcc_off - 1 (mod 8) were found empty
+    int left_on = 1;                 // 0: the region of the handed-over cells is full, this wave's blocks run to their end
   for (;;) {                         // one 8 x 8 block per pass (exactly one pass without p.persist)
     asm volatile("" : "+s"(pk));
     HZ_LOAD_PARAMS(p);
@@ -171,7 +179,24 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
 #undef HZ_KEEP
     int ti = 0, tj = 0;
     int blk = (int)blockIdx.x * HZ_WPB + wave;
-    if (p.persist) {
+    unsigned rec0 = 0u, rec_n = 0u;                  // LEFT: first entry of the sorted permutation of this wave's group, entries in it
+    if (LEFT) {
+        // the next group of 64 sorted records.  The sorted order is cut into runs of 32 groups (2048 records: neighbours on the DEM
+        // with the same number of azimuths left) that go round robin to the XCDs; a wave takes the next group of its XCD's runs,
+        // then of the other XCDs'.
+        blk = -1;
+        const unsigned groups = (p.left_in_ctl[1] + 63u) / 64u;
+        while (xcc_off < 8) {
+            const unsigned x = (unsigned)((xcc_own + xcc_off) & 7);
+            unsigned q = 0u;
+            if (lane == 0) q = atomicAdd(&p.left_in_ctl[8 + x], 1u);
+            q = (unsigned)__builtin_amdgcn_readfirstlane((int)q);
+            const unsigned g = (((q >> 5) * 8u + x) << 5) | (q & 31u);
+            if (g < groups) { blk = (int)g; rec0 = g * 64u; rec_n = min(64u, p.left_in_ctl[1] - g * 64u); break; }
+            xcc_off++;                                           // (g grows with q: this XCD's runs are used up)
+        }
+        if (blk < 0) break;
+    } else if (p.persist) {
         blk = -1;
         while (xcc_off < 8) {
             const int x = (xcc_own + xcc_off) & 7;
@@ -195,9 +220,14 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
     int j = tj * 16 + (blk & 1) * 8 + (lane & 7);
     const unsigned *rec = nullptr;                   // left_mode: this lane's record
     if (LEFT) {
-        const unsigned idx = (unsigned)blk * 64u + (unsigned)lane;
-        has_tile = blk >= 0 && idx < p.left_n;
-        if (has_tile) { rec = p.left_rec + (size_t)idx * HZ_LEFT_WORDS; i = (int)(rec[0] & 0xffffu); j = (int)(rec[0] >> 16); }
+        has_tile = (unsigned)lane < rec_n;
+        if (has_tile) {
+            rec = p.left_rec + ((size_t)p.left_in_base + (size_t)p.left_perm[rec0 + (unsigned)lane]) * HZ_LEFT_WORDS;
+            const unsigned c0 = rec[0];
+            has_tile = c0 != 0xffffffffu;
+            const unsigned di = c0 / (unsigned)p.dim_in_1;
+            i = p.row_begin + (int)di; j = (int)(c0 - di * (unsigned)p.dim_in_1);
+        }
     }
     const bool in_dom = has_tile && (i < p.row_end) && (j < p.dim_in_1);
 
@@ -322,24 +352,33 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
     }
 
     // (a block that starts with few cells -- the ragged rim of the domain -- is not worth a hand-over)
-    const int left_min = (COUNT || LEFT || __popcll(__ballot(!done)) <= 2 * p.left_min) ? 0 : p.left_min;
+    int left_min = (COUNT || !left_on || __popcll(__ballot(!done)) <= p.left_min + 8) ? 0 : p.left_min;
     while (__ballot(!done) != 0ull) {
-        if (!COUNT && !LEFT && left_min > 0 && __popcll(__ballot(!done)) <= left_min) {
-            // cells still unfinished (<= left_min of them): they go to the leftover launch (the buffer has room for every cell of the
-            // launch: a cell is handed over at most once).  A wave whose fast stack overflowed hands nothing over: its block is computed again.
+        if (!COUNT && left_min > 0 && __popcll(__ballot(!done)) <= left_min) {
+            // cells still unfinished (<= left_min of them): they go to the next leftover launch.  A wave whose fast stack overflowed
+            // hands nothing over: its block is computed again.
             const unsigned long long um = __ballot(!done);
             if (um != 0ull && !(!LEVELSTACK && __ballot(overflow) != 0ull)) {
-                const int n = __popcll(um);
+                const unsigned n = (unsigned)__popcll(um);
+                unsigned *const out_rec = p.left_rec + (size_t)p.left_out_base * HZ_LEFT_WORDS;
                 unsigned base = 0u;
-                if (lane == 0) base = atomicAdd(&p.left_cnt[0], (unsigned)n);
+                if (lane == 0) base = atomicAdd(&p.left_out_ctl[0], n);
                 base = (unsigned)__builtin_amdgcn_readfirstlane((int)base);
-                if (!done) {
-                    const unsigned rank = (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
-                    const unsigned flags = (unsigned)s.phase | (last_hit ? 0x100u : 0u) | (ray_active ? 0x200u : 0u) | ((guards != 0u) ? 0x400u : 0u);
-                    hz_left_write(p.left_rec + (size_t)(base + rank) * HZ_LEFT_WORDS, cert, (unsigned)p.dim_in_1, (unsigned)p.row_begin, (unsigned)s.k, flags,
-                                  (unsigned)s.ind, (unsigned)s.prev, (unsigned)s.pazim, (unsigned)s.count, s.lim_up, s.lim_low, s.elev_samp, s.ev, (unsigned)cache,
-                                  STAGE ? out.stage[0] : 0.0f, STAGE ? out.stage[out.stride] : 0.0f, STAGE ? out.stage[2 * out.stride] : 0.0f);
-                    done = true;
+                if (base + n > p.left_out_cap) {
+                    // the region is full: this block runs to its end, as do this wave's later ones; the slots the counter moved
+                    // over below the capacity stay unfilled (~0u in word 0: the sort's key kernel skips them)
+                    left_on = 0; left_min = 0;
+                    if (base + (unsigned)lane < p.left_out_cap) out_rec[(size_t)(base + (unsigned)lane) * HZ_LEFT_WORDS] = 0xffffffffu;
+                } else {
+                    if (lane == 0) atomicAdd(&p.counters[LEFT ? 29 : 28], (unsigned long long)n);      // (statistics: hz_stats.left_cells / left_again)
+                    if (!done) {
+                        const unsigned rank = (unsigned)__builtin_amdgcn_mbcnt_hi((unsigned)(um >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)um, 0u));
+                        const unsigned flags = (unsigned)s.phase | (last_hit ? 0x100u : 0u) | (ray_active ? 0x200u : 0u) | ((guards != 0u || had_guard) ? 0x400u : 0u);
+                        hz_left_write(out_rec + (size_t)(base + rank) * HZ_LEFT_WORDS, cert, (unsigned)s.k, flags,
+                                      (unsigned)s.ind, (unsigned)s.prev, (unsigned)s.pazim, (unsigned)s.count, s.lim_up, s.lim_low, s.elev_samp, s.ev, (unsigned)cache,
+                                      STAGE ? out.stage[0] : 0.0f, STAGE ? out.stage[out.stride] : 0.0f, STAGE ? out.stage[2 * out.stride] : 0.0f);
+                        done = true;
+                    }
                 }
             }
         }
@@ -501,30 +540,41 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
   }     // next block of this wave
 }
 
+// Workgroups of `func` (HZ_TPB threads, `lds` bytes of dynamic LDS) the current device keeps resident at once; 0: unknown.  Asked once
+// per (kernel, LDS size, device): the occupancy query and hipGetDeviceProperties are host-side work in front of every launch otherwise.
+static long long resident_workgroups(const void *func, size_t lds) {
+    struct Key { const void *f; size_t lds; int dev; long long n; };
+    static std::mutex mu;
+    static std::vector<Key> cache;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Key &k : cache) if (k.f == func && k.lds == lds && k.dev == dev) return k.n;
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    long long n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, func, HZ_TPB, lds) == hipSuccess && per_cu > 0 &&
+        hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+        n = (long long)per_cu * prop.multiProcessorCount;
+    else (void)hipGetLastError();
+    cache.push_back(Key{func, lds, dev, n});
+    return n;
+}
+
 template <int ALG, bool COUNT, bool STAGE, bool NODELET, bool LEVELSTACK>
-static int launch_one(const HorizonParams &p_in, int grid, size_t lds, hipStream_t st) {
-    HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_horizon<ALG, COUNT, STAGE, NODELET, LEVELSTACK>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+static int launch_one(const HorizonParams &p_in, int grid, size_t lds, int persist_grid, hipStream_t st) {
+    const void *func = reinterpret_cast<const void *>(k_horizon<ALG, COUNT, STAGE, NODELET, LEVELSTACK>);
+    HZ_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HorizonParams p = p_in;
     if (p.persist) {
         // persistent waves: as many workgroups as this instantiation keeps resident (registers and this launch's LDS), each
         // wave pulls blocks until the queues are empty.  A launch with fewer tiles than that stays one tile per workgroup.
-        int per_cu = 0, dev = 0;
-        hipDeviceProp_t prop;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void *>(k_horizon<ALG, COUNT, STAGE, NODELET, LEVELSTACK>),
-                                                         HZ_TPB, lds) != hipSuccess || per_cu <= 0 ||
-            hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || prop.multiProcessorCount <= 0) {
-            (void)hipGetLastError();
-            p.persist = 0;
-        } else {
-            // (HZ_PERSIST_GRID=n: test hook -- n workgroups, so that small grids run several blocks per wave too)
-            static const int grid_env = []() { const char *e = getenv("HZ_PERSIST_GRID"); return e ? atoi(e) : 0; }();
-            const long long resident = grid_env > 0 ? (long long)grid_env : (long long)per_cu * prop.multiProcessorCount;
-            if ((long long)grid <= resident) p.persist = 0;
-            else {
-                grid = (int)resident;
-                HZ_HIP(hipMemsetAsync(p.queue, 0, 8 * sizeof(unsigned), st));
-            }
+        // (persist_grid > 0: test hook -- that many workgroups, so that small grids run several blocks per wave too)
+        const long long resident = persist_grid > 0 ? (long long)persist_grid : resident_workgroups(func, lds);
+        if (resident <= 0 || (long long)grid <= resident) p.persist = 0;
+        else {
+            grid = (int)resident;
+            HZ_HIP(hipMemsetAsync(p.queue, 0, 8 * sizeof(unsigned), st));
         }
     }
     hipLaunchKernelGGL((k_horizon<ALG, COUNT, STAGE, NODELET, LEVELSTACK>), dim3(grid), dim3(HZ_TPB), lds, st, p);
@@ -532,31 +582,82 @@ static int launch_one(const HorizonParams &p_in, int grid, size_t lds, hipStream
     return HZ_OK;
 }
 
+// The LEFT instantiation: always persistent -- how many records there are is only known on the device (left_in_ctl), so the launch has
+// the resident number of workgroups and every wave pulls groups of 64 records until the sub-regions are empty.
 template <int ALG, bool STAGE>
-static int launch_left(const HorizonParams &p, int grid, size_t lds, hipStream_t st) {
-    HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_horizon<ALG, false, STAGE, false, true, true>),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL((k_horizon<ALG, false, STAGE, false, true, true>), dim3(grid), dim3(HZ_TPB), lds, st, p);
+static int launch_left(const HorizonParams &p, size_t lds, int persist_grid, hipStream_t st) {
+    const void *func = reinterpret_cast<const void *>(k_horizon<ALG, false, STAGE, false, true, true>);
+    HZ_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    long long grid = persist_grid > 0 ? (long long)persist_grid : resident_workgroups(func, lds);
+    if (grid <= 0) grid = 1024;
+    hipLaunchKernelGGL((k_horizon<ALG, false, STAGE, false, true, true>), dim3((unsigned)grid), dim3(HZ_TPB), lds, st, p);
     HZ_HIP(hipGetLastError());
     return HZ_OK;
 }
 
+// Sort keys of the records of one region (24 bits): the azimuths a cell still has to do, most first -- a LEFT wave's 64 cells
+// then finish together, and the longest groups start first --, then a Morton code of the cell's 16 x 16 tile, so that cells with
+// the same count are neighbours: at the same azimuth their rays are nearly parallel (coalesced node fetches, one traversal
+// order).  Slots that were never filled sort last; ctl[1] <- number of valid records.
+__device__ __forceinline__ unsigned hz_spread16(unsigned v) {
+    v &= 0xffffu; v = (v | (v << 8)) & 0x00ff00ffu; v = (v | (v << 4)) & 0x0f0f0f0fu; v = (v | (v << 2)) & 0x33333333u; v = (v | (v << 1)) & 0x55555555u;
+    return v;
+}
+__global__ __launch_bounds__(256) void k_left_keys(const unsigned *__restrict__ rec, unsigned cap, unsigned *__restrict__ ctl, unsigned dim_in_1,
+                                                   unsigned azim_num, int morton_shift, unsigned *__restrict__ keys, unsigned *__restrict__ vals) {
+    const unsigned idx = blockIdx.x * 256u + threadIdx.x;
+    const unsigned cnt = min(ctl[0], cap);
+    bool valid = false;
+    unsigned key = 0x00ffffffu;
+    if (idx < cnt) {
+        const unsigned c = rec[(size_t)idx * HZ_LEFT_WORDS];
+        if (c != 0xffffffffu) {
+            valid = true;
+            const unsigned k = rec[(size_t)idx * HZ_LEFT_WORDS + 1];
+            const unsigned r = min(azim_num > k ? azim_num - k : 0u, 511u);
+            const unsigned di = c / dim_in_1, j = c - di * dim_in_1;
+            const unsigned m = ((hz_spread16(di >> 4) << 1) | hz_spread16(j >> 4)) >> morton_shift;
+            key = ((511u - r) << 15) | (m & 0x7fffu);
+        }
+    }
+    if (idx < cap) { keys[idx] = key; vals[idx] = idx; }
+    const unsigned long long vm = __ballot(valid);
+    if ((threadIdx.x & 63) == 0 && vm != 0ull) atomicAdd(&ctl[1], (unsigned)__popcll(vm));
+}
+
+// Keys + sort of region `r` of the leftover records (a.left_base[r], a.left_cap[r] slots; how many are filled is known on the device
+// only, so all slots are sorted).  Leaves the sorted record numbers in a.left_sort + 3 * cap_max (3 passes: a -> b -> a -> b).
+int left_sort(const HorizonArgs &a, int r, hipStream_t st) {
+    const unsigned cap = a.left_cap[r];
+    if (cap == 0 || a.left_rec == nullptr || a.left_sort == nullptr) return HZ_OK;
+    unsigned *ctl = reinterpret_cast<unsigned *>(a.counters + HZ_CNT_LEFT) + 16 * r;
+    const int rows = a.row_end - a.row_begin;
+    int bits = 0;
+    while ((1 << bits) < std::max((rows + 15) / 16, (a.dim_in_1 + 15) / 16)) bits++;
+    const int shift = std::max(0, 2 * bits - 15);
+    uint32_t *ka = a.left_sort, *va = ka + a.left_cap_max, *kb = va + a.left_cap_max, *vb = kb + a.left_cap_max, *tmp = vb + a.left_cap_max;
+    hipLaunchKernelGGL(k_left_keys, dim3((cap + 255u) / 256u), dim3(256), 0, st, a.left_rec + (size_t)a.left_base[r] * HZ_LEFT_WORDS, cap, ctl,
+                       (unsigned)a.dim_in_1, (unsigned)a.azim_num, shift, ka, va);
+    HZ_HIP(hipGetLastError());
+    return radix_sort_pairs_u32(ka, va, kb, vb, cap, tmp, st, 3);
+}
+
 template <int ALG>
-static int launch_alg(const HorizonParams &p, int grid, size_t lds, bool count, bool level_stack, hipStream_t st) {
+static int launch_alg(const HorizonParams &p, int grid, size_t lds, bool count, bool level_stack, int pg, hipStream_t st) {
     const bool stage = p.stage_bytes != 0;
-    if (p.left_mode) return stage ? launch_left<ALG, true>(p, grid, lds, st) : launch_left<ALG, false>(p, grid, lds, st);
+    if (p.left_mode) return stage ? launch_left<ALG, true>(p, lds, pg, st) : launch_left<ALG, false>(p, lds, pg, st);
     if (ALG == ALG_GUESS && !count && p.top_nodes > 0) {    // opt-in LDS nodelet variant (opts.top_nodes > 0)
-        if (!level_stack) return stage ? launch_one<ALG_GUESS, false, true, true, false>(p, grid, lds, st)
-                                       : launch_one<ALG_GUESS, false, false, true, false>(p, grid, lds, st);
-        return stage ? launch_one<ALG_GUESS, false, true, true, true>(p, grid, lds, st)
-                     : launch_one<ALG_GUESS, false, false, true, true>(p, grid, lds, st);
+        if (!level_stack) return stage ? launch_one<ALG_GUESS, false, true, true, false>(p, grid, lds, pg, st)
+                                       : launch_one<ALG_GUESS, false, false, true, false>(p, grid, lds, pg, st);
+        return stage ? launch_one<ALG_GUESS, false, true, true, true>(p, grid, lds, pg, st)
+                     : launch_one<ALG_GUESS, false, false, true, true>(p, grid, lds, pg, st);
     }
     if (level_stack) {
-        if (count) return stage ? launch_one<ALG, true, true, false, true>(p, grid, lds, st) : launch_one<ALG, true, false, false, true>(p, grid, lds, st);
-        return stage ? launch_one<ALG, false, true, false, true>(p, grid, lds, st) : launch_one<ALG, false, false, false, true>(p, grid, lds, st);
+        if (count) return stage ? launch_one<ALG, true, true, false, true>(p, grid, lds, pg, st) : launch_one<ALG, true, false, false, true>(p, grid, lds, pg, st);
+        return stage ? launch_one<ALG, false, true, false, true>(p, grid, lds, pg, st) : launch_one<ALG, false, false, false, true>(p, grid, lds, pg, st);
     }
-    if (count) return stage ? launch_one<ALG, true, true, false, false>(p, grid, lds, st) : launch_one<ALG, true, false, false, false>(p, grid, lds, st);
-    return stage ? launch_one<ALG, false, true, false, false>(p, grid, lds, st) : launch_one<ALG, false, false, false, false>(p, grid, lds, st);
+    if (count) return stage ? launch_one<ALG, true, true, false, false>(p, grid, lds, pg, st) : launch_one<ALG, true, false, false, false>(p, grid, lds, pg, st);
+    return stage ? launch_one<ALG, false, true, false, false>(p, grid, lds, pg, st) : launch_one<ALG, false, false, false, false>(p, grid, lds, pg, st);
 }
 
 // 8 x 8 blocks (workgroup number * 4 + wave) a full launch over the rows of `a` numbers: the domain of HorizonArgs::tile_list
@@ -640,17 +741,24 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
     p.counters = a.counters;
     p.tile_list = a.tile_list; p.n_list = a.n_list;
     p.redo_list = reinterpret_cast<int *>(a.counters + HZ_CNT_N);
-    p.left_mode = a.left_mode ? 1 : 0; p.left_n = a.left_n;
-    p.left_rec = a.left_rec; p.left_cnt = reinterpret_cast<unsigned *>(a.counters + 28);
-    p.left_min = (a.left_rec != nullptr && !a.tile_list && !a.count_work && !a.left_mode) ? std::max(a.left_min, 0) : 0;
-    p.left_cap = 0;
-    // persistent waves (k_horizon): the default for full launches; HZ_PERSIST=0 restores one tile per workgroup (same-box A/Bs)
-    static const bool persist_env = []() { const char *e = getenv("HZ_PERSIST"); return !(e && e[0] == '0'); }();
-    p.persist = (persist_env && a.tile_list == nullptr && !a.left_mode && HZ_WPB == 4) ? 1 : 0;
+    // leftover cells: level l's records (l = 1 ..) live in region l - 1 of a.left_rec, its control words (16 per level) behind the counters
+    p.left_mode = std::max(a.left_mode, 0);
+    p.left_rec = a.left_rec;
+    unsigned *const left_ctl = reinterpret_cast<unsigned *>(a.counters + HZ_CNT_LEFT);
+    const bool hands_over = a.left_rec != nullptr && !a.tile_list && !a.count_work && a.left_min > 0 && p.left_mode < HZ_LEFT_LEVELS &&
+                            a.left_cap[p.left_mode] >= 64u;
+    p.left_min = hands_over ? std::min(a.left_min, 56) : 0;
+    p.left_in_base = p.left_mode ? a.left_base[p.left_mode - 1] : 0u;
+    p.left_perm = (p.left_mode && a.left_sort) ? a.left_sort + 3 * a.left_cap_max : nullptr;      // (left_sort: sorted values end in vals_b)
+    p.left_in_ctl = left_ctl + 16 * (p.left_mode ? p.left_mode - 1 : 0);
+    p.left_out_base = hands_over ? a.left_base[p.left_mode] : 0u;
+    p.left_out_cap = hands_over ? a.left_cap[p.left_mode] : 0u;
+    p.left_out_ctl = left_ctl + 16 * std::min(p.left_mode, HZ_LEFT_LEVELS - 1);
+    // persistent waves (k_horizon): the default for full launches; a.no_persist restores one tile per workgroup (same-box A/Bs)
+    p.persist = ((!a.no_persist && a.tile_list == nullptr && HZ_WPB == 4) || p.left_mode) ? 1 : 0;
     p.queue = reinterpret_cast<unsigned *>(a.counters + 24);
     const size_t lds = (size_t)p.pre_bytes + (size_t)p.stack_bytes + (size_t)top * sizeof(Node);
-    const int grid = a.left_mode ? (int)(((a.left_n + 63u) / 64u + HZ_WPB - 1) / HZ_WPB)
-                     : a.tile_list ? (a.n_list + HZ_WPB - 1) / HZ_WPB : p.tm.per_xcd * 8 * (4 / HZ_WPB);
+    const int grid = a.tile_list ? (a.n_list + HZ_WPB - 1) / HZ_WPB : p.tm.per_xcd * 8 * (4 / HZ_WPB);
     if (grid <= 0) return HZ_OK;
     const bool count = a.count_work != 0;
 #ifdef HZ_WG_TRACE
@@ -665,9 +773,9 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
 #endif
     int rc_launch;
     switch (a.alg) {
-        case ALG_DISCRETE: rc_launch = launch_alg<ALG_DISCRETE>(p, grid, lds, count, level_stack, st); break;
-        case ALG_BINARY: rc_launch = launch_alg<ALG_BINARY>(p, grid, lds, count, level_stack, st); break;
-        default: rc_launch = launch_alg<ALG_GUESS>(p, grid, lds, count, level_stack, st); break;
+        case ALG_DISCRETE: rc_launch = launch_alg<ALG_DISCRETE>(p, grid, lds, count, level_stack, a.persist_grid, st); break;
+        case ALG_BINARY: rc_launch = launch_alg<ALG_BINARY>(p, grid, lds, count, level_stack, a.persist_grid, st); break;
+        default: rc_launch = launch_alg<ALG_GUESS>(p, grid, lds, count, level_stack, a.persist_grid, st); break;
     }
 #ifdef HZ_WG_TRACE
     if (trace_dev) {

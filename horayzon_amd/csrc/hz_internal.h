@@ -117,6 +117,7 @@ inline TileMap make_tile_map(int tiles_i, int tiles_j, int gw = 8) {
 bool is_device_ptr(const void *p);
 
 // hz_horizon.hip
+#define HZ_LEFT_LEVELS 4                 // leftover regions (hand-over levels)
 struct HorizonArgs {
     const float *vec_norm, *vec_north;   // device
     const uint8_t *mask;                 // device
@@ -137,21 +138,33 @@ struct HorizonArgs {
     int verify_near;                     // counting instantiation: N >= 1 re-traces one of every N shortened rays from parameter 0 (1: all)
     float *scratch_row;                  // counting instantiation only: null, or a device row of azim_num floats that takes EVERY store of the launch instead of
                                          // `hori` (the certificate monitor runs next to the production launch and must not write its rows)
-    int left_min = 0;                    // production launches: a block ends when at most this many of its cells are unfinished and hands them to
-    unsigned *left_rec = nullptr;        //   left_rec (HZ_LEFT_WORDS words per cell, room for every cell of the launch; count: counters word 28); 0 / null: off
-    int left_mode = 0;                   // 1: this launch finishes the left_n cells recorded in left_rec (64 per wave)
-    unsigned left_n = 0;
+    // Leftover cells (hz_horizon.hip): a block ends when at most left_min of its cells are unfinished and appends them to region
+    // `left_mode` of left_rec; a launch with left_mode = l >= 1 finishes the records of region l - 1, in the order left_sort(l - 1) left
+    // in left_sort (and hands over again when its left_min > 0 and a region l exists).  Region r: left_cap[r] records from record left_base[r].
+    int left_min = 0;
+    unsigned *left_rec = nullptr;        // HZ_LEFT_WORDS words per record; null: off
+    int left_mode = 0;
+    unsigned left_base[HZ_LEFT_LEVELS] = {0, 0, 0, 0}, left_cap[HZ_LEFT_LEVELS] = {0, 0, 0, 0};
+    uint32_t *left_sort = nullptr;       // sort scratch: 4 arrays of left_cap_max words (keys / values, in / out) + sort_temp_elems(left_cap_max)
+    unsigned left_cap_max = 0;
+    int no_persist = 0;                  // 1: one tile per workgroup instead of persistent waves (same-box A/Bs, tests)
+    int persist_grid = 0;                // > 0 (tests): that many workgroups in a persistent launch, so that small grids run the block loop
     unsigned long long *counters;        // device u64[HZ_CNT_N] + int[HZ_REDO_CAP] (tiles to redo, count in [8]): [0] rays, [1] guards, [2] nodes, [3] tris, [4] cells,
                                          // [5..7] wave iterations, [8] waves whose fast-discipline stack overflowed,
                                          // [9] rays shortened by a certificate, [10] certificate violations (verify), [11] cells with a guard event,
                                          // [21] shortened rays that were re-traced (verify);
                                          // [24..27] = unsigned[8]: the per-XCD block queues of a persistent launch (hz_horizon.hip; zeroed by horizon_launch);
-                                         // [28] (low word): cells handed to the leftover launch
+                                         // [HZ_CNT_LEFT ..): unsigned[HZ_LEFT_LEVELS][16], the control words of the leftover regions: [r][0] = slots
+                                         // allocated in region r, [r][1] = valid records (k_left_keys), [r][8 + x] = groups of 64 handed to XCD x
 };
-#define HZ_CNT_N 32                      // u64 words in front of the redo list
+// default hand-over thresholds: byte l = level l (hz_opts.left_min)
+#define HZ_LEFT_DEFAULT 0x00000020u
+#define HZ_CNT_LEFT 32                   // first u64 word of the leftover control words
+#define HZ_CNT_N 64                      // u64 words in front of the redo list
 #define HZ_LEFT_WORDS 16                 // 32-bit words per leftover record
 #define HZ_REDO_CAP 16384                // 8 x 8 blocks of one launch that can be repeated one by one after a stack overflow
 int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *used_level_stack = nullptr);
+int left_sort(const HorizonArgs &a, int region, hipStream_t st);
 int horizon_num_blocks(const HorizonArgs &a);
 int topo_launch(int kind, const float *azim, const float *hori, const float *vec_tilt, int len_0, int len_1,
                 int len_2, float *out, hipStream_t st);
@@ -209,7 +222,7 @@ int shadow_refrac_factor(const float *elevation, size_t n, double *out, hipStrea
 size_t sort_temp_elems(size_t n);
 size_t scan_temp_elems(size_t n);
 int radix_sort_pairs_u32(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, size_t n,
-                         uint32_t *temp, hipStream_t st);
+                         uint32_t *temp, hipStream_t st, int passes = 4);
 int exclusive_scan_u32(const uint32_t *in, uint32_t *out, size_t n, uint32_t *temp, hipStream_t st);
 
 // hz_bench.hip: machine calibration kernels (current device)

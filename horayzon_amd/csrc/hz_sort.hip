@@ -160,16 +160,16 @@ size_t sort_temp_elems(size_t n) {
     return 2 * 256 * tiles + scan_temp_elems(256 * tiles);
 }
 
-// Sorts n pairs by key (all 32 bits, stable).  keys_a/vals_a hold the input and, after the
-// 4 passes (a -> b -> a -> b -> a), the sorted output; keys_b/vals_b are scratch.
+// Sorts n pairs by the low 8 * passes bits of the key (stable).  keys_a/vals_a hold the input and, after an even number of
+// passes (4: a -> b -> a -> b -> a), the sorted output; after an odd number the output is in keys_b/vals_b.
 int radix_sort_pairs_u32(uint32_t *keys_a, uint32_t *vals_a, uint32_t *keys_b, uint32_t *vals_b, size_t n,
-                         uint32_t *temp, hipStream_t st) {
+                         uint32_t *temp, hipStream_t st, int passes) {
     if (n == 0) return HZ_OK;
     const size_t tiles = (n + SORT_TILE - 1) / SORT_TILE;
     if (tiles > 0x7fffffffull / 256) return set_error(HZ_ERR_ARG, "too many primitives for the radix sort");
     uint32_t *hist = temp, *offs = temp + 256 * tiles, *scan_tmp = temp + 2 * 256 * tiles;
     uint32_t *ki = keys_a, *vi = vals_a, *ko = keys_b, *vo = vals_b;
-    for (int pass = 0; pass < 4; pass++) {
+    for (int pass = 0; pass < passes; pass++) {
         const int shift = 8 * pass;
         hipLaunchKernelGGL(k_hist, dim3((unsigned)tiles), dim3(SORT_TPB), 0, st, ki, n, shift, (uint32_t)tiles, hist);
         int rc = exclusive_scan_u32(hist, offs, 256 * tiles, scan_tmp, st);

@@ -13,6 +13,9 @@ from . import _lib
 from ._lib import Scene, hz_opts, hz_stats, ptr
 
 last_stats = None   # hz_stats of the most recent call as a dict (timers, ray count)
+# test hook: defaults of the launch-schedule options ("left_min", "persist_grid", "left_cap_test": hz_opts) for calls that do not
+# pass them -- lets the parity tests run their cases under other schedules without touching every call
+schedule_overrides = {}
 
 
 def _check_f32(a, ndim, name):
@@ -36,7 +39,7 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
                     hori_fill=0.0, ray_org_elev=0.01, *, device=0, verbose=False,
                     scene=None, svf_vec_tilt=None, svf_only=False, rows=None, count_work=False, devices=None,
                     _top_nodes=-1, _regroup=-1, _hit_cache=True, _chunk_rows=0, _near_skip=True, _level_stack=False,
-                    _verify_near=False):
+                    _verify_near=False, _left_min=0, _persist_grid=0):
     """Horizon computation for gridded domain.
 
     Parameters, units and return values are those of the reference
@@ -141,6 +144,10 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
     # True: certificates when the scene allows them; False: never; "force": even for a mesh that is not a height field (tests)
     opts.no_near_skip = -1 if _near_skip == "force" else (0 if _near_skip else 1)
     opts.level_stack = int(_level_stack)      # True / 1: level stack from the start; -n: fast stack of n entries (tests)
+    # schedule of the launches (results never depend on it; tests run the parity cases under several: schedule_overrides)
+    opts.left_min = int(_left_min or schedule_overrides.get("left_min", 0))            # leftover cells: byte l = hand-over threshold of level l; 0: default; < 0: off
+    opts.persist_grid = int(_persist_grid or schedule_overrides.get("persist_grid", 0))    # 0: persistent waves; < 0: one tile per workgroup; n > 0: n workgroups
+    opts.left_cap_test = int(schedule_overrides.get("left_cap_test", 0))
     n_verify = int(_verify_near)              # False / 0: off; True / 1: every shortened ray; N: one of every N (rounded up to 2^k)
     if n_verify < 0 or n_verify != _verify_near:
         raise ValueError("_verify_near must be a non-negative integer (or a bool)")

@@ -81,6 +81,15 @@ typedef struct hz_opts {
     int32_t no_host_pin;   /* 0 (default): a HOST hori_buffer is page-locked chunk by chunk on a helper thread while the   */
                            /*   first chunks are traced (hipHostRegister, released before the call returns), so that the  */
                            /*   device-to-host copies are DMA instead of staged pageable copies; 1: leave it pageable     */
+    int32_t left_min;      /* leftover cells (hz_horizon.hip): an 8 x 8 block of cells ends when at most this many of its  */
+                           /*   cells are unfinished; they are finished 64 at a time by follow-up launches, which hand     */
+                           /*   over again.  Byte l = the threshold of level l (0 = production launch; a zero byte: that   */
+                           /*   level runs to its end); 0: the default; < 0: off.  Results do not depend on it             */
+    int32_t persist_grid;  /* 0 (default): persistent waves -- a launch has as many workgroups as are resident at once and */
+                           /*   every wave pulls 8 x 8 blocks from its XCD's queue; < 0: one 16 x 16 tile per workgroup;   */
+                           /*   n > 0 (tests): persistent with n workgroups, so that small grids run the block loop too    */
+    int32_t left_cap_test; /* tests: > 0 caps every sub-region of the leftover records at this many (rounded up to 64), so   */
+                           /*   that the out-of-room path runs on small grids                                               */
 } hz_opts;
 
 /* Run-time self report (the quantities the reference prints,                  */
@@ -115,14 +124,17 @@ typedef struct hz_stats {
     int32_t height_field;  /* 1: the scene's DEM mesh is a height field over the world (x, y) plane                      */
     int32_t near_used;     /* 1: the near-field certificates were active in this call                                    */
     uint64_t near_verified;/* opts.verify_near: shortened rays that were traced a second time over their full length     */
-    double t_left_s;       /* leftover launch: part of t_kernel_s spent finishing the cells that blocks of the production     */
-    uint64_t left_cells;   /*   launch handed over when <= HZ_LEFT_MIN of their 64 cells were unfinished (hz_horizon.hip)        */
+    double t_left_s;       /* leftover launches: part of t_kernel_s spent finishing the cells that blocks of the production   */
+    uint64_t left_cells;   /*   launch handed over when <= opts.left_min of their 64 cells were unfinished (hz_horizon.hip)   */
+    uint64_t left_again;   /* hand-overs by the leftover launches themselves (levels >= 1)                                    */
+    uint64_t scratch_bytes;/* HBM scratch this call used besides the scene and the caller's buffers: near-field certificates, */
+                           /*   leftover records, the horizon chunk buffers of a host / skipped hori_buffer                   */
 } hz_stats;
 
 const char *hz_last_error(void);
 /* sizeof(hz_opts), sizeof(hz_stats) as compiled: lets a binding verify its mirror */
 int hz_abi_struct_sizes(int *opts_bytes, int *stats_bytes);
-/* ABI revision.  5 (round 5): hz_stats.t_left_s, left_cells appended.  4 (round 4): hz_stats.near_verified appended; opts.verify_near is a sampling period (1 = every ray, as   */
+/* ABI revision.  6 (round 6): opts.left_min, persist_grid and hz_stats.left_again, scratch_bytes appended.  5 (round 5): hz_stats.t_left_s, left_cells appended.  4 (round 4): hz_stats.near_verified appended; opts.verify_near is a sampling period (1 = every ray, as   */
 /* before).  3 (round 3): {row_begin > 0, row_end = 0} is rejected (was "to the end": use row_end = -1); opts.regroup <= 0 */
 /* means the default threshold (was: 0 = ray compaction off; 64 | bias << 8 still disables the early exit in effect)     */
 int hz_abi_version(void);

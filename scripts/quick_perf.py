@@ -26,6 +26,8 @@ ap.add_argument("--hit-cache", type=int, default=1)
 ap.add_argument("--stack", type=int, default=0)
 ap.add_argument("--no-near", action="store_true", help="switch the near-field certificates off")
 ap.add_argument("--verify-near", action="store_true")
+ap.add_argument("--left", type=lambda x: int(x, 0), default=0, help="hz_opts.left_min: byte l = hand-over threshold of level l (0: default, -1: off)")
+ap.add_argument("--pgrid", type=int, default=0, help="hz_opts.persist_grid")
 ap.add_argument("--verify-sample", type=int, default=0, help="production kernel with the sampled certificate check: one of every N shortened rays")
 args = ap.parse_args()
 
@@ -42,13 +44,13 @@ for rep in range(args.reps):
     t = time.time()
     hori, azim = hz.horizon.horizon_gridded(g["vert_grid"], n, n, vec_norm, vec_north, off, off,
                                             args.dist, azim_num=args.azim, ray_algorithm=args.alg,
-                                            scene=sc, _top_nodes=args.top, _regroup=args.regroup, _hit_cache=args.hit_cache, _near_skip=not args.no_near, _level_stack=(-args.stack if args.stack > 0 else False), _verify_near=(args.verify_sample if args.verify_sample else args.verify_near), count_work=args.count_all or (args.count and rep == args.reps - 1))
+                                            scene=sc, _top_nodes=args.top, _regroup=args.regroup, _hit_cache=args.hit_cache, _near_skip=not args.no_near, _level_stack=(-args.stack if args.stack > 0 else False), _verify_near=(args.verify_sample if args.verify_sample else args.verify_near), _left_min=args.left, _persist_grid=args.pgrid, count_work=args.count_all or (args.count and rep == args.reps - 1))
     st = hz.horizon.last_stats
     print("rep %d wall %.2fs kernel %.3fs rays %d rays/(cell*az) %.2f Mray/s %.1f cells/s %.0f nodes/ray %.1f tris/ray %.1f"
           % (rep, time.time() - t, st["t_kernel_s"], st["num_rays"], st["num_rays"] / (w * w * args.azim),
              st["num_rays"] / st["t_kernel_s"] / 1e6, w * w / st["t_kernel_s"],
              st["nodes_visited"] / max(st["num_rays"], 1), st["tris_tested"] / max(st["num_rays"], 1)), flush=True)
-    print("      stack redo blocks %d  fallbacks %d" % (st.get("stack_redo_blocks", -1), st.get("stack_fallbacks", -1)), flush=True)
+    print("      stack redo blocks %d  fallbacks %d  left %.4fs cells %d again %d scratch %.0f MB" % (st.get("stack_redo_blocks", -1), st.get("stack_fallbacks", -1), st.get("t_left_s", 0.0), st.get("left_cells", 0), st.get("left_again", 0), st.get("scratch_bytes", 0) / 1e6), flush=True)
     print("      near pre-pass %.4fs  rays shortened %.3f  violations %d  re-traced %d" % (st["t_near_s"], st["rays_shortened"] / max(st["num_rays"], 1), st["near_violations"], st["near_verified"]), flush=True)
 if args.count or args.count_all:
     print("SIMT efficiency: node step %.3f  leaf step %.3f  refill %.3f   (wave iters: node %.3g leaf %.3g refill %.3g)"

@@ -36,4 +36,9 @@ def hip():
     _lib.lib()
     if _lib.device_count() < 1:
         pytest.fail("no HIP device visible: -m gpu tests need an MI355X")
+    # HZ_TEST_SCHEDULE="persist_grid=5,left_min=0x1818": run the whole session under another launch schedule (results never depend
+    # on it: horayzon_amd.horizon.schedule_overrides) -- how the long fuzz sweeps exercise the block loop and the hand-over levels
+    for item in filter(None, os.environ.get("HZ_TEST_SCHEDULE", "").split(",")):
+        k, v = item.split("=")
+        horayzon_amd.horizon.schedule_overrides[k.strip()] = int(v, 0)
     return horayzon_amd

@@ -31,7 +31,7 @@ def test_abi_revision_and_struct_mirrors():
     the ctypes mirrors have the compiled sizes, and the Cython declaration in INTEGRATION.md lists every hz_opts field."""
     import ctypes as C
     L = _lib.lib()
-    assert L.hz_abi_version() == 5
+    assert L.hz_abi_version() == 6
     a, b = C.c_int(0), C.c_int(0)
     assert L.hz_abi_struct_sizes(C.byref(a), C.byref(b)) == 0
     assert a.value == C.sizeof(_lib.hz_opts) and b.value == C.sizeof(_lib.hz_stats)

@@ -48,10 +48,25 @@ def test_plain_bench_gpus_2_starts_two_ranks_and_shards_the_tile(tmp_path):
     """`python bench.py --gpus 2` (no torchrun) must itself start 2 ranks, run the STRONG-scaling row
     shard of the headline tile through dist.sharded_rows and gather the same SVF a single rank computes."""
     np = pytest.importorskip("numpy")
-    p, dump2 = _plain(tmp_path, "two", gpus=2)
+    dump_c5 = str(tmp_path / "c5_two.npy")
+    p, dump2 = _plain(tmp_path, "two", "--c5-tile", "801", "--dump-c5-path", dump_c5, gpus=2)
     assert p.returncode == 0, p.stderr[-3000:]
     d = json.loads(p.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["steps"] == 2 and d["value"] > 0
+    # VERDICT r5 item 3: the N > 1 line also carries BASELINE config 5 run over the same ranks (extras.c5); `value` stays the c3 shard
+    e5 = d["extras"]["c5"]
+    assert e5["n_gpus"] == 2 and e5["cells_per_s"] > 0 and e5["scene_bcast_s"] > 0 and e5["job_s_incl_bcast"] >= e5["job_s"] > 0
+    assert len(e5["slabs"]) == 2 and e5["slabs"][0][0] == 0 and e5["slabs"][0][1] == e5["slabs"][1][0] and e5["slabs"][1][1] == 769
+    assert e5["load_imbalance_max_over_mean"] >= 1.0 and 1.0 <= e5["load_imbalance_predicted"] < 1.01 and e5["gathered_svf_finite"] is True
+    assert "14401" not in e5["workload"] and "801x801" in e5["workload"]
+    # ... whose gathered SVF is the SVF one rank computes for that mosaic
+    env5 = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29628")
+    dump_c5_one = str(tmp_path / "c5_one.npy")
+    q5 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "c5", "--tile", "801", "--azim", "72",
+                         "--dump-svf-rows", "all", "--dump-path", dump_c5_one], cwd=ROOT, env=env5, capture_output=True, text=True, timeout=600)
+    assert q5.returncode == 0, q5.stderr[-3000:]
+    a5, b5 = np.load(dump_c5), np.load(dump_c5_one)
+    assert a5.shape == (769, 769) and np.isfinite(a5).all() and np.array_equal(a5, b5)
     c = d["config"]
     sl = c["slabs"]
     assert len(sl) == 2 and sl[0][0] == 0 and sl[0][1] == sl[1][0] and sl[1][1] == 569 and 0 < sl[0][1] < 569   # disjoint, covering

@@ -728,46 +728,65 @@ def test_near_field_certificates_with_an_outer_tin_are_per_cell(hip, orc):
     assert np.array_equal(h, h_cpu)
 
 
-@pytest.mark.parametrize("grid", ("1", "3"))
-def test_persistent_waves_on_small_grids(grid):
+def _schedule_cases(hip, orc):
+    """The parity cases that the schedule tests below run again under other launch schedules."""
+    for alg in ALGS:
+        test_c2_gaussian_hill(hip, orc, alg)
+        test_rough_tilted_frames(hip, orc, alg)
+    test_c2_guard_events(hip, orc)
+    test_mask_and_fill(hip, orc)
+    test_outer_tin(hip, orc)
+    test_row_slab(hip, orc)
+    test_odd_parameters(hip, orc)
+    test_traversal_stack_is_one_entry_per_level(hip, orc)
+    for case in ("rough", "tilted_large_coords", "steep_fine", "masked_coarse"):
+        test_near_field_certificates_are_transparent(hip, orc, case)
+    test_streamed_host_output(hip, 7)
+
+
+@pytest.fixture
+def schedule(hip):
+    """Sets hip.horizon.schedule_overrides (defaults of hz_opts.left_min / persist_grid / left_cap_test) for one test."""
+    def set_(**kw):
+        hip.horizon.schedule_overrides.clear()
+        hip.horizon.schedule_overrides.update(kw)
+    yield set_
+    hip.horizon.schedule_overrides.clear()
+
+
+@pytest.mark.parametrize("grid", (1, 3))
+def test_persistent_waves_on_small_grids(hip, orc, schedule, grid):
     """Round 5: a full launch of k_horizon has as many workgroups as are resident at once and every wave pulls 8 x 8 blocks from
     the queue of its XCD, then from the other XCDs' queues (hz_horizon.hip).  Small grids have fewer tiles than that and run one
-    tile per workgroup; HZ_PERSIST_GRID forces 1 / 3 workgroups, so that the parity tests against the oracle run the block loop
-    with many passes per wave (the variable is read once per process, hence the subprocess)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HZ_PERSIST_GRID=grid)
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider",
-                        os.path.join(root, "tests", "test_gpu_parity.py"), "-k",
-                        "c2_gaussian_hill or rough_tilted or mask_and_fill or outer_tin or row_slab or odd_parameters or "
-                        "traversal_stack or near_field_certificates or streamed_host_output"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=1200)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
+    tile per workgroup; opts.persist_grid forces 1 / 3 workgroups, so that the parity tests against the oracle run the block loop
+    with many passes per wave -- and the wave-private groups of leftover records, filled over several blocks."""
+    schedule(persist_grid=grid)
+    _schedule_cases(hip, orc)
 
 
-def test_blocks_that_run_to_their_end_without_the_hand_over():
-    """Round 5: a block of a production launch ends when at most HZ_LEFT_MIN (16) of its cells are unfinished and a second launch
-    finishes the cells it handed over (hz_horizon.hip: leftover cells) -- every other test of this file runs that way.  With
-    HZ_LEFT_MIN=0 the blocks run to their end as before: the same parity tests against the oracle (the variable is read once per
-    process, hence the subprocess)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HZ_LEFT_MIN="0")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider",
-                        os.path.join(root, "tests", "test_gpu_parity.py"), "-k",
-                        "c2_gaussian_hill or rough_tilted or mask_and_fill or row_slab or near_field_certificates"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
+@pytest.mark.parametrize("sched", (
+    dict(left_min=-1),                                   # no hand-over: every block runs to its end
+    dict(left_min=-1, persist_grid=-1),                  # ... and one tile per workgroup (the round-4 schedule)
+    dict(left_min=0x10, persist_grid=-1),                # one level, exact allocations (no groups) from non-persistent workgroups
+    dict(left_min=0x20, persist_grid=2),                 # one level at 32: half of every block is handed over
+    dict(left_min=0x38, persist_grid=-1),                # one level at the cap of 56
+    dict(left_min=0x203038, persist_grid=3),             # three levels, large thresholds
+    dict(left_min=0x03030303, persist_grid=2),           # four levels, tiny thresholds
+    dict(left_min=0x1f1f1f, persist_grid=5),             # three levels at 31
+    dict(left_min=0x101010, persist_grid=2, left_cap_test=64),      # regions of ONE group: every level runs out of room
+    dict(left_min=0x0810, persist_grid=3, left_cap_test=192),
+))
+def test_leftover_schedules(hip, orc, schedule, sched):
+    """Rounds 5 - 6: a block ends when at most t[0] of its cells are unfinished and follow-up launches finish the cells handed
+    over, handing over again at t[l] (hz_horizon.hip: leftover cells) -- every other test of this file runs the default schedule
+    (16 / 16 / 16).  The same parity cases under other thresholds, level counts, without persistent waves, without the hand-over,
+    and with record regions so small that the out-of-room path runs."""
+    schedule(**sched)
+    _schedule_cases(hip, orc)
 
 
 def test_leftover_cells_are_reported(hip):
-    """hz_stats.left_cells / t_left_s (ABI 5): a grid with full 8 x 8 blocks hands cells over and says so; the counting
+    """hz_stats.left_cells / t_left_s / left_again / scratch_bytes (ABI 5, 6): a grid with full 8 x 8 blocks hands cells over and says so; the counting
     instantiation never does."""
     import horayzon_amd as hz
     from horayzon_amd import synth
@@ -778,6 +797,11 @@ def test_leftover_cells_are_reported(hip):
     h1, _ = hz.horizon.horizon_gridded(**kw, dist_search=10.0, azim_num=36, count_work=True)
     sc = dict(hz.horizon.last_stats)
     assert np.array_equal(h0, h1) and st["num_rays"] == sc["num_rays"]
-    if os.environ.get("HZ_LEFT_MIN", "16") != "0":
-        assert 0 < st["left_cells"] <= st["num_cells"] and st["t_left_s"] > 0.0
-    assert sc["left_cells"] == 0
+    assert 0 < st["left_cells"] <= st["num_cells"] and st["t_left_s"] > 0.0 and st["scratch_bytes"] > 0
+    assert sc["left_cells"] == 0 and sc["left_again"] == 0
+    h2, _ = hz.horizon.horizon_gridded(**kw, dist_search=10.0, azim_num=36, _left_min=-1)
+    s2 = dict(hz.horizon.last_stats)
+    assert np.array_equal(h0, h2) and s2["num_rays"] == st["num_rays"] and s2["left_cells"] == 0 and s2["t_left_s"] == 0.0
+    h3, _ = hz.horizon.horizon_gridded(**kw, dist_search=10.0, azim_num=36, _left_min=0x0c0c0c, _persist_grid=2)
+    s3 = dict(hz.horizon.last_stats)
+    assert np.array_equal(h0, h3) and s3["num_rays"] == st["num_rays"] and s3["left_cells"] > 0 and s3["left_again"] > 0
