@@ -55,7 +55,8 @@ sys.path.insert(0, ROOT)
 
 NODE_BYTES = 32.0       # one 4-wide LBVH node (hz_common.h: Node; 64 B until round 3, 48 B early in round 4): the bytes a node visit reads
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 achievable
-KERNEL_SOURCES = ("hz_common.h", "hz_search.h", "hz_horizon.hip")   # what the traffic figure was measured for
+# The counter files under profiles/ (traffic.json, valu_model.json, valu_class_mix.json) describe MACHINE CODE: they carry the hash of
+# the normalised gfx950 assembly of the traversal kernels (scripts/kernel_asm.py), which the build leaves in horayzon_amd/kernel_asm.sha.
 
 # wave-level VALU instructions per wave iteration of k_horizon<guess_constant> (calibrated against
 # SQ_INSTS_VALU of the PMC pass, profiles/<round>/valu_model.json)
@@ -106,12 +107,22 @@ def parse():
     return ap.parse_args()
 
 
-def kernel_source_sha():
-    h = hashlib.sha256()
-    for name in KERNEL_SOURCES:
-        with open(os.path.join(ROOT, "horayzon_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
-    return h.hexdigest()[:16]
+def kernel_asm_sha():
+    """Hash of the traversal kernels' device assembly as built (horayzon_amd/kernel_asm.sha, written by the Makefile next to the
+    library); computed with hipcc when that file is missing; "unknown" without either."""
+    try:
+        with open(os.path.join(ROOT, "horayzon_amd", "kernel_asm.sha")) as f:
+            v = f.read().strip()
+        if len(v) == 64:
+            return v
+    except OSError:
+        pass
+    try:
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import kernel_asm
+        return kernel_asm.sha(ROOT)
+    except Exception:
+        return "unknown"
 
 
 def load_valu_model():
@@ -119,23 +130,23 @@ def load_valu_model():
     profiles/valu_class_mix.json when they were measured for the present kernel sources, else the built-in constants."""
     model, mix = dict(VALU_MODEL_DEFAULT), dict(CLASS_MIX_DEFAULT)
     notes = {"valu_model": "built-in constants", "class_mix_note": "built-in class mix"}
-    sha = kernel_source_sha()
+    sha = kernel_asm_sha()
     try:
         mj = json.load(open(os.path.join(ROOT, "profiles", "valu_model.json")))
-        if mj.get("kernel_source_sha") == sha:
+        if mj.get("kernel_asm_sha") == sha:
             model.update({k: mj[k] for k in model if k in mj})
             if "shadow_setup_winst_per_64_cells" in mj:
                 model["shadow_setup"] = mj["shadow_setup_winst_per_64_cells"]
-            notes["valu_model"] = "profiles/valu_model.json (calibrated on SQ_INSTS_VALU, same kernel sources)"
+            notes["valu_model"] = "profiles/valu_model.json (calibrated on SQ_INSTS_VALU of this machine code)"
         else:
-            notes["valu_model"] = "built-in constants (profiles/valu_model.json was measured for other kernel sources)"
+            notes["valu_model"] = "built-in constants (profiles/valu_model.json was measured for other machine code)"
     except Exception:
         pass
     try:
         cj = json.load(open(os.path.join(ROOT, "profiles", "valu_class_mix.json")))
-        if cj.get("kernel_source_sha") == sha:
+        if cj.get("kernel_asm_sha") == sha:
             mix = {k: cj[k]["fast_fraction"] for k in mix if k in cj}
-            notes["class_mix_note"] = "profiles/valu_class_mix.json (scripts/isa_class_mix.py, same kernel sources)"
+            notes["class_mix_note"] = "profiles/valu_class_mix.json (scripts/isa_class_mix.py, this machine code)"
     except Exception:
         pass
     return model, mix, notes
@@ -458,6 +469,10 @@ def run_c3(ctx):
                                    "scene broadcast once" % world),
                    "bvh_build_s": scene_stats["t_bvh_s"] if scene_stats else None,
                    "scene_bytes": int(blob_bytes), "scene_bcast_s": t_bcast, "scene_create_wall_s": t_build,
+                   # HBM scratch of a step besides the scene and the resident inputs / outputs: near-field certificates ((2 A + 4) B per cell
+                   # of the launch), records of the handed-over cells + their sort buffers (hz_stats.scratch_bytes)
+                   "scratch_bytes": int(stats.scratch_bytes), "leftover_cells_per_step": stats.left_cells / max(steps, 1),
+                   "leftover_groups_repeated": int(stats.left_redo_groups),
                    "load_imbalance_max_over_mean": imbalance, "near_prepass_ms_per_step": 1e3 * stats.t_near_s / max(steps, 1),
                    # the reference's searches do not terminate where these fire (horizon_comp.cpp:474-488, README.md:209-213):
                    # rim cells whose rays leave the DEM below the lowest table angle; this library stops them and counts
@@ -736,15 +751,16 @@ def roofline(args, stats, steps, cw, peaks, A, n, rps):
     cells_launch = stats.num_cells / max(steps, 1)
     b_io = (12 + 12 + 12 + 1 + 12 + 4) * cells_launch + 4.0 * A * cells_launch
     left_s = getattr(stats, "t_left_s", 0.0) / max(steps, 1)
-    r = {"kernel": "hz::k_horizon<2,false,true,false,false,false> (guess_constant, staged output, fast stack discipline, persistent waves) + its leftover "
-                   "launch hz::k_horizon<2,false,true,false,true,true> (the cells that blocks handed over when <= 16 of their 64 were unfinished)",
+    r = {"kernel": "hz::k_horizon<2,false,true,false,false,false> (guess_constant, staged output, fast stack discipline, persistent waves) + its follow-up "
+                   "launch hz::k_horizon<2,false,true,false,false,true> (the cells that blocks handed over when <= 36 of their 64 were unfinished, "
+                   "sorted by azimuths left and position: k_left_keys + radix sort, included in kernel_ms_leftover_launch)",
          "kernel_ms_per_launch": 1e3 * k_launch_s,
          "kernel_ms_production_launch": 1e3 * (k_launch_s - left_s), "kernel_ms_leftover_launch": 1e3 * left_s,
          "leftover_cells_per_launch": getattr(stats, "left_cells", 0) / max(steps, 1),
          "mray_per_s_kernel": rays_launch / k_launch_s / 1e6 if k_launch_s else None,
          "svf_kernel_ms_per_launch": 1e3 * stats.t_svf_s / max(steps, 1)}
     model, mix0, mnotes = load_valu_model()
-    sha = kernel_source_sha()
+    sha = kernel_asm_sha()
     r["valu_model"] = mnotes["valu_model"]
     b_trav = 0.0
     if cw is not None and cw.num_rays:
@@ -796,8 +812,8 @@ def roofline(args, stats, steps, cw, peaks, A, n, rps):
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("kernel_source_sha") != sha:
-                tnote = "profiles/traffic.json was measured for other kernel sources (stale): not reported"
+            if tj.get("kernel_asm_sha") != sha:
+                tnote = "profiles/traffic.json was measured for other machine code (stale): not reported"
             elif tj.get("rows_per_step") == rps and tj.get("tile") == n and tj.get("azim") == A:
                 traffic, tnote = tj.get("hbm_bytes_per_launch"), "rocprofv3 PMC passes of this kernel (profiles/traffic.json)"
         except Exception:

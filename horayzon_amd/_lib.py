@@ -46,7 +46,7 @@ class hz_stats(C.Structure):
                 ("stack_redo_blocks", C.c_uint64), ("guard_cells", C.c_uint64),
                 ("height_field", C.c_int32), ("near_used", C.c_int32), ("near_verified", C.c_uint64),
                 ("t_left_s", C.c_double), ("left_cells", C.c_uint64),
-                ("left_again", C.c_uint64), ("scratch_bytes", C.c_uint64)]
+                ("left_again", C.c_uint64), ("scratch_bytes", C.c_uint64), ("left_redo_groups", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -62,7 +62,7 @@ SYMBOLS = (
     "hz_slope_plane_meth", "hz_slope_vector_meth", "hz_lonlat2ecef", "hz_ecef2enu", "hz_wgs2swiss", "hz_swiss2wgs",
     "hz_ecef2enu_vector", "hz_surf_norm", "hz_north_dir", "hz_vert_grid_len", "hz_pack_vertices",
     "hz_debug_sort_pairs", "hz_debug_exclusive_scan",
-    "hz_debug_valu_peak", "hz_debug_copy_peak", "hz_debug_inst_rate",
+    "hz_debug_valu_peak", "hz_debug_copy_peak", "hz_debug_inst_rate", "hz_debug_set",
     "hz_terrain_create", "hz_terrain_initialise", "hz_terrain_initialise_scene",
     "hz_terrain_shadow", "hz_terrain_sw_dir_cor", "hz_terrain_shadow_batch",
     "hz_terrain_sw_dir_cor_batch", "hz_terrain_count_work", "hz_terrain_destroy",
@@ -147,6 +147,7 @@ def lib():
     L.hz_debug_valu_peak.argtypes = [ip, ip, ip, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_int)]
     L.hz_debug_copy_peak.argtypes = [ip, C.c_size_t, C.POINTER(C.c_double)]
     L.hz_debug_inst_rate.argtypes = [ip, ip, C.POINTER(C.c_double)]
+    L.hz_debug_set.argtypes = [C.c_char_p, ip]
     L.hz_terrain_create.argtypes = [ip, C.POINTER(vp)]
     L.hz_terrain_initialise.argtypes = [vp, vp, ip, ip, ip, ip, vp, vp, ip, ip, vp, vp, vp,
                                         C.c_char_p, C.c_float, C.c_float, ip, C.POINTER(hz_stats)]

@@ -531,7 +531,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     DevIn<unsigned long long> d_cnt;
     unsigned long long zeros[HZ_CNT_N] = {0};      // counters; behind them the list of tiles to redo (hz_horizon.hip)
     void *cnt_dev = nullptr;
-    HZ_HIP(hipMalloc(&cnt_dev, sizeof(zeros) + HZ_REDO_CAP * sizeof(int)));
+    HZ_HIP(hipMalloc(&cnt_dev, sizeof(zeros) + 2 * HZ_REDO_CAP * sizeof(int)));      // (two lists: blocks, and groups of the leftover launch)
     d_cnt.owned = cnt_dev;
     HZ_HIP(hipStreamSynchronize(st));
     const double h2d_s = t_h2d.stop();
@@ -573,7 +573,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     NearMonitor mon;
     float ms = 0.0f, ms_svf = 0.0f;
     int fallbacks = 0;
-    unsigned long long redo_blocks = 0;
+    unsigned long long redo_blocks = 0, redo_groups = 0;
 
     // HIP events on the kernels' stream: horizon kernel and SVF kernel are timed separately
     struct Ev { hipEvent_t a = nullptr, b = nullptr, c = nullptr, d = nullptr, l = nullptr; };
@@ -649,10 +649,10 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     a.left_rec = n_left_launches > 0 ? (unsigned *)sc->left_buf : nullptr;
     a.persist_grid = (opts && opts->persist_grid > 0) ? opts->persist_grid : 0;
     a.no_persist = (opts && opts->persist_grid < 0) ? 1 : 0;
-    // HZ_NEAR_REASONS=1: histogram of why cells got no certificate, printed to stderr at the end of the call
+    // opts.verbose >= 2: histogram of why cells got no certificate, printed to stderr at the end of the call
     unsigned *near_reasons = nullptr;
     struct ReasonsFree { unsigned **p; ~ReasonsFree() { if (*p) (void)hipFree(*p); } } reasons_free{&near_reasons};
-    if (use_near && getenv("HZ_NEAR_REASONS")) {
+    if (use_near && opts && opts->verbose >= 2) {
         if (hipMalloc((void **)&near_reasons, 20 * sizeof(unsigned)) != hipSuccess) { (void)hipGetLastError(); near_reasons = nullptr; }
         else (void)hipMemsetAsync(near_reasons, 0, 20 * sizeof(unsigned), st);
     }
@@ -765,7 +765,10 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
                     if ((r = left_sort(a, l - 1, st))) break;
                     HorizonArgs b = a;
                     b.left_mode = l; b.left_min = l < n_left_launches ? left_t[l] : 0;
-                    b.level_stack = 1; b.tile_list = nullptr; b.n_list = 0;      // (one entry per level: nothing can overflow there)
+                    // a single follow-up launch runs the stack discipline of the production launch (a group whose fast stack overflows is
+                    // computed again, below); with several levels they run one entry per level: nothing can overflow there
+                    if (n_left_launches > 1) b.level_stack = 1;
+                    b.tile_list = nullptr; b.n_list = 0;
                     r = horizon_launch(sc, b, st, nullptr);
                 }
                 return r;
@@ -776,20 +779,30 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
                 // fast stack discipline: did a wave run out of entries?  Its 8 x 8 block does not count (and handed nothing over) and is
                 // computed again with the one-entry-per-level kernel: block by block when they are few (deep trees overflow in a
                 // few places only), the whole launch -- and every later launch on this scene -- when they are many
-                unsigned long long ov = 0;
-                if (hipMemcpyAsync(&ov, (unsigned long long *)cnt_dev + 8, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+                unsigned long long cov[32] = {0};
+                if (hipMemcpyAsync(cov, cnt_dev, sizeof(cov), hipMemcpyDeviceToHost, st) != hipSuccess ||
                     hipStreamSynchronize(st) != hipSuccess)
                     return fail(set_error(HZ_ERR_HIP, "horizon kernel failed: %s", hipGetErrorString(hipGetLastError())));
-                if (ov != 0) {
+                const unsigned long long ov = cov[8], lov = cov[30];      // blocks / groups of the leftover launch that ran out of entries
+                if (ov != 0 || lov != 0) {
                     const unsigned long long tiles = (unsigned long long)((re - rb + 7) / 8) * (unsigned long long)((dim_in_1 + 7) / 8);   // 8 x 8 blocks
                     fallbacks++;
                     a.level_stack = 1;
-                    if (ov <= HZ_REDO_CAP && ov * 4 <= tiles) {
-                        a.tile_list = reinterpret_cast<const int *>((unsigned long long *)cnt_dev + HZ_CNT_N);
-                        a.n_list = (int)ov;
-                        redo_blocks += ov;
-                        rc = horizon_launch(sc, a, st, &safe);
-                        a.tile_list = nullptr; a.n_list = 0;
+                    if (ov <= HZ_REDO_CAP && lov <= HZ_REDO_CAP && (ov + lov) * 4 <= tiles) {
+                        redo_blocks += ov + lov; redo_groups += lov;
+                        if (ov != 0) {
+                            a.tile_list = reinterpret_cast<const int *>((unsigned long long *)cnt_dev + HZ_CNT_N);
+                            a.n_list = (int)ov;
+                            rc = horizon_launch(sc, a, st, &safe);
+                            a.tile_list = nullptr; a.n_list = 0;
+                        }
+                        if (!rc && lov != 0) {
+                            HorizonArgs b = a;
+                            b.left_mode = 1; b.left_min = 0;
+                            b.tile_list = reinterpret_cast<const int *>((unsigned long long *)cnt_dev + HZ_CNT_N) + HZ_REDO_CAP;
+                            b.n_list = (int)lov;
+                            rc = horizon_launch(sc, b, st, nullptr);
+                        }
                     } else {
                         sc->level_stack.store(1, std::memory_order_relaxed);
                         if (hipMemcpyAsync(cnt_dev, zeros, sizeof(zeros), hipMemcpyHostToDevice, st) != hipSuccess)
@@ -819,11 +832,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             for (int k = 0; k < 16; k++) cnt[k] += c[k];
             left_cells += c[28]; left_again += c[29];
             n_verified += c[21];
-#ifdef HZ_PROBE_Q1
-            if (a.count_work) fprintf(stderr, "hz probe q1: leaf-step lanes with a second queued leaf %llu, node-step lanes blocked by a full queue %llu, node-step lanes with a decided ray %llu (lane-leaf-steps %llu = tris / 2, wave node iters %llu, wave leaf iters %llu)\n",
-                                      c[22], c[23], c[21], c[3] / 2, c[5], c[6]);
-#endif
-            if (a.count_work && getenv("HZ_XCD_TRACE")) {      // per-XCD span of this launch (counting instantiation)
+            if (a.count_work && opts && opts->verbose >= 3) {      // per-XCD span of this launch (counting instantiation)
                 const unsigned long long t0 = ~c[20];
                 fprintf(stderr, "hz xcd spans [ms] rows %d..%d:", rb, re);
                 for (int x = 0; x < 8; x++) fprintf(stderr, " %.1f", c[12 + x] ? (double)(c[12 + x] - t0) * 1.0e-5 : 0.0);
@@ -854,7 +863,7 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         stats->t_d2h_s += d2h_s;
         stats->t_total_s += t_total.stop();
         stats->elev_num = tb.elev_num; stats->bvh_height = sc->hdr.height; stats->scene_bytes = sc->hdr.total_bytes;
-        stats->stack_fallbacks += (uint64_t)fallbacks; stats->stack_redo_blocks += redo_blocks;
+        stats->stack_fallbacks += (uint64_t)fallbacks; stats->stack_redo_blocks += redo_blocks; stats->left_redo_groups += redo_groups;
         stats->rays_shortened += cnt[9]; stats->near_violations += cnt[10] + n_mon_violations; stats->t_near_s += (double)ms_near * 1e-3;
         stats->guard_cells += cnt[11]; stats->near_verified += n_verified;
         stats->t_left_s += (double)ms_left * 1e-3; stats->left_cells += left_cells; stats->left_again += left_again;
@@ -1265,6 +1274,14 @@ int hz_debug_valu_peak(int device, int packed, int waves_per_simd, double *winst
     int rc = select_device(device);
     if (rc) return rc;
     return bench_valu_peak(packed, waves_per_simd, winst_per_s_per_simd, clock_ghz, simds);
+}
+
+int hz_debug_set(const char *key, int value) {
+    if (!key) return hz::set_error(HZ_ERR_ARG, "hz_debug_set: null key");
+    if (!strcmp(key, "shadow_fast_cap")) hz::g_shadow_fast_cap.store(value < 0 ? HZ_SHADOW_FAST_CAP_DEFAULT : value, std::memory_order_relaxed);
+    else if (!strcmp(key, "topo_wide")) hz::g_topo_wide.store(value != 0, std::memory_order_relaxed);
+    else return hz::set_error(HZ_ERR_ARG, "hz_debug_set: unknown key '%s'", key);
+    return HZ_OK;
 }
 
 int hz_debug_inst_rate(int device, int op, double *cycles_per_inst) {

@@ -385,35 +385,20 @@ __device__ __forceinline__ void hz_node_hits(const NodeRay &n, const RayBox &r, 
     const float nx1 = hz_fma_mix_lo(px1, n.ax, n.bx), fx1 = hz_fma_mix_hi(px1, n.ax, n.bx);
     const float ny0 = hz_fma_mix_lo(py0, n.ay, n.by), fy0 = hz_fma_mix_hi(py0, n.ay, n.by);
     const float ny1 = hz_fma_mix_lo(py1, n.ay, n.by), fy1 = hz_fma_mix_hi(py1, n.ay, n.by);
-#ifdef HZ_PROBE_NO_SLACK      // measurement probe: how much does the relative slack cost?
-#define HZ_SLACK(x) (x)
-#else
-#define HZ_SLACK(x) ((x) * 1.000001f)
-#endif
     // the ray's own interval [0, tfar] is folded into the two x terms, which every child shares with one other child:
     // 2 + 2 instead of 4 + 4 clamps, and one max3 / min3 per child
-#ifdef HZ_V_NO_XCLAMP
-    const float cx0 = nx0, cx1 = nx1, gx0 = fx0, gx1 = fx1;
-#define HZ_CHILD(pz, nx, fx, ny, fy, out) do { \
-        const float nz_ = hz_fma_mix_lo(pz, n.az, n.bz), fz_ = hz_fma_mix_hi(pz, n.az, n.bz); \
-        const float tmin_ = __builtin_fmaxf(__builtin_fmaxf(nx, ny), __builtin_fmaxf(nz_, 0.0f)); \
-        const float tmax_ = __builtin_fminf(__builtin_fminf(fx, fy), __builtin_fminf(fz_, tfar)); \
-        out = tmin_ <= HZ_SLACK(tmax_); } while (0)
-#else
     const float cx0 = __builtin_fmaxf(nx0, 0.0f), cx1 = __builtin_fmaxf(nx1, 0.0f);
     const float gx0 = __builtin_fminf(fx0, tfar), gx1 = __builtin_fminf(fx1, tfar);
 #define HZ_CHILD(pz, nx, fx, ny, fy, out) do { \
         const float nz_ = hz_fma_mix_lo(pz, n.az, n.bz), fz_ = hz_fma_mix_hi(pz, n.az, n.bz); \
         const float tmin_ = __builtin_fmaxf(__builtin_fmaxf(nx, ny), nz_); \
         const float tmax_ = __builtin_fminf(__builtin_fminf(fx, fy), fz_); \
-        out = tmin_ <= HZ_SLACK(tmax_); } while (0)
-#endif
+        out = tmin_ <= tmax_ * 1.000001f; } while (0)
     HZ_CHILD(pz0, cx0, gx0, ny0, fy0, h0);      // slot k: column half k & 1, row half k >> 1
     HZ_CHILD(pz1, cx1, gx1, ny0, fy0, h1);
     HZ_CHILD(pz2, cx0, gx0, ny1, fy1, h2);
     HZ_CHILD(pz3, cx1, gx1, ny1, fy1, h3);
 #undef HZ_CHILD
-#undef HZ_SLACK
 }
 
 // The same test with the four results as lane MASKS (all ones: the child box is hit; zero: it is not) formed from the SIGN of
@@ -452,10 +437,6 @@ __device__ __forceinline__ void hz_node_hit_masks(const NodeRay &n, const RayBox
 // the first half of round 4 48 B ones (three): the vector-memory pipe is the kernel's co-limit -- every load instruction
 // per visit is worth ~4 % (+1 load: -3 %, round 3; 4 -> 3 loads: +4.2 %; a fire-and-forget prefetch load: -6 %).
 __device__ __forceinline__ void hz_load_node(const Node *n, float4 &n0, uint4 &n1) {
-#ifdef HZ_PROBE_PAD_VMEM   // sensitivity probe: one more (4 B, same cache line) vector-memory instruction per node visit
-    unsigned pad_;
-    asm volatile("global_load_dword %0, %1, off offset:4" : "=&v"(pad_) : "v"(n) : "memory");
-#endif
     asm volatile("global_load_dwordx4 %0, %2, off\n\t"
                  "global_load_dwordx4 %1, %2, off offset:16\n\t"
                  "s_waitcnt vmcnt(0)"
@@ -507,9 +488,6 @@ __device__ __forceinline__ void hz_load_prim(const Prim *q, float4 &q0, float4 &
 // returns 0 = miss, 1 = hit (t.lq0 is the blocking leaf), 2 = suspended (state is valid, call again)
 // ---------------------------------------------------------------------------
 struct TravCounters { unsigned nodes, tris, w_nodes, w_leaves;
-#ifdef HZ_PROBE_Q1     // measurement probe (counting instantiation): lanes with a SECOND queued leaf at a leaf step; lanes that sit out a
-    unsigned q1, blk, fin;   // node step with a full leaf queue and a leaf link in hand; lanes that sit out a node step with their ray decided
-#endif
 };
 struct TravState { int node, sp, pf, pm, lq0, lq1; };
 
@@ -536,50 +514,12 @@ __device__ __forceinline__ void hz_entry_unpack(int e, int &pf, int &pm) {
 //          host repeats that launch with the other discipline.
 //   true:  one entry per level as described above: `height` entries, no overflow case (+10 % VALU instructions on
 //          the 3601^2 tile).
-// Sensitivity probes (scripts/build_variant.sh <name> -DHZ_PROBE_PAD_SLOW=8 ...; results unchanged): n dead instructions of one
-// kind per node step -- what does the node step wait for?  slow / fast: the two VALU issue classes; LDS: ds_write to the
-// lane's own free stack entry; SALU: scalar moves.
-#if defined(HZ_PROBE_PAD_SLOW) || defined(HZ_PROBE_PAD_FAST) || defined(HZ_PROBE_PAD_LDS) || defined(HZ_PROBE_PAD_SALU)   // (HZ_PROBE_PAD_VMEM: see hz_load_node)
-#ifndef HZ_PROBE_PAD_SLOW
-#define HZ_PROBE_PAD_SLOW 0
-#endif
-#ifndef HZ_PROBE_PAD_FAST
-#define HZ_PROBE_PAD_FAST 0
-#endif
-#ifndef HZ_PROBE_PAD_LDS
-#define HZ_PROBE_PAD_LDS 0
-#endif
-#ifndef HZ_PROBE_PAD_SALU
-#define HZ_PROBE_PAD_SALU 0
-#endif
-#define HZ_PROBE_PADS(seed) do { \
-        float pad_a_ = (seed), pad_b_ = (seed); unsigned pad_s_; \
-        _Pragma("unroll") for (int q_ = 0; q_ < HZ_PROBE_PAD_SLOW; q_ += 2) { \
-            asm volatile("v_max_f32 %0, %0, %0" : "+v"(pad_a_)); asm volatile("v_max_f32 %0, %0, %0" : "+v"(pad_b_)); } \
-        _Pragma("unroll") for (int q_ = 0; q_ < HZ_PROBE_PAD_FAST; q_ += 2) { \
-            asm volatile("v_xor_b32 %0, 1, %0" : "+v"(pad_a_)); asm volatile("v_xor_b32 %0, 1, %0" : "+v"(pad_b_)); } \
-        _Pragma("unroll") for (int q_ = 0; q_ < HZ_PROBE_PAD_SALU; q_++) asm volatile("s_mov_b32 %0, 0" : "=s"(pad_s_)); \
-        if (!LEVELSTACK) { _Pragma("unroll") for (int q_ = 0; q_ < HZ_PROBE_PAD_LDS; q_++) \
-            asm volatile("ds_write_b32 %0, %1 offset:2048" : : "v"(sa), "v"(pad_a_) : "memory"); } \
-    } while (0)
-#else
-#define HZ_PROBE_PADS(seed) do { } while (0)
-#endif
-// POOL (round 5, fast stack discipline only): the leaf step POOLS the queued leaves of the wave over its lanes.  At a leaf step
-// 72 % of the lanes that test a leaf hold a second one in their queue while 60 % of the wave's lanes have none (probe build
-// -DHZ_PROBE_Q1, profiles/r05/): the items (lane, queued leaf) -- first every lane's lq0, then the lq1s -- are numbered through
-// the wave (v_mbcnt over the two ballots), lane k tests item k with the OWNER's ray, and the owners read their results out of
-// the ballot of the hits.  For that a lane's ray (origin, direction) lives in LDS (`pool`: 6 rows of TPB floats, written by the
-// caller at every refill, ray[k * TPB + tid]) instead of in registers -- ox .. dz are then ignored -- and the wave owns a
-// 64-entry item table behind the pool (item -> owner lane).  Hit decisions are per (ray, leaf) and the answer is "any leaf
-// hit": which lane evaluates a test, and that a lane's second leaf is tested although its first one hits, changes nothing.
-template <int TPB, bool COUNT, int QLEN = 2, bool NODELET = false, bool LEVELSTACK = true, bool POOL = false>
+template <int TPB, bool COUNT, int QLEN = 2, bool NODELET = false, bool LEVELSTACK = true>
 __device__ __forceinline__ int hz_trace(const Node *__restrict__ nodes, const Prim *__restrict__ prims,
                                         const float4 *top, int ntop, int *stack, int tid,
                                         float ox, float oy, float oz, float dx, float dy, float dz, float tfar,
                                         float tfar_box, const RayBox &rb, TravState &t, int regroup, int leaf_bias,
-                                        TravCounters &cnt, int stack_cap, bool &overflow, unsigned pool = 0u) {
-    static_assert(!POOL || !LEVELSTACK, "leaf pooling is written for the fast stack discipline");
+                                        TravCounters &cnt, int stack_cap, bool &overflow) {
     const int lane = tid & 63;
     int node = t.node, sp = t.sp, pf = t.pf, pm = t.pm, lq0 = t.lq0, lq1 = t.lq1;
     const int n_entry = __popcll(__ballot(1));   // lanes that entered with a ray
@@ -623,18 +563,6 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
     // ray is decided idles until then: a miss holds HZ_EMPTY and an empty queue; a hit holds HZ_EMPTY and the NUMBER of
     // the blocking leaf instead of its link in lq0 (non-negative: "no leaf queued"; never HZ_EMPTY).  No per-lane exit, no result register in the loop.
     const int n_leave = max(min(regroup, n_entry), 1);
-#ifdef HZ_PREFETCH
-    // Probe (scripts/build_variant.sh pf -DHZ_PREFETCH): touch the cache line of the link a node step has just chosen with
-    // a fire-and-forget 4 B load, so that the three 16 B loads of the next visit hit L1.  The destination register is
-    // carried through the loop (loads return in order; the wait in the next load block covers it) and waited for at the exit.
-    unsigned pf_sink = 0u;
-#define HZ_PF(link) do { if ((link) != HZ_EMPTY) { \
-        const char *pa_ = HZ_IS_NODE(link) ? reinterpret_cast<const char *>(nodes + (link)) \
-                                           : reinterpret_cast<const char *>(prims + HZ_LEAF_ID(link)); \
-        asm volatile("global_load_dword %0, %1, off" : "+v"(pf_sink) : "v"(pa_) : "memory"); } } while (0)
-#else
-#define HZ_PF(link) do { } while (0)
-#endif
     // The loop is rotated by hand: [queue fills + votes] once in front of it and again at the end of its body, so that the
     // wave's exit test is the loop condition itself.
     bool can_node, can_leaf;
@@ -649,31 +577,16 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
         } else {
             // top entry and the one below it (the row below the sentinel belongs to the caller's staging buffer or padding:
             // read with the sentinel, never used)
-#ifdef HZ_V_NO_READ2ASM
-            int t0 = HZ_STACK_AT(sa + (unsigned)(TPB * 4));
-            const int t1 = HZ_STACK_AT(sa);
-#else
             hz_int2 t10;
             // (second element = one stack row above: TPB * 4 bytes = TPB / 64 units of 64 dwords)
             asm volatile("ds_read2st64_b32 %0, %1 offset1:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(t10) : "v"(sa), "n"(TPB / 64) : "memory");
             int t0 = t10.y;
             const int t1 = t10.x;
-#endif
             // "node is a leaf link (negative) and the place is free (HZ_EMPTY: positive)" as ONE vector compare of
             // node & ~place: scalar logic on two compare results waits for both (round 4: a scalar instruction that
             // consumes a vector compare costs about 1 % of the kernel, profiles/r04/ab_scalar_mask_logic.log)
             // (round 5: the sign of node & ~place is smeared into a lane mask and the moves are bit selects -- v_ashrrev_i32 +
             //  v_bitop3_b32, fast-class instructions, instead of a compare and v_cndmask_b32s, slow-class ones)
-#ifdef HZ_V_CMP_NODE_STEP
-            int m1 = node & ~lq0;
-            asm volatile("" : "+v"(m1));
-            const bool c1 = m1 < 0;
-            lq0 = c1 ? node : lq0; node = c1 ? t0 : node; t0 = c1 ? t1 : t0; sa -= c1 ? (unsigned)(TPB * 4) : 0u;
-            int m2 = node & ~lq1;
-            asm volatile("" : "+v"(m2));
-            const bool c2 = m2 < 0;
-            lq1 = c2 ? node : lq1; node = c2 ? t0 : node; sa -= c2 ? (unsigned)(TPB * 4) : 0u;
-#else
 #define HZ_SELM(m, x, y) (((m) & (x)) | (~(m) & (y)))
             int m1 = (node & ~lq0) >> 31;
             asm volatile("" : "+v"(m1));          // (the compiler must not know that this is 0 / -1)
@@ -682,7 +595,6 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
             asm volatile("" : "+v"(m2));
             lq1 = HZ_SELM(m2, node, lq1); node = HZ_SELM(m2, t0, node); sa -= (unsigned)m2 & (unsigned)(TPB * 4);
 #undef HZ_SELM
-#endif
         }
         can_node = HZ_IS_NODE(node);
         can_leaf = lq0 < 0;
@@ -697,9 +609,6 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
         const int n_leaf = __popcll(m_leaf);
         if (n_node * 16 >= n_leaf * leaf_bias) {
             // ---------------- node step ------------------------------------------------------
-#ifdef HZ_PROBE_Q1
-            if (COUNT) { if (!can_node && node < 0) cnt.blk++; if (!can_node && !can_leaf && !(node < 0)) cnt.fin++; }
-#endif
             if (can_node) {
                 float4 n0; uint4 n1;
                 // NODELET: top-of-tree nodes from LDS, the rest from global memory (two separate asm paths:
@@ -715,7 +624,6 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
                 // nick a crest are served by the hit cache.  (Rounds 2-3 stored the tallest child first: +1 %; the
                 // quadrant order is what lets x and y share one range per half, i.e. the 32 B node.)
                 const int first = __float_as_int(n0.w);
-                HZ_PROBE_PADS(n0.x);
                 if (LEVELSTACK) {
                     bool h0, h1, h2, h3;
                     hz_node_hits(nr, rb, tfar_box, n1, h0, h1, h2, h3);
@@ -726,14 +634,8 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
                     }
                     HZ_POP();                        // ... and the first of them (or of a level above) is entered
                 } else {
-#ifdef HZ_V_CMP_NODE_STEP        // the round-4 form (compares + selects), kept for A/Bs
-                    bool h0, h1, h2, h3;
-                    hz_node_hits(nr, rb, tfar_box, n1, h0, h1, h2, h3);
-                    const int m0 = h0 ? -1 : 0, m1 = h1 ? -1 : 0, m2 = h2 ? -1 : 0, m3 = h3 ? -1 : 0;
-#else
                     int m0, m1, m2, m3;              // lane masks: all ones = child hit (hz_node_hit_masks)
                     hz_node_hit_masks(nr, rb, tfar_box, n1, m0, m1, m2, m3);
-#endif
                     // out of entries: remember the highest pointer (checked once, at the exit) and clamp
                     sa_hi = max(sa_hi, sa);
                     sa = min(sa, sa_cap);
@@ -754,64 +656,14 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
 #undef HZ_SEL
                     node = next; sa = sa + o3210 - S;
                 }
-                HZ_PF(node);
             }
         } else {
             // ---------------- leaf step: the two triangles of a DEM quad (or one TIN triangle) ---
-            if (POOL) {
-                // items: lq0 of every lane that has one (in lane order), then the lq1s, as far as the wave has lanes
-                const unsigned long long m1 = __ballot(lq1 < 0);
-                const bool full = __ballot(1) == ~0ull;         // (a wave with lanes masked off -- cells that are finished --
-                                                                //  cannot hand items to them: every lane tests its own lq0)
-                const int r0 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m_leaf >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m_leaf, 0u));
-                const int r1 = (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u));
-                const int slot0 = full ? r0 : lane;
-                const int slot1 = (full ? n_leaf : 64) + r1;
-                const unsigned tabw = pool + (unsigned)(6 * TPB * 4) + (unsigned)(tid & ~63) * 4u;
-                const bool two = (lq1 < 0) & (slot1 < 64);     // this lane's second leaf is an item of this step
-                int e = lane;
-                if (full) {
-                    if (can_leaf) HZ_STACK_AT(tabw + 4u * (unsigned)slot0) = lane;
-                    if (two) HZ_STACK_AT(tabw + 4u * (unsigned)slot1) = lane | 64;
-                    asm volatile("" ::: "memory");
-                    e = HZ_STACK_AT(tabw + 4u * (unsigned)lane);
-                }
-                const int n_items = min(n_leaf + __popcll(m1), 64);
-                const bool mine = full ? (lane < n_items) : can_leaf;
-                const int src = e & 63;
-                int link = lq0;
-                if (full) {
-                    const int l0 = __builtin_amdgcn_ds_bpermute(src << 2, lq0), l1 = __builtin_amdgcn_ds_bpermute(src << 2, lq1);
-                    link = (e & 64) ? l1 : l0;
-                }
-                bool hit = false;
-                if (mine) {
-                    const unsigned ra = pool + (unsigned)((tid & ~63) + src) * 4u;
-                    const float rox = __int_as_float(HZ_STACK_AT(ra)), roy = __int_as_float(HZ_STACK_AT(ra + (unsigned)(TPB * 4)));
-                    const float roz = __int_as_float(HZ_STACK_AT(ra + (unsigned)(2 * TPB * 4))), rdx_ = __int_as_float(HZ_STACK_AT(ra + (unsigned)(3 * TPB * 4)));
-                    const float rdy_ = __int_as_float(HZ_STACK_AT(ra + (unsigned)(4 * TPB * 4))), rdz_ = __int_as_float(HZ_STACK_AT(ra + (unsigned)(5 * TPB * 4)));
-                    float4 q0, q1, q2;
-                    hz_load_prim(prims + HZ_LEAF_ID(link), q0, q1, q2);
-                    if (COUNT) { cnt.tris += (q2.y == q2.y) ? 2 : 1; HZ_WAVE_TICK(cnt.w_leaves, lane); }
-                    hit = hz_quad_hit(rox, roy, roz, rdx_, rdy_, rdz_, tfar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
-                                      q2.x, q2.y, q2.z, q2.w, q2.y == q2.y);
-                }
-                const unsigned long long H = __ballot(hit);
-                const bool h0 = can_leaf & (((H >> slot0) & 1ull) != 0ull);
-                const bool h1 = two & (((H >> (slot1 & 63)) & 1ull) != 0ull);
-                // decided (blocked): lq0 = the NUMBER of the blocking leaf, node and lq1 empty; else the tested places leave the queue
-                const int blk_leaf = h0 ? HZ_LEAF_ID(lq0) : HZ_LEAF_ID(lq1);
-                const bool dec = h0 | h1;
-                const int nq0 = two ? HZ_EMPTY : lq1;
-                if (can_leaf) { lq0 = dec ? blk_leaf : nq0; lq1 = HZ_EMPTY; node = dec ? HZ_EMPTY : node; }
-            } else if (can_leaf) {
+            if (can_leaf) {
                 float4 q0, q1, q2;
                 hz_load_prim(prims + HZ_LEAF_ID(lq0), q0, q1, q2);
                 // a = (q0.x q0.y q0.z) b = (q0.w q1.x q1.y) c = (q1.z q1.w q2.x) d = (q2.y q2.z q2.w)
                 if (COUNT) { cnt.tris += (q2.y == q2.y) ? 2 : 1; HZ_WAVE_TICK(cnt.w_leaves, lane); }
-#ifdef HZ_PROBE_Q1
-                if (COUNT && lq1 < 0) cnt.q1++;
-#endif
                 const bool hit = hz_quad_hit(ox, oy, oz, dx, dy, dz, tfar, q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w,
                                              q2.x, q2.y, q2.z, q2.w, q2.y == q2.y);
                 if (hit) { lq0 = HZ_LEAF_ID(lq0); node = HZ_EMPTY; }     // decided: blocked by this leaf
@@ -820,16 +672,12 @@ typedef __attribute__((address_space(3))) int hz_lds_int;
         }
         top_of_iteration();
     }
-#ifdef HZ_PREFETCH
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(pf_sink) : : "memory");
-#endif
     if (!LEVELSTACK && sa_hi > sa_cap) overflow = true;
     const bool blocked = lq0 >= 0 && lq0 != HZ_EMPTY;
     const int res = blocked ? 1 : ((HZ_IS_NODE(node) || lq0 < 0) ? 2 : 0);
     if (blocked) lq0 = (int)((unsigned)lq0 | 0x80000000u);      // the caller reads the blocking leaf (as a link) from the state
     HZ_SAVE();
     return res;
-#undef HZ_PF
 #undef HZ_POP
 #undef HZ_SAVE
 #undef HZ_STACK_AT

@@ -27,29 +27,16 @@
  * with an "s" constraint).  hipcc otherwise hoists the ~60 coefficients of the refraction branch out of k_shadow_refill's cell
  * loop into vector registers that live through the traversal -- 29 spilled VGPRs at the 72 registers of 7 workgroups per CU;
  * pinned: 1 -- and config 4 with refraction runs 3.6 % faster (140.6 -> 135.5 ms per 144 sun positions,
- * profiles/r05/ab_crmath_sgpr_pin.log).  Same instructions on the same values: results unchanged (-DHZ_CRM_NO_PIN: off, for A/Bs).
- *
- * -DHZ_CRM_FUSED (both users, together) runs the steps as fused multiply-adds: one rounding per step instead of two, the error
- * bounds stated with each kernel only get smaller.  Measured in round 5 and NOT the default: unpinned it made the spills worse
- * (105 VGPRs: config 4 with refraction 24 % SLOWER, profiles/r05/ab_crmath_fused_horner.log); pinned (-DHZ_CRM_FUSED
- * -DHZ_CRM_FUSED_SGPR) it gains another 0.6 % over the pinned two-rounding steps -- not worth a change of the contract. */
+ * profiles/r05/ab_crmath_sgpr_pin.log).  Same instructions on the same values: results unchanged.
+ * (Fused steps were measured in round 5 and dropped: profiles/r05/ab_crmath_fused_horner.log; the switch is in profiles/r06/lab_probes.patch.) */
 #ifndef HZ_CRM_FMA
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(HZ_CRM_NO_PIN)
+#if defined(__HIP_DEVICE_COMPILE__)
 #define HZ_CRM_PINNED(c_) asm volatile("" : "+s"(c_))
 #else
 #define HZ_CRM_PINNED(c_) ((void)0)
 #endif
-#ifdef HZ_CRM_FUSED
-#define HZ_CRM_FMA(a, b, c) __builtin_fma((a), (b), (c))
-#if defined(HZ_CRM_FUSED_SGPR)
-#define HZ_CRM_FMAK(a, b, c) ({ double c_ = (c); HZ_CRM_PINNED(c_); __builtin_fma((a), (b), c_); })
-#else
-#define HZ_CRM_FMAK(a, b, c) __builtin_fma((a), (b), (c))
-#endif
-#else
 #define HZ_CRM_FMA(a, b, c) ((a) * (b) + (c))
 #define HZ_CRM_FMAK(a, b, c) ({ double c_ = (c); HZ_CRM_PINNED(c_); (a) * (b) + c_; })
-#endif
 #endif
 
 /* x / c for a CONSTANT c with rc = the double nearest to 1 / c: q = x rc, r = x - c q (exact: one fused multiply-add),

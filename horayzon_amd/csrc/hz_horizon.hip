@@ -87,9 +87,6 @@ struct HorizonParams {
 // (the counting instantiation carries ~20 more live values: at 5 workgroups per CU it spilled 10 - 22 VGPRs, so it is built
 //  for 4.  Its tallies -- rays, node visits, triangle tests, wave iterations -- are functions of the lanes' states only, not
 //  of the schedule, so they are the production launch's numbers: the ray counts of the two instantiations are compared by the tests.)
-#ifdef HZ_WG_TRACE   // measurement probe (scripts/build_variant.sh trace -DHZ_WG_TRACE): start / end of every wave on the 100 MHz clock
-__device__ unsigned long long *hz_wg_trace_buf = nullptr;      // [waves of the launch][2]
-#endif
 // One leftover record (written once per hand-over of a cell, at the end of a block).  Word 0 is the launch-local cell number
 // (row - row_begin) * dim_in_1 + column (32 bits: the host switches the hand-over off for launches of 2^32 - 1 cells or more);
 // ~0u marks a slot that was reserved and never filled.
@@ -125,21 +122,6 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
     HorizonParams p;
     HZ_LOAD_PARAMS(p);
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-#ifdef HZ_CODE_SHIFT   // measurement probe: moves everything below by 4 * HZ_CODE_SHIFT bytes (does the position of the traversal loop matter?)
-#pragma unroll
-    for (int q_ = 0; q_ < HZ_CODE_SHIFT; q_++) asm volatile("s_nop 0");
-#endif
-#ifdef HZ_LEAF_POOL      // experiment (scripts/build_variant.sh pool -DHZ_LEAF_POOL): the leaf step pools the wave's queued leaves (hz_trace POOL)
-    constexpr bool POOLK = !LEVELSTACK;
-#else
-    constexpr bool POOLK = false;
-#endif
-    // POOLK: [ staging | ray pool: 6 rows of HZ_TPB floats (origin, direction of every lane's ray) | item tables: 64 ints per wave | stack ]
-    constexpr int POOL_BYTES = 7 * HZ_TPB * 4;
-    typedef __attribute__((address_space(3))) float hz_lds_float;
-    const unsigned pool = (unsigned)(size_t)reinterpret_cast<hz_lds_float *>(
-                              (__attribute__((address_space(3))) char *)reinterpret_cast<char *>(smem)) + (unsigned)(p.pre_bytes - POOL_BYTES);
-#define HZ_POOL_AT(k) (*reinterpret_cast<hz_lds_float *>((size_t)(pool + (unsigned)((k) * HZ_TPB * 4) + (unsigned)threadIdx.x * 4u)))
     int *stack = reinterpret_cast<int *>(smem + p.pre_bytes);
     const float4 *top = reinterpret_cast<const float4 *>(smem + p.pre_bytes + p.stack_bytes);
     const int tid = threadIdx.x;
@@ -186,6 +168,11 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
         // then of the other XCDs'.
         blk = -1;
         const unsigned groups = (p.left_in_ctl[1] + 63u) / 64u;
+        if (p.tile_list) {           // the groups whose fast stack overflowed, one per wave (left_mode launch with a list)
+            const int b = (int)blockIdx.x * HZ_WPB + wave;
+            const int g = b < p.n_list ? p.tile_list[b] : -1;
+            if (g >= 0 && (unsigned)g < groups) { blk = g; rec0 = (unsigned)g * 64u; rec_n = min(64u, p.left_in_ctl[1] - (unsigned)g * 64u); }
+        } else
         while (xcc_off < 8) {
             const unsigned x = (unsigned)((xcc_own + xcc_off) & 7);
             unsigned q = 0u;
@@ -232,9 +219,6 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
     const bool in_dom = has_tile && (i < p.row_end) && (j < p.dim_in_1);
 
     const Tables &t = p.tb;
-#ifdef HZ_WG_TRACE
-    const unsigned long long trace_t0 = (unsigned long long)wall_clock64();
-#endif
     const unsigned long long t_start = COUNT ? (unsigned long long)wall_clock64() : 0ull;
     const size_t cell = in_dom ? ((size_t)i * p.dim_in_1 + j) : 0;
     bool done = !in_dom;
@@ -253,9 +237,6 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
     out.stride = HZ_TPB;
     float ox = 0, oy = 0, oz = 0;
     float r01 = 0, r02 = 0, r11 = 0, r12 = 0, r21 = 0, r22 = 0;
-#ifdef HZ_V_EAST_REG
-    float e00 = 0, e10 = 0, e20 = 0;
-#endif
     const bool masked = in_dom && p.mask[cell] != 1;
     {   // masked cells get hori_fill for every azimuth (horizon_comp.cpp:789-794).  The wave fills them together, one
         // cell after the other with consecutive lanes on consecutive azimuths: 256 B per store instruction instead of
@@ -284,19 +265,12 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
             r01 = north_x; r02 = norm_x;
             r11 = north_y; r12 = norm_y;
             r21 = north_z; r22 = norm_z;
-            if (POOLK) { HZ_POOL_AT(0) = ox; HZ_POOL_AT(1) = oy; HZ_POOL_AT(2) = oz; }
-#ifdef HZ_V_EAST_REG
-            e00 = north_y * norm_z - north_z * norm_y;
-            e10 = north_z * norm_x - north_x * norm_z;
-            e20 = north_x * norm_y - north_y * norm_x;
-#endif
         }
     }
     // (the origin in the scene-centred frame is formed from (ox, oy, oz) where it is needed -- three subtractions per ray
     //  instead of three more registers that live through the traversal; the empty asm stops the compiler from hoisting them)
-#define HZ_OC(ocx, ocy, ocz) float ocx, ocy, ocz; { float ax_, ay_, az_; \
-        if (POOLK) { ax_ = HZ_POOL_AT(0); ay_ = HZ_POOL_AT(1); az_ = HZ_POOL_AT(2); } \
-        else { ax_ = ox; ay_ = oy; az_ = oz; asm volatile("" : "+v"(ax_), "+v"(ay_), "+v"(az_)); } \
+#define HZ_OC(ocx, ocy, ocz) float ocx, ocy, ocz; { float ax_ = ox, ay_ = oy, az_ = oz; \
+        asm volatile("" : "+v"(ax_), "+v"(ay_), "+v"(az_)); \
         ocx = ax_ - p.sv.cx; ocy = ay_ - p.sv.cy; ocz = az_ - p.sv.cz; }
     const float tfar = p.dist;
 
@@ -305,9 +279,6 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
     s.lim_up = 0; s.lim_low = 0; s.elev_samp = 0; s.ev = 0;
     unsigned rays = 0, guards = 0, w_adv = 0;
     TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.w_nodes = 0; tc.w_leaves = 0;   // COUNT only
-#ifdef HZ_PROBE_Q1
-    tc.q1 = 0; tc.blk = 0; tc.fin = 0;
-#endif
     const unsigned cells_cnt = (in_dom && !done && !LEFT) ? 1u : 0u;
     bool ray_active = false, last_hit = false;
     float dx = 0, dy = 0, dz = 1;
@@ -343,7 +314,6 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
             dx = (r00 * rx + r01 * ry) + r02 * rz;
             dy = (r10 * rx + r11 * ry) + r12 * rz;
             dz = (r20 * rx + r21 * ry) + r22 * rz;
-            if (POOLK) { HZ_POOL_AT(3) = dx; HZ_POOL_AT(4) = dy; HZ_POOL_AT(5) = dz; }
             HZ_OC(ocx, ocy, ocz)
             rb = hz_raybox(ocx + p.neg_tau * dx, ocy + p.neg_tau * dy, ocz + p.neg_tau * dz, dx, dy, dz);
             hz_trav_reset(ts);
@@ -407,20 +377,15 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
                     near_rad = p.near_r[cert_r];
                 }
                 const float rx = ec * asn, ry = ec * acs, rz = es;
-#ifdef HZ_V_EAST_REG
-                const float r00 = e00, r10 = e10, r20 = e20;
-#else
                 float nx_ = r01, ny_ = r11, nz_ = r21;        // (the empty asm keeps the products inside the loop)
                 asm volatile("" : "+v"(nx_), "+v"(ny_), "+v"(nz_));
                 const float r00 = ny_ * r22 - nz_ * r12;      // east = north x norm (horizon_comp.cpp:763-766)
                 const float r10 = nz_ * r02 - nx_ * r22;
                 const float r20 = nx_ * r12 - ny_ * r02;
-#endif
                 dx = (r00 * rx + r01 * ry) + r02 * rz;
                 dy = (r10 * rx + r11 * ry) + r12 * rz;
                 dz = (r20 * rx + r21 * ry) + r22 * rz;
-                if (POOLK) { HZ_POOL_AT(3) = dx; HZ_POOL_AT(4) = dy; HZ_POOL_AT(5) = dz; }
-                tn = (s.ind >= near_i) ? near_rad : p.neg_tau;    // no certificate: the box tests start at -tau (hz_common.h)
+                    tn = (s.ind >= near_i) ? near_rad : p.neg_tau;    // no certificate: the box tests start at -tau (hz_common.h)
                 if (COUNT && tn > 0.0f) shortened++;
                 if (COUNT) want_v = p.verify_near && tn > 0.0f && (((rays + cert) & p.verify_mask) == 0u);
                 HZ_OC(ocx, ocy, ocz)
@@ -430,7 +395,6 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
                 second = p.hit_cache && (cache != 0) && (s.ind <= s.pazim) && (s.k > 0);
                 if (second) {
                     ts.node = cache;
-#ifndef HZ_V_CACHE_RESTART
                     // Fast stack (round 5): the ROOT waits in entry 1, below the cached subtree.  A cache walk that finds nothing
                     // pops it and carries on with the full traversal inside hz_trace -- the same node visits and triangle tests
                     // as leaving the loop with "miss" and coming back with a reset state (which is what `second` still does for
@@ -438,7 +402,6 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
                     // Depth: the walk below the cached node needs <= 3 * anc_levels entries above this one, far below the
                     // root traversal's own maximum, so no launch overflows that did not before.
                     if (!LEVELSTACK) { ts.sp = 1; stack[HZ_TPB + tid] = 0; second = false; }
-#endif
                 }
                 ray_active = true;
                 rays++;
@@ -450,16 +413,13 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
         bool start_v = false, viol = false;
         if (ray_active) {
             int r;
-            if (POOLK) r = hz_trace<HZ_TPB, COUNT, HZ_QLEN, NODELET, LEVELSTACK, POOLK>(p.sv.nodes, p.sv.prims, top, ntop, stack, tid, 0.0f, 0.0f, 0.0f,
-                                                 0.0f, 0.0f, 0.0f, tfar, p.dist_box, rb, ts, p.regroup, p.leaf_bias, tc, p.stack_cap, overflow, pool);
-            else r = hz_trace<HZ_TPB, COUNT, HZ_QLEN, NODELET, LEVELSTACK>(p.sv.nodes, p.sv.prims, top, ntop, stack, tid, ox, oy, oz,
+            r = hz_trace<HZ_TPB, COUNT, HZ_QLEN, NODELET, LEVELSTACK>(p.sv.nodes, p.sv.prims, top, ntop, stack, tid, ox, oy, oz,
                                                  dx, dy, dz, tfar, p.dist_box, rb, ts, p.regroup, p.leaf_bias, tc, p.stack_cap, overflow);
             if (r == 0 && second) {                      // nothing in the cached subtree: full traversal
                 second = false; hz_trav_reset(ts);
             } else if (COUNT && want_v && r != 2) {
                 // the shortened ray is done: trace it again over its full length and compare the decisions
                 want_v = false; verifying = true; first_result = (r == 1); start_v = true;
-                if (POOLK) { dx = HZ_POOL_AT(3); dy = HZ_POOL_AT(4); dz = HZ_POOL_AT(5); }
                 HZ_OC(ocx, ocy, ocz)
                 rb = hz_raybox(ocx + p.neg_tau * dx, ocy + p.neg_tau * dy, ocz + p.neg_tau * dz, dx, dy, dz);
                 hz_trav_reset(ts);
@@ -474,13 +434,6 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
             w_violations += (unsigned)__popcll(__ballot(viol));
         }
     }
-#ifdef HZ_WG_TRACE
-    if (lane == 0 && hz_wg_trace_buf != nullptr && !p.tile_list && blk >= 0) {
-        const size_t w = (size_t)blk;
-        hz_wg_trace_buf[2 * w] = trace_t0;
-        hz_wg_trace_buf[2 * w + 1] = (unsigned long long)wall_clock64() | ((unsigned long long)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u) << 60);
-    }
-#endif
     // one atomic per wave and counter
     unsigned long long r = rays, g = guards, nc = tc.nodes, tcn = tc.tris, cc = cells_cnt;
     unsigned long long wn = tc.w_nodes, wl = tc.w_leaves, wa = w_adv;
@@ -496,8 +449,9 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
     const bool wave_overflowed = !LEVELSTACK && __ballot(overflow) != 0ull;
     if (wave_overflowed) {
         if (lane == 0) {
-            const unsigned long long slot = atomicAdd(&p.counters[8], 1ull);
-            if (slot < (unsigned long long)HZ_REDO_CAP) p.redo_list[slot] = blk;
+            // (LEFT: the GROUP is computed again -- its records are only read here -- and has a count and a list of its own)
+            const unsigned long long slot = atomicAdd(&p.counters[LEFT ? 30 : 8], 1ull);
+            if (slot < (unsigned long long)HZ_REDO_CAP) p.redo_list[(LEFT ? HZ_REDO_CAP : 0) + (int)slot] = blk;
         }
     } else {
     const int guard_cells = __popcll(__ballot(guards != 0u && !(LEFT && had_guard)));   // cells where the reference's search would not terminate (a leftover cell: counted once)
@@ -510,13 +464,6 @@ __global__ __launch_bounds__(HZ_TPB, (COUNT ? 4 : HZ_WG_PER_CU) * (4 / HZ_WPB)) 
             atomicAdd(&p.counters[5], wn); atomicAdd(&p.counters[6], wl); atomicAdd(&p.counters[7], wa);
         }
     }
-#ifdef HZ_PROBE_Q1
-    if (COUNT) {
-        unsigned long long a = tc.q1, b = tc.blk, c = tc.fin;
-        for (int off = 32; off > 0; off >>= 1) { a += __shfl_xor(a, off); b += __shfl_xor(b, off); c += __shfl_xor(c, off); }
-        if (lane == 0) { atomicAdd(&p.counters[22], a); atomicAdd(&p.counters[23], b); atomicAdd(&p.counters[21], c); }   // (21: the verify tally, unused in this probe)
-    }
-#endif
     if (COUNT) {
         // when did the last wave of each XCD finish?  (counters[12 + xcc] = latest end, counters[20] = ~earliest start, on
         // the 100 MHz real-time counter; HZ_XCD_TRACE=1 prints the spans: the 8 XCDs own fixed regions of the tile)
@@ -584,13 +531,15 @@ static int launch_one(const HorizonParams &p_in, int grid, size_t lds, int persi
 
 // The LEFT instantiation: always persistent -- how many records there are is only known on the device (left_in_ctl), so the launch has
 // the resident number of workgroups and every wave pulls groups of 64 records until the sub-regions are empty.
-template <int ALG, bool STAGE>
+// (with a list -- the groups to repeat after a stack overflow -- one group per wave of a plain launch)
+template <int ALG, bool STAGE, bool LS>
 static int launch_left(const HorizonParams &p, size_t lds, int persist_grid, hipStream_t st) {
-    const void *func = reinterpret_cast<const void *>(k_horizon<ALG, false, STAGE, false, true, true>);
+    const void *func = reinterpret_cast<const void *>(k_horizon<ALG, false, STAGE, false, LS, true>);
     HZ_HIP(hipFuncSetAttribute(func, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    long long grid = persist_grid > 0 ? (long long)persist_grid : resident_workgroups(func, lds);
+    long long grid = p.tile_list ? (long long)((p.n_list + HZ_WPB - 1) / HZ_WPB)
+                                 : (persist_grid > 0 ? (long long)persist_grid : resident_workgroups(func, lds));
     if (grid <= 0) grid = 1024;
-    hipLaunchKernelGGL((k_horizon<ALG, false, STAGE, false, true, true>), dim3((unsigned)grid), dim3(HZ_TPB), lds, st, p);
+    hipLaunchKernelGGL((k_horizon<ALG, false, STAGE, false, LS, true>), dim3((unsigned)grid), dim3(HZ_TPB), lds, st, p);
     HZ_HIP(hipGetLastError());
     return HZ_OK;
 }
@@ -645,7 +594,10 @@ int left_sort(const HorizonArgs &a, int r, hipStream_t st) {
 template <int ALG>
 static int launch_alg(const HorizonParams &p, int grid, size_t lds, bool count, bool level_stack, int pg, hipStream_t st) {
     const bool stage = p.stage_bytes != 0;
-    if (p.left_mode) return stage ? launch_left<ALG, true>(p, lds, pg, st) : launch_left<ALG, false>(p, lds, pg, st);
+    if (p.left_mode) {
+        if (level_stack) return stage ? launch_left<ALG, true, true>(p, lds, pg, st) : launch_left<ALG, false, true>(p, lds, pg, st);
+        return stage ? launch_left<ALG, true, false>(p, lds, pg, st) : launch_left<ALG, false, false>(p, lds, pg, st);
+    }
     if (ALG == ALG_GUESS && !count && p.top_nodes > 0) {    // opt-in LDS nodelet variant (opts.top_nodes > 0)
         if (!level_stack) return stage ? launch_one<ALG_GUESS, false, true, true, false>(p, grid, lds, pg, st)
                                        : launch_one<ALG_GUESS, false, false, true, false>(p, grid, lds, pg, st);
@@ -694,18 +646,13 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
     // keeps it for the scene.  Shallow trees whose worst case fits never need the second kernel.
     const int stage = ((a.azim_num & 3) == 0 && (reinterpret_cast<size_t>(a.hori) & 15) == 0) ? 4 * HZ_TPB * 4 : 0;
     // (two rows: a lane that has popped its sentinel but still has queued leaves reads the two rows below the stack)
-#ifdef HZ_LEAF_POOL
-    const int pool_bytes = (a.level_stack > 0) ? 0 : 7 * HZ_TPB * 4;      // ray pool + item tables in front of the fast stack
-#else
-    const int pool_bytes = 0;
-#endif
-    const int pre = (stage ? stage : 2 * HZ_TPB * 4) + pool_bytes;
+    const int pre = stage ? stage : 2 * HZ_TPB * 4;
     const int height = std::max(sc->hdr.height, 1);
     // (a.level_stack < 0: test hook, the fast discipline with that many entries)
     // (with the opt-in LDS nodelet the fast stack gives up the entries the nodelet's bytes need, so that 5 workgroups stay resident)
     const int want_top = (a.top_nodes > 0 && a.alg == ALG_GUESS && !a.count_work) ? std::min(a.top_nodes, sc->hdr.n_top) : 0;
-    // (HZ_LDS_BUDGET: bytes of LDS per workgroup the fast stack may use with staging and nodelet -- experiments with the residency)
-    static const int lds_budget = []() { const char *e = getenv("HZ_LDS_BUDGET"); return (e && atoi(e) > 8192 ? atoi(e) : 31 * 1024) / (4 / HZ_WPB); }();
+    // (bytes of LDS per workgroup the fast stack may use together with staging and nodelet: 31 KiB keeps 5 workgroups per CU resident)
+    const int lds_budget = 31 * 1024 / (4 / HZ_WPB);
     // (entry 0 of the fast stack is the sentinel, and a node step wants three free entries above the top: at least 4)
     const int fast_cap = a.level_stack < 0 ? std::max(-a.level_stack, 4)
                                            : std::max((lds_budget - pre - want_top * (int)sizeof(Node)) / (HZ_TPB * 4), 4);
@@ -755,46 +702,18 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
     p.left_out_cap = hands_over ? a.left_cap[p.left_mode] : 0u;
     p.left_out_ctl = left_ctl + 16 * std::min(p.left_mode, HZ_LEFT_LEVELS - 1);
     // persistent waves (k_horizon): the default for full launches; a.no_persist restores one tile per workgroup (same-box A/Bs)
-    p.persist = ((!a.no_persist && a.tile_list == nullptr && HZ_WPB == 4) || p.left_mode) ? 1 : 0;
+    p.persist = (a.tile_list == nullptr && ((!a.no_persist && HZ_WPB == 4) || p.left_mode)) ? 1 : 0;
     p.queue = reinterpret_cast<unsigned *>(a.counters + 24);
     const size_t lds = (size_t)p.pre_bytes + (size_t)p.stack_bytes + (size_t)top * sizeof(Node);
     const int grid = a.tile_list ? (a.n_list + HZ_WPB - 1) / HZ_WPB : p.tm.per_xcd * 8 * (4 / HZ_WPB);
     if (grid <= 0) return HZ_OK;
     const bool count = a.count_work != 0;
-#ifdef HZ_WG_TRACE
-    // probe build: every launch is synchronous and appends "start end xcc" lines (10 ns ticks relative to the first start) to $HZ_WG_TRACE_OUT
-    unsigned long long *trace_dev = nullptr;
-    const size_t n_waves = (size_t)grid * HZ_WPB;
-    if (getenv("HZ_WG_TRACE_OUT") && !a.tile_list) {
-        HZ_HIP(hipMalloc((void **)&trace_dev, n_waves * 16));
-        HZ_HIP(hipMemsetAsync(trace_dev, 0, n_waves * 16, st));
-        HZ_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(hz_wg_trace_buf), &trace_dev, sizeof(trace_dev), 0, hipMemcpyHostToDevice, st));
-    }
-#endif
     int rc_launch;
     switch (a.alg) {
         case ALG_DISCRETE: rc_launch = launch_alg<ALG_DISCRETE>(p, grid, lds, count, level_stack, a.persist_grid, st); break;
         case ALG_BINARY: rc_launch = launch_alg<ALG_BINARY>(p, grid, lds, count, level_stack, a.persist_grid, st); break;
         default: rc_launch = launch_alg<ALG_GUESS>(p, grid, lds, count, level_stack, a.persist_grid, st); break;
     }
-#ifdef HZ_WG_TRACE
-    if (trace_dev) {
-        std::vector<unsigned long long> h(2 * n_waves);
-        HZ_HIP(hipStreamSynchronize(st));
-        HZ_HIP(hipMemcpy(h.data(), trace_dev, n_waves * 16, hipMemcpyDeviceToHost));
-        unsigned long long *nul = nullptr;
-        HZ_HIP(hipMemcpyToSymbol(HIP_SYMBOL(hz_wg_trace_buf), &nul, sizeof(nul)));
-        (void)hipFree(trace_dev);
-        unsigned long long t0 = ~0ull;
-        for (size_t w = 0; w < n_waves; w++) if (h[2 * w]) t0 = std::min(t0, h[2 * w]);
-        if (FILE *f = fopen(getenv("HZ_WG_TRACE_OUT"), "a")) {
-            fprintf(f, "# launch rows %d..%d waves %zu wpb %d\n", a.row_begin, a.row_end, n_waves, HZ_WPB);
-            for (size_t w = 0; w < n_waves; w++)
-                if (h[2 * w]) fprintf(f, "%llu %llu %llu\n", h[2 * w] - t0, (h[2 * w + 1] & 0x0fffffffffffffffull) - t0, h[2 * w + 1] >> 60);
-            fclose(f);
-        }
-    }
-#endif
     return rc_launch;
 }
 
@@ -979,11 +898,10 @@ int topo_launch(int kind, const float *azim, const float *hori, const float *vec
     const size_t ncell = (size_t)len_0 * len_1;
     if (ncell == 0) return HZ_OK;
     const size_t lds = (2 * (size_t)len_2 + 4 * 64 * (HZ_TOPO_CH + 1)) * sizeof(float);
-    // (HZ_TOPO_WIDE=1: force the fallback kernel -- tests compare the two paths on the same input, so that they cannot
-    //  drift apart: k_topo takes the float32 arctangent only where the tilted plane limits, k_topo_wide calls libm's
+    // (hz_debug_set("topo_wide", 1) forces the fallback kernel -- tests compare the two paths on the same input, so that they
+    //  cannot drift apart: k_topo takes the float32 arctangent only where the tilted plane limits, k_topo_wide calls libm's
     //  float64 routines per azimuth as the Cython code does; both are held to 1e-5 against the reference-made fixtures)
-    const char *force_wide = getenv("HZ_TOPO_WIDE");
-    if (lds <= 60 * 1024 && !(force_wide && force_wide[0] == '1')) {
+    if (lds <= 60 * 1024 && g_topo_wide.load(std::memory_order_relaxed) == 0) {
         const dim3 grid((unsigned)((ncell + 255) / 256)), block(256);
         if (kind == 0) hipLaunchKernelGGL(k_topo<0>, grid, block, lds, st, azim, hori, vec_tilt, ncell, len_2, out);
         else if (kind == 1) hipLaunchKernelGGL(k_topo<1>, grid, block, lds, st, azim, hori, vec_tilt, ncell, len_2, out);

@@ -24,6 +24,11 @@ namespace hz {
 
 int set_error(int code, const char *fmt, ...);
 
+#define HZ_SHADOW_FAST_CAP_DEFAULT 19   // entries of k_shadow_refill's fast stack (hz_shadow.hip)
+// test knobs (hz_debug_set, include/horayzon_hip.h): process wide, read at every launch; results never depend on them
+extern std::atomic<int> g_shadow_fast_cap;   // entries of k_shadow_refill's fast stack (default HZ_SHADOW_FAST_CAP_DEFAULT; 0: level stack only)
+extern std::atomic<int> g_topo_wide;         // 1: the reductions over the azimuth axis use the fallback kernel k_topo_wide
+
 #define HZ_HIP(expr)                                                                      \
     do {                                                                                  \
         hipError_t e_ = (expr);                                                           \
@@ -93,8 +98,6 @@ inline SceneView scene_view(const Scene *sc) {
 
 inline TileMap make_tile_map(int tiles_i, int tiles_j, int gw = 8) {
     TileMap m;
-    static const int gw_env = []() { const char *e = getenv("HZ_TILE_GW"); return e ? atoi(e) : 0; }();
-    if (gw_env > 0) gw = gw_env;
     m.tiles_i = tiles_i; m.tiles_j = tiles_j; m.gw = gw;
     m.rj = std::max(1, (tiles_j + 7) / 8);
     // patch rows: near-square patches, but at least 16 rows when the grid is high enough and at most 64.  Measured on
@@ -103,8 +106,6 @@ inline TileMap make_tile_map(int tiles_i, int tiles_j, int gw = 8) {
     // super tiles (ms per sun position): 1: 1.455, 8: 1.265, 32: 1.317, 56: 1.260, 112: 1.417
     int pi = (tiles_i + m.rj - 1) / m.rj;
     pi = std::min(std::max(pi, std::min(16, tiles_i / 4)), 64);
-    static const int pi_env = []() { const char *e = getenv("HZ_PATCH_ROWS"); return e ? atoi(e) : 0; }();
-    if (pi_env > 0) pi = pi_env;
     pi = std::max(1, std::min(pi, tiles_i));
     m.pi = pi;
     m.ri = (tiles_i + pi - 1) / pi;
@@ -158,7 +159,7 @@ struct HorizonArgs {
                                          // allocated in region r, [r][1] = valid records (k_left_keys), [r][8 + x] = groups of 64 handed to XCD x
 };
 // default hand-over thresholds: byte l = level l (hz_opts.left_min)
-#define HZ_LEFT_DEFAULT 0x00000020u
+#define HZ_LEFT_DEFAULT 0x00000024u
 #define HZ_CNT_LEFT 32                   // first u64 word of the leftover control words
 #define HZ_CNT_N 64                      // u64 words in front of the redo list
 #define HZ_LEFT_WORDS 16                 // 32-bit words per leftover record

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
         if (i1 - i0 >= 8 || j1 - j0 >= 8) bad_mesh = true;
         else {
             const int i = i0 + (lane & 7), j = j0 + (lane >> 3);
-            const bool hit = i <= i1 && j <= j1 && ((p.bad_bits[((size_t)j * nb + i) >> 5] >> (i & 31)) & 1u) != 0u;
+            const bool hit = i <= i1 && j <= j1 && ((p.bad_bits[((size_t)j * nb + i) >> 5] >> (((size_t)j * nb + i) & 31)) & 1u) != 0u;
             bad_mesh = __ballot(hit) != 0ull;
         }
     }

@@ -249,7 +249,7 @@ __global__ __launch_bounds__(256) void k_mark_bad(BuildParams b, int majority, B
                 const float cx = m.x0 + ((float)i + 0.5f) / m.sx;
                 if (ex[0] * cx + ey[0] * cy > ec[0] || ex[1] * cx + ey[1] * cy > ec[1] || ex[2] * cx + ey[2] * cy > ec[2]) continue;
             }
-            atomicOr(&m.bits[((size_t)j * m.nb + i) >> 5], 1u << (i & 31));
+            atomicOr(&m.bits[((size_t)j * m.nb + i) >> 5], 1u << (((size_t)j * m.nb + i) & 31));      // bit (j * nb + i) of the bitmap
         }
     }
 }

@@ -46,18 +46,13 @@ __device__ __forceinline__ float f_sin(float x) { return hz_crm_sinf(x); }
 __device__ __forceinline__ float f_pow(float x, float y) { return hz_crm_powf(x, y); }
 
 // shadow_comp.cpp:43-62: float in, double arithmetic, float out.  The divisions by the two constants are the correctly rounded
-// quotients in four instructions each (hz_crmath.h: hz_crm_div_const; -DHZ_V_IEEE_CONST_DIV: plain divisions, for A/Bs)
-#ifdef HZ_V_IEEE_CONST_DIV
-__device__ __forceinline__ float deg2rad_f(float a) { return (float)(((double)a / 180.0) * 3.14159265358979323846); }
-__device__ __forceinline__ float rad2deg_f(float a) { return (float)(((double)a / 3.14159265358979323846) * 180.0); }
-#else
+// quotients in four instructions each (hz_crmath.h: hz_crm_div_const)
 __device__ __forceinline__ float deg2rad_f(float a) {
     return (float)(hz_crm_div_const((double)a, 180.0, 1.0 / 180.0) * 3.14159265358979323846);
 }
 __device__ __forceinline__ float rad2deg_f(float a) {
     return (float)(hz_crm_div_const((double)a, 3.14159265358979323846, 1.0 / 3.14159265358979323846) * 180.0);
 }
-#endif
 
 // shadow_comp.cpp:96-106
 __device__ __forceinline__ void vec_unit(float &x, float &y, float &z) {
@@ -98,23 +93,6 @@ int shadow_refrac_factor(const float *elevation, size_t n, double *out, hipStrea
 }
 
 // any-hit traversal to completion (regroup = 0: never suspends; no LDS nodelet: top = null)
-template <bool COUNT>
-__device__ __forceinline__ bool occluded(const SceneView &sv, int *stack, int tid,
-                                         float ox, float oy, float oz, float dx, float dy, float dz,
-                                         float tfar, TravCounters &tc) {
-#ifdef HZ_PROBE_SHADOW_TN     // measurement probe (results NOT valid): every ray's box tests start HZ_PROBE_SHADOW_TN metres out
-    const float tn_ = (float)HZ_PROBE_SHADOW_TN;
-    const RayBox rb = hz_raybox(ox - sv.cx + tn_ * dx, oy - sv.cy + tn_ * dy, oz - sv.cz + tn_ * dz, dx, dy, dz);
-#else
-    // (box tests start at -tau: hz_common.h)
-    const RayBox rb = hz_raybox((ox - sv.cx) - sv.tau * dx, (oy - sv.cy) - sv.tau * dy, (oz - sv.cz) - sv.tau * dz, dx, dy, dz);
-#endif
-    TravState ts; hz_trav_reset(ts);
-    bool overflow = false;      // unused: the one-entry-per-level stack cannot overflow
-    return hz_trace<HZ_TPB, COUNT>(sv.nodes, sv.prims, nullptr, 0, stack, tid, ox, oy, oz, dx, dy, dz, tfar, tfar + 2.0f * sv.tau, rb,
-                                   ts, 0, HZ_SHADOW_LEAF_BIAS, tc, 0, overflow) == 1;
-}
-
 template <bool COUNT>
 __device__ __forceinline__ void shadow_counters(const ShadowParams &p, unsigned rays, const TravCounters &tc, int lane) {
     unsigned long long r = rays;
@@ -204,42 +182,13 @@ __device__ __forceinline__ void shadow_result(const ShadowParams &p, size_t cell
     out_f32[cell] = (r.dot_ts / dot_prod_ns) * p.surf_enl_fac[cell];
 }
 
-// k_shadow: one lane = one cell, one ray, traced to completion (the round-2 kernel; HZ_SHADOW_REFILL=0 selects it).
-// COUNT: also count node visits / triangle tests / wave-level steps (Terrain count_work; the roofline's B_trav)
-template <bool COUNT>
-__global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    int *stack = reinterpret_cast<int *>(smem);
-    const int tid = threadIdx.x;
-    int ti = 0, tj = 0;
-    const bool has_tile = hz_tile_of_block(p.tm, blockIdx.x, &ti, &tj);
-    const int wave = tid >> 6, lane = tid & 63;
-    const int i = ti * 16 + (wave >> 1) * 8 + (lane >> 3);
-    const int j = tj * 16 + (wave & 1) * 8 + (lane & 7);
-    const bool in_dom = has_tile && (i < p.dim_in_0) && (j < p.dim_in_1);
-    // all sun positions of a batch in ONE launch (grid.y): no launch gap and no draining tail between positions, and
-    // the workgroups of night positions (no rays) make room at once
-    const int sun_idx = blockIdx.y;
-    const float p_sun_x = p.suns[3 * sun_idx], p_sun_y = p.suns[3 * sun_idx + 1], p_sun_z = p.suns[3 * sun_idx + 2];
-    uint8_t *const out_u8 = p.out_u8 ? p.out_u8 + (size_t)sun_idx * p.out_stride : nullptr;
-    float *const out_f32 = p.out_f32 ? p.out_f32 + (size_t)sun_idx * p.out_stride : nullptr;
-    unsigned rays = 0;
-    TravCounters tc; tc.nodes = 0; tc.tris = 0; tc.w_nodes = 0; tc.w_leaves = 0;
-    ShadowRay r;
-    if (in_dom && shadow_setup(p, i, j, p_sun_x, p_sun_y, p_sun_z, out_u8, out_f32, r)) {
-        rays = 1;
-        const bool h = occluded<COUNT>(p.sv, stack, tid, r.ox, r.oy, r.oz, r.dx, r.dy, r.dz, __builtin_inff(), tc);
-        shadow_result(p, (size_t)i * p.dim_in_1 + j, h, r, out_u8, out_f32);
-    }
-    shadow_counters<COUNT>(p, rays, tc, lane);
-}
 
 // k_shadow_refill: a wave owns p.nb consecutive 8 x 8 blocks (the same quadrant of nb neighbouring 16 x 16
-// tiles) and hands their cells to its lanes as they become free.  The rays of one sun position are parallel, so a
-// wave's duration in k_shadow is its longest ray while most lanes idle (45 % of the lanes active per VALU
-// instruction, profiles/r02/pmc_shadow_summary.json); here a lane whose ray is finished takes the next cell once
-// fewer than `regroup` lanes are still traversing (the ray compaction of the horizon kernel).  Cells are handed out
-// in block order, so the rays in flight stay neighbours.  Results are those of k_shadow bit for bit.
+// tiles) and hands their cells to its lanes as they become free.  The rays of one sun position are parallel, so with one
+// ray per lane traced to completion (the round-2 kernel k_shadow, removed in round 6) a wave lasted as long as its longest
+// ray while most lanes idled (45 % of the lanes active per VALU instruction, profiles/r02/pmc_shadow_summary.json); here a
+// lane whose ray is finished takes the next cell once fewer than `regroup` lanes are still traversing (the ray compaction of
+// the horizon kernel).  Cells are handed out in block order, so the rays in flight stay neighbours.
 #ifndef HZ_SHADOW_FAST_CAP_DEFAULT
 #define HZ_SHADOW_FAST_CAP_DEFAULT 19   // 21 KiB of LDS per workgroup: 7 resident; round 4: level stack 1.074 -> fast stack 0.964 ms per position at 5 workgroups (profiles/r04/ab_shadow_fast_stack.log)
 #endif
@@ -256,6 +205,7 @@ __global__ __launch_bounds__(HZ_TPB) void k_shadow(ShadowParams p) {
 #ifndef HZ_SHADOW_WG
 #define HZ_SHADOW_WG 7
 #endif
+// COUNT: also count node visits / triangle tests / wave-level steps (Terrain count_work; the roofline's B_trav)
 template <bool COUNT, bool FAST>
 __global__ __launch_bounds__(HZ_TPB, COUNT ? 5 : HZ_SHADOW_WG) void k_shadow_refill(ShadowParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -325,6 +275,9 @@ __global__ __launch_bounds__(HZ_TPB, COUNT ? 5 : HZ_SHADOW_WG) void k_shadow_ref
     shadow_counters<COUNT>(p, rays, tc, lane);
 }
 
+std::atomic<int> g_shadow_fast_cap{HZ_SHADOW_FAST_CAP_DEFAULT};      // hz_debug_set (hz_internal.h)
+std::atomic<int> g_topo_wide{0};
+
 int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st) {
     ShadowParams p;
     p.sv = scene_view(sc);
@@ -345,19 +298,16 @@ int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st) {
     p.counters = a.counters;
     // fast stack (k_shadow_refill<.., true>): HZ_SHADOW_FAST_CAP entries (0: off) behind two padding rows, if the level
     // stack of the in-kernel retry fits into them
-    static const int fast_cap_env = []() { const char *e = getenv("HZ_SHADOW_FAST_CAP"); return e ? atoi(e) : HZ_SHADOW_FAST_CAP_DEFAULT; }();
+    const int fast_cap_env = g_shadow_fast_cap.load(std::memory_order_relaxed);      // (hz_debug_set("shadow_fast_cap", n): tests)
     const int height = std::max(sc->hdr.height, 1);
     const int fast_cap = std::min(fast_cap_env, 3 * height + 1);
     const bool fast = fast_cap >= 5 && fast_cap >= height;
     p.stack_cap = fast ? fast_cap : 0;
     const size_t lds = fast ? (size_t)(fast_cap + 2) * HZ_TPB * 4 : (size_t)p.stack_bytes;
-    static const bool refill = []() { const char *e = getenv("HZ_SHADOW_REFILL"); return !(e && e[0] == '0'); }();
     // blocks per wave: as many as leave >= ~48 workgroups per CU over the whole launch (measured on the 3601^2 tile, 144
     // positions per launch: 2 / 4 / 8 / 16 / 32 / 64 blocks -> 1.64 / 1.49 / 1.42 / 1.36 / 1.29 / 1.51 ms per position; a single
     // position: 1 / 2 / 4 / 8 / 16 blocks -> 2.49 / 1.77 / 1.67 / 1.65 / 1.79 ms, k_shadow 2.52 ms)
-    p.nb = 1;
-    if (refill) {
-        static const int nb_env = []() { const char *e = getenv("HZ_SHADOW_NB"); return e ? atoi(e) : 0; }();
+    {
         const int tiles_j = (a.dim_in_1 + 15) / 16;
         const double wgs = (double)tiles_i * tiles_j * (double)a.num_sun;
         int nb = (int)(wgs / (48.0 * 256.0));
@@ -366,7 +316,6 @@ int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st) {
         // wave measured 1.41 ms, 32 blocks 1.29 ms per position)
         for (int c = nb; c >= std::max(1, (nb * 3) / 4); c--)
             if (tiles_j % c == 0) { nb = c; break; }
-        if (nb_env > 0) nb = std::min(nb_env, tiles_j);
         p.nb = nb;
         p.tm = make_tile_map(tiles_i, (tiles_j + nb - 1) / nb);
     }
@@ -375,9 +324,8 @@ int shadow_launch(const Scene *sc, const ShadowArgs &a, hipStream_t st) {
 #define HZ_LAUNCH_SHADOW(K) do { \
         HZ_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL(K, grid, dim3(HZ_TPB), lds, st, p); } while (0)
-    if (refill && fast) { if (a.count_work) HZ_LAUNCH_SHADOW((k_shadow_refill<true, true>)); else HZ_LAUNCH_SHADOW((k_shadow_refill<false, true>)); }
-    else if (refill) { if (a.count_work) HZ_LAUNCH_SHADOW((k_shadow_refill<true, false>)); else HZ_LAUNCH_SHADOW((k_shadow_refill<false, false>)); }
-    else { if (a.count_work) HZ_LAUNCH_SHADOW(k_shadow<true>); else HZ_LAUNCH_SHADOW(k_shadow<false>); }
+    if (fast) { if (a.count_work) HZ_LAUNCH_SHADOW((k_shadow_refill<true, true>)); else HZ_LAUNCH_SHADOW((k_shadow_refill<false, true>)); }
+    else { if (a.count_work) HZ_LAUNCH_SHADOW((k_shadow_refill<true, false>)); else HZ_LAUNCH_SHADOW((k_shadow_refill<false, false>)); }
 #undef HZ_LAUNCH_SHADOW
     HZ_HIP(hipGetLastError());
     return HZ_OK;

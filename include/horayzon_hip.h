@@ -129,12 +129,14 @@ typedef struct hz_stats {
     uint64_t left_again;   /* hand-overs by the leftover launches themselves (levels >= 1)                                    */
     uint64_t scratch_bytes;/* HBM scratch this call used besides the scene and the caller's buffers: near-field certificates, */
                            /*   leftover records, the horizon chunk buffers of a host / skipped hori_buffer                   */
+    uint64_t left_redo_groups; /* groups of 64 leftover cells computed again with the one-entry-per-level stack after a ray of */
+                           /*   theirs ran out of entries of the fast one (counted in stack_redo_blocks as well)               */
 } hz_stats;
 
 const char *hz_last_error(void);
 /* sizeof(hz_opts), sizeof(hz_stats) as compiled: lets a binding verify its mirror */
 int hz_abi_struct_sizes(int *opts_bytes, int *stats_bytes);
-/* ABI revision.  6 (round 6): opts.left_min, persist_grid and hz_stats.left_again, scratch_bytes appended.  5 (round 5): hz_stats.t_left_s, left_cells appended.  4 (round 4): hz_stats.near_verified appended; opts.verify_near is a sampling period (1 = every ray, as   */
+/* ABI revision.  6 (round 6): opts.left_min, persist_grid, left_cap_test and hz_stats.left_again, scratch_bytes, left_redo_groups appended.  5 (round 5): hz_stats.t_left_s, left_cells appended.  4 (round 4): hz_stats.near_verified appended; opts.verify_near is a sampling period (1 = every ray, as   */
 /* before).  3 (round 3): {row_begin > 0, row_end = 0} is rejected (was "to the end": use row_end = -1); opts.regroup <= 0 */
 /* means the default threshold (was: 0 = ray compaction off; 64 | bias << 8 still disables the early exit in effect)     */
 int hz_abi_version(void);
@@ -250,6 +252,10 @@ int hz_debug_valu_peak(int device, int packed, int waves_per_simd, double *winst
 int hz_debug_copy_peak(int device, size_t bytes, double *gbs);
 /* issue rate of one VALU instruction kind (selector list: hz_bench.hip) in cycles per wave64 instruction per SIMD */
 int hz_debug_inst_rate(int device, int op, double *cycles_per_inst);
+/* test knobs (process wide; results never depend on them): "shadow_fast_cap" = entries of the shadow kernel's fast stack (< 0: */
+/* the default; small values make the in-kernel retry with the level stack the common case), "topo_wide" = 1: the reductions    */
+/* over the azimuth axis use the one-lane-per-cell fallback kernel                                                               */
+int hz_debug_set(const char *key, int value);
 
 /* ------------------------------------------------------------------------- */
 /* Steps next to the path: slope and input preparation */

@@ -116,7 +116,7 @@ def main():
                 leaf_end = i + 1
                 break
     sec = {"node_step": k[node[1]:leaf[0]], "leaf_step": k[leaf[1]:leaf_end], "refill_and_loop_overhead": k[outer:hdr]}
-    res = {"kernel_source_sha": bench.kernel_source_sha(), "classes": "fast: " + ", ".join(FAST)}
+    res = {"kernel_asm_sha": bench.kernel_asm_sha(), "classes": "fast: " + ", ".join(FAST)}
     for name, lines in sec.items():
         f, s, names = classify(lines)
         res[name] = {"fast": f, "slow": s, "fast_fraction": f / max(f + s, 1), "slow_breakdown": names,

@@ -62,18 +62,27 @@ def kernels(lines):
     return out
 
 
+def assemblies(tree):
+    """{source: normalised listing}, the three compilations side by side."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(len(SOURCES)) as ex:
+        return dict(zip(SOURCES, ex.map(lambda s_: normalise(assembly(tree, s_)), SOURCES)))
+
+
 def sha(tree=ROOT):
     h = hashlib.sha256()
+    asm = assemblies(tree)
     for src in SOURCES:
-        for t in normalise(assembly(tree, src)):
+        for t in asm[src]:
             h.update(t.encode()); h.update(b"\n")
     return h.hexdigest()
 
 
 def diff(a, b):
     rc = 0
+    asm_a, asm_b = assemblies(a), assemblies(b)
     for src in SOURCES:
-        ka, kb = kernels(normalise(assembly(a, src))), kernels(normalise(assembly(b, src)))
+        ka, kb = kernels(asm_a[src]), kernels(asm_b[src])
         bad = sorted(k for k in set(ka) | set(kb) if ka.get(k) != kb.get(k))
         if not bad:
             print("%-18s identical device code (%d kernels)" % (src, len(ka)))

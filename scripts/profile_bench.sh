@@ -31,5 +31,13 @@ timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_V
     python $R/bench.py --workload c4 --steps 2 --no-count > /dev/null 2> $R/gpurun_out/${P}_c4sq.err
 timeout 600 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d $R/gpurun_out/${P}_c4grbm -- \
     python $R/bench.py --workload c4 --steps 2 --no-count > /dev/null 2> $R/gpurun_out/${P}_c4grbm.err
+# wait / busy split of the wave cycles, final kernels (two passes each: the SQ counters of one pass share 8 slots)
+for W in "wb1:SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" "wb2:SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_VALU"; do
+  tag=${W%%:*}; set=${W#*:}
+  timeout 600 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/${P}_$tag -- \
+      python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-count --no-peaks --no-e2e --no-extras > /dev/null 2> $R/gpurun_out/${P}_$tag.err
+  timeout 600 rocprofv3 --pmc $set --output-format csv -d $R/gpurun_out/${P}_c4$tag -- \
+      python $R/bench.py --workload c4 --steps 1 --warmup 0 --no-count > /dev/null 2> $R/gpurun_out/${P}_c4$tag.err
+done
 cd $R
 tail -1 gpurun_out/${P}_kt_bench.json | cut -c1-400

@@ -1,14 +1,15 @@
 """Copy the rocprofv3 summaries of a bench run from gpurun_out/ into profiles/<round>/ and recompute
 profiles/traffic.json (HBM bytes of k_horizon per launch) and profiles/valu_model.json (wave-level VALU
-instructions per wave iteration, calibrated on SQ_INSTS_VALU), both stamped with the hash of the kernel sources
-they were measured for -- bench.py refuses them when the sources changed.
+instructions per wave iteration, calibrated on SQ_INSTS_VALU), both stamped with the hash of the kernels' device assembly
+(scripts/kernel_asm.py) they were measured for -- bench.py refuses them when the machine code changed.  "The traversal" is the
+production instantiation of k_horizon PLUS its follow-up launch (LEFT) of the same step: their counters are added up.
 usage: refresh_profiles.py <prefix> <round>, e.g. prof2 r02"""
 import csv, glob, json, os, shutil, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 pre, rnd = sys.argv[1], sys.argv[2]
 os.makedirs("profiles/%s" % rnd, exist_ok=True)
-sha = bench.kernel_source_sha()
+sha = bench.kernel_asm_sha()
 newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)       # gpurun_out/ keeps the files of earlier calls
 shutil.copy(newest("gpurun_out/%s_kt/*/*kernel_stats.csv" % pre), "profiles/%s/bench_kernel_stats.csv" % rnd)
 shutil.copy("gpurun_out/%s_kt_bench.json" % pre, "profiles/%s/bench_under_rocprof.json" % rnd)
@@ -22,7 +23,8 @@ try:      # config 4
     shutil.copy("gpurun_out/%s_c4kt_bench.json" % pre, "profiles/%s/bench_c4_under_rocprof.json" % rnd)
 except (ValueError, OSError):
     pass
-KERNEL = "k_horizon<2, false, true, false, false, false>"      # the production instantiation (not its leftover launch <..., true, true>)
+KERNEL = "k_horizon<2, false, true, false, false, false>"      # the production instantiation
+LEFT = "k_horizon<2, false, true, false, false, true>"         # its follow-up launch (the cells handed over), fast stack
 
 
 def per_kernel(d, names):
@@ -40,16 +42,22 @@ for name, d in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
     out[name] = {k[0]: {"dispatches": len(v), "mean_KiB": sum(v) / len(v)} for k, v in agg.items() if "hz::" in k[0]}
 json.dump(out, open("profiles/%s/pmc_fetch_write_summary.json" % rnd, "w"), indent=1)
 k = [x for x in out["FETCH_SIZE"] if KERNEL in x][0]
+kl = [x for x in out["FETCH_SIZE"] if LEFT in x]
 f, w = out["FETCH_SIZE"][k]["mean_KiB"], out["WRITE_SIZE"][k]["mean_KiB"]
+f_prod, w_prod = f, w
+if kl:      # one follow-up launch per production launch
+    f += out["FETCH_SIZE"][kl[0]]["mean_KiB"]; w += out["WRITE_SIZE"][kl[0]]["mean_KiB"]
 cal_r = out["FETCH_SIZE"]["hz::k_bounds"]["mean_KiB"] * 1024 / (12 * 3601 * 3601)
 cal_w = out["WRITE_SIZE"]["hz::k_morton"]["mean_KiB"] * 1024 / (8 * 3600 * 3600)     # key + primitive id per quad
 b = json.loads(open("gpurun_out/%s_kt_bench.json" % pre).read().strip().splitlines()[-1])
-t = {"tile": 3601, "azim": 360, "rows_per_step": b["config"]["rows_per_step"], "kernel_source_sha": sha,
+t = {"tile": 3601, "azim": 360, "rows_per_step": b["config"]["rows_per_step"], "kernel_asm_sha": sha,
      "device": b["config"].get("device"), "rocm": b["config"].get("rocm"),
      "hbm_bytes_per_launch": 2 * f * 1024 + w * 1024, "fetch_bytes": 2 * f * 1024, "write_bytes": w * 1024,
+     "production_launch": {"fetch_bytes": 2 * f_prod * 1024, "write_bytes": w_prod * 1024},
+     "follow_up_launch": {"fetch_bytes": 2 * (f - f_prod) * 1024, "write_bytes": (w - w_prod) * 1024},
      "note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes (profiles/%s/pmc_fetch_write_summary.json), mean "
              "over the launches of 2 steps; KiB units; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2); calibration "
-             "on this run: k_bounds read ratio %.3f, k_morton write ratio %.3f; kernel %s" % (rnd, cal_r, cal_w, k)}
+             "on this run: k_bounds read ratio %.3f, k_morton write ratio %.3f; kernel %s + its follow-up launch" % (rnd, cal_r, cal_w, k)}
 json.dump(t, open("profiles/traffic.json", "w"), indent=1)
 print(json.dumps(t))
 # ---- VALU model: scale the per-iteration constants so that they reproduce SQ_INSTS_VALU ------------------------
@@ -58,22 +66,32 @@ sq = per_kernel("sq", ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_THREAD_CYCLES
 kk = [x for x in sq if KERNEL in x[0]]
 if kk:
     m = {c: sum(v) / len(v) for (kn, c), v in sq.items() if KERNEL in kn}
+    m_left = {c: sum(v) / len(v) for (kn, c), v in sq.items() if LEFT in kn}
+    m_prod = dict(m)
+    for c, v in m_left.items():
+        m[c] = m.get(c, 0.0) + v
     bs = json.loads(open("gpurun_out/%s_sq_bench.json" % pre).read().strip().splitlines()[-1])
     model_winst = bs["roofline"].get("valu_winst_per_launch")
     d = bs["roofline"].get("valu_model_constants") or dict(bench.VALU_MODEL_DEFAULT)   # the constants that run used
     fac = m["SQ_INSTS_VALU"] / model_winst if model_winst else None
-    vm = {"kernel_source_sha": sha, "device": bs["config"].get("device"), "rocm": bs["config"].get("rocm"),
-          "sq_counters_per_launch": m, "model_winst_before": model_winst,
+    vm = {"kernel_asm_sha": sha, "device": bs["config"].get("device"), "rocm": bs["config"].get("rocm"),
+          "sq_counters_per_launch": m, "sq_counters_production_launch": m_prod, "sq_counters_follow_up_launch": m_left,
+          "lane_utilisation_valu_production_launch": m_prod["SQ_THREAD_CYCLES_VALU"] / (64.0 * m_prod["SQ_INSTS_VALU"]) if m_prod.get("SQ_INSTS_VALU") else None,
+          "lane_utilisation_valu_follow_up_launch": m_left["SQ_THREAD_CYCLES_VALU"] / (64.0 * m_left["SQ_INSTS_VALU"]) if m_left.get("SQ_INSTS_VALU") else None,
+          "model_winst_before": model_winst,
           "scale": fac, "lane_utilisation_valu": m["SQ_THREAD_CYCLES_VALU"] / (64.0 * m["SQ_INSTS_VALU"]) if m.get("SQ_INSTS_VALU") else None,
           "note": "per-iteration constants of that bench run scaled by SQ_INSTS_VALU / (its model) on the launches of 2 bench steps "
                   "(the counter pass of the same run supplies the wave-iteration counts)"}
     # engine cycles of the launch (own PMC pass) -> the clock the kernel ran at and the share of issue slots it used
     gr = per_kernel("grbm", ("GRBM_GUI_ACTIVE",))
     gk = [v for (kn, c), v in gr.items() if KERNEL in kn]
+    gl = [v for (kn, c), v in gr.items() if LEFT in kn]
     if gk:
         cyc = sum(gk[0]) / len(gk[0]) / 8.0          # rocprofv3 sums the counter over the 8 XCDs
-        kt = [r for r in csv.DictReader(open("profiles/%s/bench_kernel_stats.csv" % rnd)) if KERNEL in r["Name"]][0]
-        dur = float(kt["AverageNs"]) * 1e-9
+        if gl:
+            cyc += sum(gl[0]) / len(gl[0]) / 8.0
+        rows = list(csv.DictReader(open("profiles/%s/bench_kernel_stats.csv" % rnd)))
+        dur = sum(float(r["AverageNs"]) for r in rows if KERNEL in r["Name"] or LEFT in r["Name"]) * 1e-9
         simds = bs["roofline"].get("simds") or 1024
         vm.update({"grbm_gui_active_cycles_per_launch": cyc, "engine_clock_ghz_during_kernel": cyc / dur / 1e9,
                    "valu_issue_slots_used": 4.0 * m["SQ_INSTS_VALU"] / (simds * cyc)})
@@ -120,3 +138,35 @@ try:
     print(json.dumps(out4))
 except (ValueError, OSError, KeyError) as e:
     print("no config-4 counters:", e)
+
+
+# ---- wait / busy split of the wave cycles: two PMC passes over one bench step and over config 4 ---------------
+try:
+    res = {"command": "bench.py --steps 1 --warmup 1 (c3) / --workload c4 --steps 1; rocprofv3 --pmc in two passes each; sums over the dispatches of "
+                      "each kernel and all XCDs", "kernels": {}}
+    for d in ("wb1", "wb2", "c4wb1", "c4wb2"):
+        try:
+            f = newest("gpurun_out/%s_%s/*/*counter_collection.csv" % (pre, d))
+        except ValueError:
+            continue
+        for r in csv.DictReader(open(f)):
+            kn = r["Kernel_Name"].split("(")[0]
+            if "hz::" in kn:
+                res["kernels"].setdefault(kn, {}).setdefault(r["Counter_Name"], 0.0)
+                res["kernels"][kn][r["Counter_Name"]] += float(r["Counter_Value"])
+    for kn, c in res["kernels"].items():
+        wc = c.get("SQ_WAVE_CYCLES")
+        if wc:
+            c["frac_wave_cycles"] = {"wait_any(parked: s_waitcnt)": round(c.get("SQ_WAIT_ANY", 0) / wc, 3),
+                                     "wait_inst_any(issue stall)": round(c.get("SQ_WAIT_INST_ANY", 0) / wc, 3),
+                                     "active_inst_any": round(c.get("SQ_ACTIVE_INST_ANY", 0) / wc, 3),
+                                     "active_inst_valu": round(c.get("SQ_ACTIVE_INST_VALU", 0) / wc, 3),
+                                     "active_inst_sca": round(c.get("SQ_ACTIVE_INST_SCA", 0) / wc, 3),
+                                     "active_inst_lds": round(c.get("SQ_ACTIVE_INST_LDS", 0) / wc, 3)}
+    if res["kernels"]:
+        json.dump(res, open("profiles/%s/pmc_sq_wait_busy.json" % rnd, "w"), indent=1)
+        for kn in res["kernels"]:
+            if "frac_wave_cycles" in res["kernels"][kn] and ("k_horizon" in kn or "k_shadow" in kn or "k_near" in kn or "k_topo" in kn):
+                print(kn[:70], res["kernels"][kn]["frac_wave_cycles"])
+except Exception as e:
+    print("no wait / busy passes:", e)

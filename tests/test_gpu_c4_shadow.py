@@ -87,17 +87,15 @@ def test_c4_full_tile_144_sun_positions(hip, orc, refrac):
                       "sw_dir_cor_kernel_s": st_sw["t_kernel_s"], "cells_checked_vs_oracle": checked}))
 
 
-def test_overflowed_shadow_rays_are_traced_again_with_the_level_stack():
+def test_overflowed_shadow_rays_are_traced_again_with_the_level_stack(hip, orc):
     """Round 4: the shadow kernel runs the fast stack (19 entries); a ray that runs out of entries is traced again with the
-    one-entry-per-level discipline in its lane's own LDS column.  With 6 entries that retry is the common case: the shadow /
-    sw_dir_cor parity tests must stay bit-identical (the variable is read once per process, hence the subprocess)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, HZ_SHADOW_FAST_CAP="6")
-    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider",
-                        os.path.join(root, "tests", "test_gpu_parity.py"), "-k", "shadow_and_sw_dir_cor"],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=900)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
+    one-entry-per-level discipline in its lane's own LDS column.  With 6 entries (hz_debug_set("shadow_fast_cap", 6)) that
+    retry is the common case: the shadow / sw_dir_cor parity tests must stay bit-identical."""
+    from horayzon_amd import _lib
+    from tests import test_gpu_parity
+    _lib.check(_lib.lib().hz_debug_set(b"shadow_fast_cap", 6))
+    try:
+        for refrac in (False, True):
+            test_gpu_parity.test_shadow_and_sw_dir_cor(hip, orc, refrac)
+    finally:
+        _lib.check(_lib.lib().hz_debug_set(b"shadow_fast_cap", -1))

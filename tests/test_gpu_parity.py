@@ -382,16 +382,20 @@ def test_traversal_stack_is_one_entry_per_level(hip, orc):
     # entries that fit; a wave that runs out is detected and that launch repeated with the level stack.  Forced here
     # with tiny fast stacks; `_level_stack=True` uses the level stack from the start.
     # A few overflowing tiles are repeated one by one (`stack_redo_blocks`), many repeat the whole launch.
-    seen, redo = set(), {}
+    seen, redo, redo_left = set(), {}, {}
     for cap in (0, -3, -4, -7, -9, -10, -11, -12, -13, -14, -30, 1):
         h2, _ = hip.horizon.horizon_gridded(**kw, **par, _level_stack=cap)
         st = dict(hip.horizon.last_stats)
         assert np.array_equal(h2, ref) and st["num_rays"] == so["rays"] and st["num_cells"] == ref.shape[0] * ref.shape[1], cap
         seen.add((cap, st["stack_fallbacks"]))
         redo[cap] = st["stack_redo_blocks"]
+        redo_left[cap] = st["left_redo_groups"]
     assert (0, 0) in seen and (-3, 1) in seen and (-30, 0) in seen and (1, 0) in seen
     assert redo[-3] == 0 and redo[0] == 0                   # all tiles overflow with 3 entries: one full repeat
     assert any(0 < v <= 85 for v in redo.values()), redo    # ... and some cap leaves only a few of the 342 blocks
+    # (round 6: the follow-up launch of the handed-over cells runs the fast stack too; a group of 64 that overflows is repeated)
+    if st["left_cells"] > 0:
+        assert any(v > 0 for v in redo_left.values()), redo_left
     # ... and a scene remembers: after one overflow its launches go straight to the level stack
     hip.horizon.horizon_gridded(**kw, **par, scene=sc, _level_stack=-3)
     assert hip.horizon.last_stats["stack_fallbacks"] == 1

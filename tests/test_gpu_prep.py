@@ -38,13 +38,14 @@ def test_topo_kernels_agree_with_each_other(hip):
         a = (T.sky_view_factor(d["azim_" + n], d["hori_" + n], d["tilt_" + n]),
              T.visible_sky_fraction(d["azim_" + n], d["hori_" + n], d["tilt_" + n]),
              T.topographic_openness(d["azim_" + n], d["hori_" + n]))
-        os.environ["HZ_TOPO_WIDE"] = "1"
+        from horayzon_amd import _lib
+        _lib.check(_lib.lib().hz_debug_set(b"topo_wide", 1))
         try:
             b = (T.sky_view_factor(d["azim_" + n], d["hori_" + n], d["tilt_" + n]),
                  T.visible_sky_fraction(d["azim_" + n], d["hori_" + n], d["tilt_" + n]),
                  T.topographic_openness(d["azim_" + n], d["hori_" + n]))
         finally:
-            del os.environ["HZ_TOPO_WIDE"]
+            _lib.check(_lib.lib().hz_debug_set(b"topo_wide", 0))
         for x, y, key in zip(a, b, ("svf_", "vsf_", "top_")):
             assert np.abs(x - y).max() <= 2.0e-6, key
             assert np.abs(y - d[key + n]).max() <= 1.0e-5, key
