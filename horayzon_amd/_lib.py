@@ -29,7 +29,7 @@ class hz_opts(C.Structure):
                 ("level_stack", C.c_int32), ("hori_is_slab", C.c_int32),
                 ("no_near_skip", C.c_int32), ("verify_near", C.c_int32),
                 ("inputs_are_slab", C.c_int32), ("no_host_pin", C.c_int32),
-                ("left_min", C.c_int32), ("persist_grid", C.c_int32), ("left_cap_test", C.c_int32)]
+                ("left_min", C.c_int32), ("persist_grid", C.c_int32), ("left_cap_test", C.c_int32), ("left_tune", C.c_int32)]
 
 
 class hz_stats(C.Structure):

@@ -392,6 +392,157 @@ struct NearMonitor {
     }
 };
 
+// opts.verbose >= 2: why cells got no certificate (device histogram of hz_near.hip), to stderr
+static void print_near_reasons(const unsigned *near_reasons) {
+    unsigned h[20] = {0};
+    if (hipMemcpy(h, near_reasons, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { (void)hipGetLastError(); return; }
+    static const char *nm[14] = {"frame", "vertex_on_axis", "edge_over_axis", "az_tolerance", "inplane_edge", "crossing_near_axis",
+                                 "interval", "precision", "edge_on", "orientation", "origin_below", "axis_in_triangle", "window_or_mask",
+                                 "bad_mesh_nearby"};
+    fprintf(stderr, "hz near reasons: cells %u certified %u", h[0], h[1]);
+    for (int b = 0; b < 14; b++) if (h[2 + b]) fprintf(stderr, " %s %u", nm[b], h[2 + b]);
+    fprintf(stderr, " | tasks %u bins %u\n", h[16], h[17]);
+}
+
+// opts.verbose: the reference's report, horizon_comp.cpp:673-700, 805-810 (same lines, same order)
+static void print_reference_report(const Scene *sc, int alg, unsigned long long cells, unsigned long long rays, size_t slab_cells,
+                                   int dim_in_0, int dim_in_1, int azim_num, double kernel_s, bool certificates_off, bool certificates_per_cell) {
+    static const char *alg_name[3] = {"discrete_sampling", "binary search", "guess horizon from previous azimuth direction"};
+    printf("Horizon detection algorithm: %s\n", alg_name[alg]);
+    printf("Number of grid cells for which horizon is computed: %llu \n", cells);
+    printf("Fraction of total number of grid cells: %g %%\n", (double)((float)cells / (float)slab_cells * 100.0f));
+    printf("Total memory required for horizon output: %g GB\n",
+           (double)(((float)dim_in_0 * (float)dim_in_1 * (float)azim_num * 4.0f) / 1.0e9f));
+    printf("Ray tracing time: %g s\n", kernel_s);
+    printf("Number of rays shot: %llu\n", rays);
+    printf("Average number of rays per location and azimuth: %.2f \n",
+           cells ? (double)((float)rays / (float)(cells * (unsigned long long)azim_num)) : 0.0);
+    // (not a line of the reference: why this call ran without the near-field certificates, if it did)
+    if (certificates_off)
+        printf("Near-field certificates off: a DEM quad that is not part of a height field over the (x, y) plane, or a triangle "
+               "of the outer simplified domain, is too large for the per-cell guard (results unaffected, slower)\n");
+    else if (certificates_per_cell)
+        printf("Near-field certificates per cell: %u DEM triangle(s) project onto the (x, y) plane collapsed or against the "
+               "majority, %d outer-domain triangle(s); cells near them run without (results unaffected)\n", sc->hdr.n_flipped, sc->hdr.n_tin);
+    fflush(stdout);
+}
+
+// Rows per launch and the device buffer of one chunk of horizon, when `hori` is host memory or skipped (SVF only).
+// Every launch ends with a tail (the last waves run on a draining GPU; a lane owns its cell for all azimuths), so launches
+// should be few: at least 16 GiB of horizon per launch when it is only the SVF's input (nothing is copied out; less if HBM is
+// short), at least 4 GiB when chunks are copied to the host behind the next chunk's kernel.
+static int alloc_hori_chunk(int rows_all, size_t row_bytes, bool skip_hori, int fixed_rows, int *chunk_rows_out, void **buf) {
+    size_t target = skip_hori ? ((size_t)16 << 30) : ((size_t)4 << 30);
+    {   // host path with plenty of free HBM: equal chunks of <= 8 GiB (the 3601^2 tile: 3 instead of 5 launches, 2.57 ->
+        // 2.49 s).  (64 GiB chunks for the SVF-only path were measured on config 5: 5 instead of 18 launches save
+        // 0.7 s of kernel tails and cost 2 s of hipMalloc / hipFree of the 62 + 33 GB buffers -- kept at 16 GiB.)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            if (!skip_hori) {
+                const size_t all = (size_t)rows_all * row_bytes;
+                const size_t parts = std::max<size_t>(1, (all + ((size_t)8 << 30) - 1) / ((size_t)8 << 30));
+                if (free_b / 6 >= all / parts + row_bytes) target = std::max(target, all / parts + row_bytes);
+            }
+        } else (void)hipGetLastError();
+    }
+    const bool fixed = fixed_rows > 0;
+    for (;;) {
+        int chunk_rows = rows_all;
+        if (fixed) chunk_rows = std::min(chunk_rows, fixed_rows);
+        else {
+            chunk_rows = (int)std::max<size_t>(16, std::min<size_t>((size_t)chunk_rows, target / row_bytes));
+            // equal chunks (whole 16-row tile rows) instead of full ones and a small rest: a slab of 1800 rows is
+            // 3 x 608 rows, not 830 + 830 + 140 -- every launch ends with a tail, and a short launch is mostly tail
+            const int n_ch = (rows_all + chunk_rows - 1) / chunk_rows;
+            chunk_rows = std::min(chunk_rows, std::max(16, ((rows_all + n_ch - 1) / n_ch + 15) / 16 * 16));
+        }
+        chunk_rows = std::min(chunk_rows, rows_all);
+        *chunk_rows_out = chunk_rows;
+        if (hipMalloc(buf, (size_t)chunk_rows * row_bytes) == hipSuccess) return HZ_OK;
+        (void)hipGetLastError();
+        *buf = nullptr;
+        if (fixed || target <= ((size_t)1 << 30)) return set_error(HZ_ERR_HIP, "hipMalloc of the horizon chunk (%zu bytes) failed", (size_t)chunk_rows * row_bytes);
+        target >>= 1;
+    }
+}
+
+// Near-field certificates of the rows [na.row_begin, na.row_end) (hz_near.hip) into the scratch kept with the scene (grown on
+// demand: (2 A + 4) B per cell); fills na.near_idx / near_r, adds the pre-pass's GPU time to *ms_near.
+static int near_prepass(const Scene *sc, NearArgs &na, hipStream_t st, float *ms_near) {
+    const size_t cells = (size_t)(na.row_end - na.row_begin) * na.dim_in_1;
+    const size_t idx_bytes = (cells * (size_t)na.azim_num * 2 + 255) & ~(size_t)255;
+    const size_t need = idx_bytes + cells * 4;
+    if (sc->near_bytes < need) {
+        if (sc->near_buf) (void)hipFree(sc->near_buf);
+        sc->near_buf = nullptr; sc->near_bytes = 0;
+        if (hipMalloc(&sc->near_buf, need) != hipSuccess) return set_error(HZ_ERR_HIP, "hipMalloc of the near-field certificates failed");
+        sc->near_bytes = need;
+    }
+    na.near_idx = (unsigned short *)sc->near_buf;
+    na.near_r = (float *)((char *)sc->near_buf + idx_bytes);
+    hipEvent_t n0 = nullptr, n1 = nullptr;
+    if (hipEventCreate(&n0) != hipSuccess || hipEventCreate(&n1) != hipSuccess) {
+        if (n0) (void)hipEventDestroy(n0);
+        return set_error(HZ_ERR_HIP, "hipEventCreate failed");
+    }
+    (void)hipEventRecord(n0, st);
+    const int rc = near_launch(sc, na, st);
+    (void)hipEventRecord(n1, st);
+    if (!rc) {
+        (void)hipEventSynchronize(n1);
+        float mn = 0.0f;
+        (void)hipEventElapsedTime(&mn, n0, n1);
+        *ms_near += mn;
+    }
+    (void)hipEventDestroy(n0); (void)hipEventDestroy(n1);
+    return rc;
+}
+
+// Leftover cells (hz_horizon.hip): a block of a production launch ends when at most t[0] (default 36; opts.left_min) of its cells are
+// unfinished -- a lane whose cell is done idles until its block's slowest cell is (12 % of the lane time, profiles/r05/
+// probe_done_lanes.log) -- and follow-up launches finish the cells handed over, 64 per wave, sorted by the azimuths they have left
+// and by position (left_sort); a wave of follow-up launch l may hand over again at t[l], the last one runs to the end.  How many
+// records a level got is only known on the device: keys, sort and follow-up launches are sized by the region's capacity and read
+// the counts there, the host never waits between them.  One 64 B record per hand-over; region l is sized from what the level
+// above can hand over at most; a region that still runs out of room stops the hand-over (hz_horizon.hip).  Kept with the scene.
+// Fills left_t[] (thresholds per level) and a.left_base / left_cap / left_sort / left_cap_max, grows the scene's buffer; returns the
+// number of follow-up launches (0: no hand-over -- switched off, a counting call, or no memory: the blocks run to their end).
+static int plan_leftover(const Scene *sc, const hz_opts *opts, int rows_max, int dim_in_1, int left_t[HZ_LEFT_LEVELS], HorizonArgs &a) {
+    int n_left_launches = 0;
+    for (int l = 0; l < HZ_LEFT_LEVELS; l++) left_t[l] = 0;
+    const int pack = opts ? opts->left_min : 0;
+    const unsigned upack = pack == 0 ? HZ_LEFT_DEFAULT : (pack < 0 ? 0u : (unsigned)pack);
+    for (int l = 0; l < HZ_LEFT_LEVELS; l++) {
+        left_t[l] = (int)std::min((upack >> (8 * l)) & 0xffu, 56u);
+        if (left_t[l] == 0) break;      // (a level that does not hand over is the last one)
+        n_left_launches = l + 1;
+    }
+    if ((opts && opts->count_work) || n_left_launches == 0) return 0;
+    const TileMap tm = make_tile_map((rows_max + 15) / 16, (dim_in_1 + 15) / 16);
+    unsigned long long units = (unsigned long long)tm.per_xcd * 8ull * 4ull;      // 8 x 8 blocks, then groups of 64 records
+    unsigned long long total = 0, cap_max = 0;
+    for (int l = 0; l < n_left_launches; l++) {
+        unsigned long long cap = ((units * (unsigned long long)left_t[l] + 63ull) & ~63ull) + 64ull;
+        if (opts && opts->left_cap_test > 0) cap = std::min<unsigned long long>(cap, ((unsigned long long)opts->left_cap_test + 63ull) & ~63ull);
+        a.left_base[l] = (unsigned)total; a.left_cap[l] = (unsigned)cap;
+        total += cap; cap_max = std::max(cap_max, cap);
+        units = cap / 64ull;
+    }
+    const size_t rec_bytes = (size_t)total * HZ_LEFT_WORDS * sizeof(unsigned);
+    const size_t sort_words = 4 * (size_t)cap_max + sort_temp_elems((size_t)cap_max) + 64;
+    const size_t need = rec_bytes + sort_words * sizeof(uint32_t);
+    // (record numbers and launch-local cell numbers are 32 bit)
+    if (total >= (1ull << 31) || (unsigned long long)rows_max * (unsigned long long)dim_in_1 >= 0xffffffffull) return 0;
+    if (sc->left_bytes < need) {
+        if (sc->left_buf) (void)hipFree(sc->left_buf);
+        sc->left_buf = nullptr; sc->left_bytes = 0;
+        if (hipMalloc(&sc->left_buf, need) != hipSuccess) { (void)hipGetLastError(); sc->left_buf = nullptr; return 0; }
+        sc->left_bytes = need;
+    }
+    a.left_sort = (uint32_t *)((char *)sc->left_buf + rec_bytes); a.left_cap_max = (unsigned)cap_max;
+    return n_left_launches;
+}
+
 static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_north, int offset_0,
                        int offset_1, float *hori_buffer, int dim_in_0, int dim_in_1, int azim_num,
                        float dist_search, float hori_acc, const char *ray_algorithm,
@@ -482,41 +633,8 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
     const bool stream_out = !skip_hori && !is_device_ptr(hori_slab_host);
     if (skip_hori || stream_out) {
         if (skip_hori && !want_svf) return set_error(HZ_ERR_ARG, "skip_hori without svf: nothing to compute");
-        // Every launch ends with a tail (the last workgroups run on a draining GPU; a lane owns its cell for all
-        // azimuths), so launches should be few: at least 16 GiB of horizon per launch when it is only the SVF's input (nothing
-        // is copied out; less if HBM is short), at least 4 GiB when chunks are copied to the host behind the next chunk's kernel.
-        size_t target = skip_hori ? ((size_t)16 << 30) : ((size_t)4 << 30);
-        {   // host path with plenty of free HBM: equal chunks of <= 8 GiB (the 3601^2 tile: 3 instead of 5 launches, 2.57 ->
-            // 2.49 s).  (64 GiB chunks for the SVF-only path were measured on config 5: 5 instead of 18 launches save
-            // 0.7 s of kernel tails and cost 2 s of hipMalloc / hipFree of the 62 + 33 GB buffers -- kept at 16 GiB.)
-            size_t free_b = 0, total_b = 0;
-            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
-                if (!skip_hori) {
-                    const size_t all = (size_t)(row_end - row_begin) * row_bytes;
-                    const size_t parts = std::max<size_t>(1, (all + ((size_t)8 << 30) - 1) / ((size_t)8 << 30));
-                    if (free_b / 6 >= all / parts + row_bytes) target = std::max(target, all / parts + row_bytes);
-                }
-            } else (void)hipGetLastError();
-        }
-        const bool fixed = opts && opts->chunk_rows > 0;
-        for (;;) {
-            chunk_rows = row_end - row_begin;
-            if (fixed) chunk_rows = std::min(chunk_rows, opts->chunk_rows);
-            else {
-                chunk_rows = (int)std::max<size_t>(16, std::min<size_t>((size_t)chunk_rows, target / row_bytes));
-                // equal chunks (whole 16-row tile rows) instead of full ones and a small rest: a slab of 1800 rows is
-                // 3 x 608 rows, not 830 + 830 + 140 -- every launch ends with a tail, and a short launch is mostly tail
-                const int rows_all = row_end - row_begin;
-                const int n_ch = (rows_all + chunk_rows - 1) / chunk_rows;
-                chunk_rows = std::min(chunk_rows, std::max(16, ((rows_all + n_ch - 1) / n_ch + 15) / 16 * 16));
-            }
-            chunk_rows = std::min(chunk_rows, row_end - row_begin);
-            if (hipMalloc(&tmp_hori, (size_t)chunk_rows * row_bytes) == hipSuccess) break;
-            (void)hipGetLastError();
-            tmp_hori = nullptr;
-            if (fixed || target <= ((size_t)1 << 30)) return set_error(HZ_ERR_HIP, "hipMalloc of the horizon chunk (%zu bytes) failed", (size_t)chunk_rows * row_bytes);
-            target >>= 1;
-        }
+        if ((rc = alloc_hori_chunk(row_end - row_begin, row_bytes, skip_hori, (opts && opts->chunk_rows > 0) ? opts->chunk_rows : 0, &chunk_rows, &tmp_hori)))
+            return rc;
         tmp_bytes = (size_t)chunk_rows * row_bytes;
         if (stream_out && chunk_rows < row_end - row_begin) { HZ_HIP(hipMalloc(&tmp_hori2, (size_t)chunk_rows * row_bytes)); tmp_bytes *= 2; }
     } else {
@@ -601,52 +719,12 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
             sc->near_bytes = need;
         }
     }
-    // Leftover cells (hz_horizon.hip): a block of a production launch ends when at most t[0] (default 16; opts.left_min) of its cells are
-    // unfinished -- a lane whose cell is done idles until its block's slowest cell is (12 % of the lane time, profiles/r05/
-    // probe_done_lanes.log) -- and follow-up launches finish the cells handed over, 64 per wave, sorted by the azimuths they have left
-    // and by position (left_sort); a wave of follow-up launch l may hand over again at t[l], the last one runs to the end.  How many
-    // records a level got is only known on the device: keys, sort and follow-up launches are sized by the region's capacity and read
-    // the counts there, the host never waits between them.  One 64 B record per hand-over; region l is sized from what the level
-    // above can hand over at most; a region that still runs out of room stops the hand-over (hz_horizon.hip).  Kept with the scene.
-    int left_t[HZ_LEFT_LEVELS] = {0, 0, 0, 0};
-    int n_left_launches = 0;
-    {
-        const int pack = opts ? opts->left_min : 0;
-        const unsigned upack = pack == 0 ? HZ_LEFT_DEFAULT : (pack < 0 ? 0u : (unsigned)pack);
-        for (int l = 0; l < HZ_LEFT_LEVELS; l++) {
-            left_t[l] = (int)std::min((upack >> (8 * l)) & 0xffu, 56u);
-            if (left_t[l] == 0) break;      // (a level that does not hand over is the last one)
-            n_left_launches = l + 1;
-        }
-        if (opts && opts->count_work) n_left_launches = 0;
-    }
-    if (n_left_launches > 0) {
-        const int rows_max = std::min(chunk_rows, row_end - row_begin);
-        const TileMap tm = make_tile_map((rows_max + 15) / 16, (dim_in_1 + 15) / 16);
-        unsigned long long units = (unsigned long long)tm.per_xcd * 8ull * 4ull;      // 8 x 8 blocks, then groups of 64 records
-        unsigned long long total = 0, cap_max = 0;
-        for (int l = 0; l < n_left_launches; l++) {
-            unsigned long long cap = ((units * (unsigned long long)left_t[l] + 63ull) & ~63ull) + 64ull;
-            if (opts && opts->left_cap_test > 0) cap = std::min<unsigned long long>(cap, ((unsigned long long)opts->left_cap_test + 63ull) & ~63ull);
-            a.left_base[l] = (unsigned)total; a.left_cap[l] = (unsigned)cap;
-            total += cap; cap_max = std::max(cap_max, cap);
-            units = cap / 64ull;
-        }
-        const size_t rec_bytes = (size_t)total * HZ_LEFT_WORDS * sizeof(unsigned);
-        const size_t sort_words = 4 * (size_t)cap_max + sort_temp_elems((size_t)cap_max) + 64;
-        const size_t need = rec_bytes + sort_words * sizeof(uint32_t);
-        const bool fits = total < (1ull << 31) && (unsigned long long)rows_max * (unsigned long long)dim_in_1 < 0xffffffffull;
-        if (fits && sc->left_bytes < need) {
-            if (sc->left_buf) (void)hipFree(sc->left_buf);
-            sc->left_buf = nullptr; sc->left_bytes = 0;
-            if (hipMalloc(&sc->left_buf, need) != hipSuccess) { (void)hipGetLastError(); sc->left_buf = nullptr; }     // (no room: the blocks run to their end)
-            else sc->left_bytes = need;
-        }
-        if (!fits || !sc->left_buf) n_left_launches = 0;
-        else { a.left_sort = (uint32_t *)((char *)sc->left_buf + rec_bytes); a.left_cap_max = (unsigned)cap_max; }
-    }
+    int left_t[HZ_LEFT_LEVELS];
+    const int n_left_launches = plan_leftover(sc, opts, std::min(chunk_rows, row_end - row_begin), dim_in_1, left_t, a);
     a.left_min = n_left_launches > 0 ? left_t[0] : 0;
     a.left_rec = n_left_launches > 0 ? (unsigned *)sc->left_buf : nullptr;
+    a.left_regroup = (opts && (opts->left_tune & 0xff) > 0) ? (opts->left_tune & 0xff) : HZ_LEFT_REGROUP;
+    a.left_key_shift = (opts && ((opts->left_tune >> 8) & 0xff) > 0) ? std::min(((opts->left_tune >> 8) & 0xff) - 1, 8) : HZ_LEFT_KEY_SHIFT;
     a.persist_grid = (opts && opts->persist_grid > 0) ? opts->persist_grid : 0;
     a.no_persist = (opts && opts->persist_grid < 0) ? 1 : 0;
     // opts.verbose >= 2: histogram of why cells got no certificate, printed to stderr at the end of the call
@@ -700,36 +778,15 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         a.hori = hori_chunk - (size_t)rb * dim_in_1 * azim_num;
         a.row_begin = rb; a.row_end = re;
         if (use_near) {
-            const size_t cells = (size_t)(re - rb) * dim_in_1;
-            const size_t idx_bytes = (cells * (size_t)azim_num * 2 + 255) & ~(size_t)255;
-            const size_t need = idx_bytes + cells * 4;
-            if (sc->near_bytes < need) {
-                if (sc->near_buf) (void)hipFree(sc->near_buf);
-                sc->near_buf = nullptr; sc->near_bytes = 0;
-                if (hipMalloc(&sc->near_buf, need) != hipSuccess) return fail(set_error(HZ_ERR_HIP, "hipMalloc of the near-field certificates failed"));
-                sc->near_bytes = need;
-            }
             NearArgs na;
             na.vec_norm = norm0; na.vec_north = north0; na.mask = mask0;
             na.azim_sin = d_as.dev; na.azim_cos = d_ac.dev;
             na.offset_0 = offset_0; na.offset_1 = offset_1; na.dim_in_1 = dim_in_1; na.row_begin = rb; na.row_end = re;
             na.azim_num = azim_num; na.elev_num = tb.elev_num;
             na.ray_org_elev = ray_org_elev; na.hori_acc = tb.hori_acc; na.low = tb.low; na.up = tb.up;
-            na.near_idx = (unsigned short *)sc->near_buf;
-            na.near_r = (float *)((char *)sc->near_buf + idx_bytes);
             na.reasons = near_reasons;
             na.ignore_bad_map = near_opt < 0 ? 1 : 0;
-            hipEvent_t n0 = nullptr, n1 = nullptr;
-            if (hipEventCreate(&n0) != hipSuccess || hipEventCreate(&n1) != hipSuccess) return fail(set_error(HZ_ERR_HIP, "hipEventCreate failed"));
-            (void)hipEventRecord(n0, st);
-            rc = near_launch(sc, na, st);
-            (void)hipEventRecord(n1, st);
-            if (rc) { (void)hipEventDestroy(n0); (void)hipEventDestroy(n1); return fail(rc); }
-            (void)hipEventSynchronize(n1);
-            float mn = 0.0f;
-            (void)hipEventElapsedTime(&mn, n0, n1);
-            ms_near += mn;
-            (void)hipEventDestroy(n0); (void)hipEventDestroy(n1);
+            if ((rc = near_prepass(sc, na, st, &ms_near))) return fail(rc);
             a.near_idx = na.near_idx; a.near_r = na.near_r;
         }
         {
@@ -870,37 +927,10 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
         stats->scratch_bytes = (uint64_t)((use_near ? sc->near_bytes : 0) + (n_left_launches > 0 ? sc->left_bytes : 0) + tmp_bytes);
         stats->height_field = height_field ? 1 : 0; stats->near_used = use_near ? 1 : 0;
     }
-    if (near_reasons) {
-        unsigned h[20] = {0};
-        if (hipMemcpy(h, near_reasons, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess) {
-            static const char *nm[14] = {"frame", "vertex_on_axis", "edge_over_axis", "az_tolerance", "inplane_edge", "crossing_near_axis",
-                                         "interval", "precision", "edge_on", "orientation", "origin_below", "axis_in_triangle", "window_or_mask",
-                                         "bad_mesh_nearby"};
-            fprintf(stderr, "hz near reasons: cells %u certified %u", h[0], h[1]);
-            for (int b = 0; b < 14; b++) if (h[2 + b]) fprintf(stderr, " %s %u", nm[b], h[2 + b]);
-            fprintf(stderr, " | tasks %u bins %u\n", h[16], h[17]);
-        }
-    }
-    if (opts && opts->verbose) {   // the reference's report, horizon_comp.cpp:673-700, 805-810 (same lines, same order)
-        static const char *alg_name[3] = {"discrete_sampling", "binary search", "guess horizon from previous azimuth direction"};
-        printf("Horizon detection algorithm: %s\n", alg_name[alg]);
-        printf("Number of grid cells for which horizon is computed: %llu \n", cnt[4]);
-        printf("Fraction of total number of grid cells: %g %%\n", (double)((float)cnt[4] / (float)slab_cells * 100.0f));
-        printf("Total memory required for horizon output: %g GB\n",
-               (double)(((float)dim_in_0 * (float)dim_in_1 * (float)azim_num * 4.0f) / 1.0e9f));
-        printf("Ray tracing time: %g s\n", (double)ms * 1e-3);
-        printf("Number of rays shot: %llu\n", cnt[0]);
-        printf("Average number of rays per location and azimuth: %.2f \n",
-               cnt[4] ? (double)((float)cnt[0] / (float)(cnt[4] * (unsigned long long)azim_num)) : 0.0);
-        // (not a line of the reference: why this call ran without the near-field certificates, if it did)
-        if (!use_near && near_opt <= 0 && !height_field && !bad_map)
-            printf("Near-field certificates off: a DEM quad that is not part of a height field over the (x, y) plane, or a triangle "
-                   "of the outer simplified domain, is too large for the per-cell guard (results unaffected, slower)\n");
-        else if (use_near && bad_map)
-            printf("Near-field certificates per cell: %u DEM triangle(s) project onto the (x, y) plane collapsed or against the "
-                   "majority, %d outer-domain triangle(s); cells near them run without (results unaffected)\n", sc->hdr.n_flipped, sc->hdr.n_tin);
-        fflush(stdout);
-    }
+    if (near_reasons) print_near_reasons(near_reasons);
+    if (opts && opts->verbose)
+        print_reference_report(sc, alg, cnt[4], cnt[0], slab_cells, dim_in_0, dim_in_1, azim_num, (double)ms * 1e-3,
+                               !use_near && near_opt <= 0 && !height_field && !bad_map, use_near && bad_map);
     return HZ_OK;
 }
 

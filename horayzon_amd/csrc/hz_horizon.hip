@@ -553,7 +553,8 @@ __device__ __forceinline__ unsigned hz_spread16(unsigned v) {
     return v;
 }
 __global__ __launch_bounds__(256) void k_left_keys(const unsigned *__restrict__ rec, unsigned cap, unsigned *__restrict__ ctl, unsigned dim_in_1,
-                                                   unsigned azim_num, int morton_shift, unsigned *__restrict__ keys, unsigned *__restrict__ vals) {
+                                                   unsigned azim_num, int morton_shift, int class_shift, unsigned *__restrict__ keys,
+                                                   unsigned *__restrict__ vals) {
     const unsigned idx = blockIdx.x * 256u + threadIdx.x;
     const unsigned cnt = min(ctl[0], cap);
     bool valid = false;
@@ -566,7 +567,7 @@ __global__ __launch_bounds__(256) void k_left_keys(const unsigned *__restrict__ 
             const unsigned r = min(azim_num > k ? azim_num - k : 0u, 511u);
             const unsigned di = c / dim_in_1, j = c - di * dim_in_1;
             const unsigned m = ((hz_spread16(di >> 4) << 1) | hz_spread16(j >> 4)) >> morton_shift;
-            key = ((511u - r) << 15) | (m & 0x7fffu);
+            key = (((511u - r) >> class_shift) << 15) | (m & 0x7fffu);
         }
     }
     if (idx < cap) { keys[idx] = key; vals[idx] = idx; }
@@ -586,7 +587,7 @@ int left_sort(const HorizonArgs &a, int r, hipStream_t st) {
     const int shift = std::max(0, 2 * bits - 15);
     uint32_t *ka = a.left_sort, *va = ka + a.left_cap_max, *kb = va + a.left_cap_max, *vb = kb + a.left_cap_max, *tmp = vb + a.left_cap_max;
     hipLaunchKernelGGL(k_left_keys, dim3((cap + 255u) / 256u), dim3(256), 0, st, a.left_rec + (size_t)a.left_base[r] * HZ_LEFT_WORDS, cap, ctl,
-                       (unsigned)a.dim_in_1, (unsigned)a.azim_num, shift, ka, va);
+                       (unsigned)a.dim_in_1, (unsigned)a.azim_num, shift, a.left_key_shift, ka, va);
     HZ_HIP(hipGetLastError());
     return radix_sort_pairs_u32(ka, va, kb, vb, cap, tmp, st, 3);
 }
@@ -675,6 +676,7 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
     // beat 40 by 1.2 %, 28 and 40 tie, 16 costs 7 %); leaf step when 24 n_leaf > 16 n_node.  opts.regroup = threshold | bias << 8.
     // (<= 0: the default -- a zeroed hz_opts must not switch the ray compaction off: 2.9 s instead of 2.15 s per tile)
     p.regroup = (a.regroup <= 0) ? 36 : std::min(a.regroup & 0xff, 64);
+    if (a.left_mode && a.left_regroup > 0) p.regroup = std::min(a.left_regroup, 64);
     p.leaf_bias = (a.regroup >= 256) ? (a.regroup >> 8) : 24;      // (20 until round 4: re-swept after the node step lost 18 instructions, profiles/r04/regroup_sweep.log)
     p.hit_cache = (a.hit_cache != 0) ? 1 : 0;
     p.near_idx = a.near_idx; p.near_r = a.near_r;
@@ -730,31 +732,35 @@ int horizon_launch(const Scene *sc, const HorizonArgs &a, hipStream_t st, int *u
 // kept).  (Round 2 read `hori` with one lane per cell straight from HBM: 4 B loads at a stride of 4 A bytes, 1.7 - 3.4 x
 // over-fetch and 31.5 ms per 3601^2 tile for an 18 GB read.)
 //
-// Trigonometry: the Cython code calls libm's float64 atan / cos / sin three times per (cell, azimuth); all arguments
-// lie in [-pi/2, pi/2].  Here ONE float64 sine / cosine pair of the horizon angle (fdlibm's kernel polynomials on the
-// halved argument + the double-angle formulas, |error| < 1e-15) gives cos^2, sin(2 h) / 2 = sin cos and -- through
-// tan(h) >= x  <=>  sin >= x cos -- the comparison with the tilted plane's own horizon atan(x) without an arctangent;
-// the arctangent (float32: the value is rounded to float32 there anyway, :443) is only evaluated where the plane limits.
-// Differences from the libm path are ~1e-7 rad in that branch and ~1e-16 elsewhere; the result is a float32 (the bar is
-// 1e-5, the reference itself is built with -ffast-math).  Each lane prefetches its share of the next block into
-// registers before it reduces the current one.
+// Trigonometry: the Cython code calls libm's float64 atan / cos / sin three times per (cell, azimuth) and adds the float64 term
+// to a FLOAT32 accumulator (topo_param.pyx:446); all arguments lie in [-pi/2, pi/2].  Here ONE sine / cosine pair of the horizon
+// angle gives cos^2, sin(2 h) / 2 = sin cos and -- through tan(h) >= x  <=>  sin >= x cos -- the comparison with the tilted plane's
+// own horizon atan(x) without an arctangent; the arctangent is only evaluated where the plane limits.
+// Round 6: the pair and the term are evaluated in FLOAT32 (fdlibm-style kernel polynomials on the halved argument + the
+// double-angle formulas, |error| < 2e-7; every multiply and add rounds separately, -ffp-contract=off).  With the float64 pair of
+// rounds 3 - 5 the kernel was bound by its float64 instructions (7.8e9 wave instructions at 4 cycles = 12.7 ms for 18.35 GB:
+// 1.6 TB/s), not by memory.  What decides the result's accuracy is the float32 accumulator both sides share (half an ulp of a sum
+// of ~100: 4e-6 per add before the division by azim_num), not the 1e-7 of a term: against the reference-made fixtures the float32
+// terms differ by <= 2.4e-7 (tests/test_gpu_prep.py; the bar is 1e-5, the reference itself is built with -ffast-math), and
+// k_topo_wide keeps libm's float64 routines per azimuth as the Cython code has them.  Each lane prefetches its share of the next
+// block into registers before it reduces the current one.
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ void hz_sincos_halfpi(double x, double &s, double &c) {
-    // sin / cos for |x| <= pi/2 (+ a little): kernel polynomials of fdlibm (k_sin.c, k_cos.c; valid on [-pi/4, pi/4])
-    // on y = x / 2, then sin x = 2 sin y cos y, cos x = 1 - 2 sin^2 y
-    const double y = 0.5 * x, z = y * y;
-#define HZ_F(a, b, c_) __builtin_fma((a), (b), (c_))
-    const double ps = HZ_F(z, HZ_F(z, HZ_F(z, HZ_F(z, HZ_F(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
-                      2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03),
-                      -1.66666666666666324348e-01);
-    const double pc = HZ_F(z, HZ_F(z, HZ_F(z, HZ_F(z, HZ_F(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
-                      -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03),
-                      4.16666666666666019037e-02);
-    const double sy = HZ_F(y * z, ps, y);
-    const double cy = HZ_F(z * z, pc, HZ_F(-0.5, z, 1.0));
-#undef HZ_F
-    s = 2.0 * sy * cy;
-    c = __builtin_fma(-2.0 * sy, sy, 1.0);
+__device__ __forceinline__ void hz_sincos_halfpi_f(float x, float &s, float &c) {
+    // sin / cos for |x| <= pi/2 (+ a little): polynomials in z = y^2 on y = x / 2 (|y| <= pi/4: truncation < 2e-9), then
+    // sin x = 2 sin y cos y, cos x = 1 - 2 sin^2 y
+    const float y = 0.5f * x, z = y * y;
+    float ps = 2.7557314e-06f;                                  //  1/9!
+    ps = ps * z + -1.9841270e-04f;                              // -1/7!
+    ps = ps * z + 8.3333338e-03f;                               //  1/5!
+    ps = ps * z + -1.6666667e-01f;                              // -1/3!
+    float pc = -2.7557314e-07f;                                 // -1/10!
+    pc = pc * z + 2.4801587e-05f;                               //  1/8!
+    pc = pc * z + -1.3888889e-03f;                              // -1/6!
+    pc = pc * z + 4.1666668e-02f;                               //  1/4!
+    const float sy = (y * z) * ps + y;
+    const float cy = (z * z) * pc + (1.0f - 0.5f * z);
+    s = (2.0f * sy) * cy;
+    c = 1.0f - (2.0f * sy) * sy;
 }
 
 #define HZ_TOPO_CH 32      // azimuths per LDS block
@@ -784,6 +790,7 @@ __global__ __launch_bounds__(256, HZ_TOPO_WG) void k_topo(const float *__restric
     // are formed once per cell (the Cython expression divides per azimuth: same value to a float rounding)
     const float qx = -tx / tz, qy = -ty / tz;
     const double half_pi = 3.14159265358979323846 / 2.0;
+    const float half_pi_f = 1.57079632679489661923f;
     float agg = 0.0f;
     const int half = lane >> 5, col = lane & 31;
     // this lane's share of a block: rows half, half + 2, ... of column `col` (128 B contiguous per half wave and row)
@@ -826,28 +833,23 @@ __global__ __launch_bounds__(256, HZ_TOPO_WG) void k_topo(const float *__restric
             }
             const float as = az_tab[k0 + kk], ac = az_tab[A + k0 + kk];
             const float xf = as * qx + ac * qy;
-            double sn, cs;
-            hz_sincos_halfpi((double)hv, sn, cs);
-            double he = (double)hv;
+            float sn, cs;
+            hz_sincos_halfpi_f(hv, sn, cs);
+            float he = hv;
             // hv < atan(x)  <=>  sin < x cos: the tilted plane hides the horizon (:444 takes the larger angle)
-            if (!(sn >= (double)xf * cs)) {
+            if (!(sn >= xf * cs)) {
                 const float hp = atanf(xf);
-                // Round 5: sine and cosine of the plane's horizon come from its tangent (cos = 1 / sqrt(1 + x^2), sin = x cos) in
-                // float32 -- 5 instructions instead of a second float64 sine / cosine pair (25 float64 instructions that nearly
-                // every wave executed at nearly every azimuth: on sloped terrain some lane always looks uphill).  The value
-                // enters a float32 accumulator (:446) with weight <= 1: a relative 1e-7 here is 1e-7 / azim_num in the result
-                // (the bar is 1e-5; measured against the reference fixtures in tests/test_gpu_prep.py).
+                // sine and cosine of the plane's horizon come from its tangent: cos = 1 / sqrt(1 + x^2), sin = x cos
                 if (!(hv >= hp)) {
-                    he = (double)hp;
+                    he = hp;
                     const float rc = __builtin_amdgcn_rsqf(1.0f + xf * xf);
-                    cs = (double)rc; sn = (double)(xf * rc);
+                    cs = rc; sn = xf * rc;
                 }
             }
             if (KIND == 0) {
-                agg = (float)((double)agg + ((double)(tx * as + ty * ac) * ((half_pi - he) - sn * cs)
-                              + (double)tz * (cs * cs)));                                     // :446-452
+                agg = agg + ((tx * as + ty * ac) * ((half_pi_f - he) - sn * cs) + tz * (cs * cs));      // :446-452
             } else {
-                agg = (float)((double)agg + (1.0 - sn));           // 1 - cos(pi/2 - he), :540
+                agg = agg + (1.0f - sn);                           // 1 - cos(pi/2 - he), :540
             }
         }
     }

@@ -146,6 +146,7 @@ struct HorizonArgs {
     unsigned *left_rec = nullptr;        // HZ_LEFT_WORDS words per record; null: off
     int left_mode = 0;
     unsigned left_base[HZ_LEFT_LEVELS] = {0, 0, 0, 0}, left_cap[HZ_LEFT_LEVELS] = {0, 0, 0, 0};
+    int left_regroup = 0, left_key_shift = 0;      // follow-up launches: compaction threshold (0: as `regroup`), log2 of the class width of the sort key
     uint32_t *left_sort = nullptr;       // sort scratch: 4 arrays of left_cap_max words (keys / values, in / out) + sort_temp_elems(left_cap_max)
     unsigned left_cap_max = 0;
     int no_persist = 0;                  // 1: one tile per workgroup instead of persistent waves (same-box A/Bs, tests)
@@ -160,6 +161,10 @@ struct HorizonArgs {
 };
 // default hand-over thresholds: byte l = level l (hz_opts.left_min)
 #define HZ_LEFT_DEFAULT 0x00000024u
+// follow-up launches (hz_opts.left_tune; swept in round 6, profiles/r06/ab_leftover_tune.log: 73 ms against 76 with classes of one
+// azimuth and the production launch's threshold of 36; classes of 32 azimuths: 95 ms)
+#define HZ_LEFT_KEY_SHIFT 3              // log2 of the width of the azimuths-left classes of the sort key: 8 azimuths
+#define HZ_LEFT_REGROUP 24               // compaction threshold in lanes
 #define HZ_CNT_LEFT 32                   // first u64 word of the leftover control words
 #define HZ_CNT_N 64                      // u64 words in front of the redo list
 #define HZ_LEFT_WORDS 16                 // 32-bit words per leftover record

@@ -148,6 +148,7 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
     opts.left_min = int(_left_min or schedule_overrides.get("left_min", 0))            # leftover cells: byte l = hand-over threshold of level l; 0: default; < 0: off
     opts.persist_grid = int(_persist_grid or schedule_overrides.get("persist_grid", 0))    # 0: persistent waves; < 0: one tile per workgroup; n > 0: n workgroups
     opts.left_cap_test = int(schedule_overrides.get("left_cap_test", 0))
+    opts.left_tune = int(schedule_overrides.get("left_tune", 0))
     n_verify = int(_verify_near)              # False / 0: off; True / 1: every shortened ray; N: one of every N (rounded up to 2^k)
     if n_verify < 0 or n_verify != _verify_near:
         raise ValueError("_verify_near must be a non-negative integer (or a bool)")

@@ -90,6 +90,9 @@ typedef struct hz_opts {
                            /*   n > 0 (tests): persistent with n workgroups, so that small grids run the block loop too    */
     int32_t left_cap_test; /* tests: > 0 caps every sub-region of the leftover records at this many (rounded up to 64), so   */
                            /*   that the out-of-room path runs on small grids                                               */
+    int32_t left_tune;     /* tuning of the follow-up launches (0: defaults): byte 0 = their compaction threshold in lanes   */
+                           /*   (opts.regroup of those launches), byte 1 = 1 + log2 of the width of the azimuths-left        */
+                           /*   classes their cells are sorted into (1: one class per azimuth)                               */
 } hz_opts;
 
 /* Run-time self report (the quantities the reference prints,                  */
@@ -136,7 +139,7 @@ typedef struct hz_stats {
 const char *hz_last_error(void);
 /* sizeof(hz_opts), sizeof(hz_stats) as compiled: lets a binding verify its mirror */
 int hz_abi_struct_sizes(int *opts_bytes, int *stats_bytes);
-/* ABI revision.  6 (round 6): opts.left_min, persist_grid, left_cap_test and hz_stats.left_again, scratch_bytes, left_redo_groups appended.  5 (round 5): hz_stats.t_left_s, left_cells appended.  4 (round 4): hz_stats.near_verified appended; opts.verify_near is a sampling period (1 = every ray, as   */
+/* ABI revision.  6 (round 6): opts.left_min, persist_grid, left_cap_test, left_tune and hz_stats.left_again, scratch_bytes, left_redo_groups appended.  5 (round 5): hz_stats.t_left_s, left_cells appended.  4 (round 4): hz_stats.near_verified appended; opts.verify_near is a sampling period (1 = every ray, as   */
 /* before).  3 (round 3): {row_begin > 0, row_end = 0} is rejected (was "to the end": use row_end = -1); opts.regroup <= 0 */
 /* means the default threshold (was: 0 = ray compaction off; 64 | bias << 8 still disables the early exit in effect)     */
 int hz_abi_version(void);

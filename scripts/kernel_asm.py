@@ -1,7 +1,8 @@
 """Device assembly of the traversal kernels, normalised, and its hash.
 
-    python scripts/kernel_asm.py sha [tree]           -> one sha256 over the normalised gfx950 assembly of hz_horizon.hip, hz_shadow.hip and
-                                                          hz_locations.hip of `tree` (default: this repository)
+    python scripts/kernel_asm.py sha [tree]           -> one sha256 over the normalised gfx950 assembly of the kernels the counter files
+                                                          describe (PROFILED: production launch of k_horizon, its follow-up launch,
+                                                          k_shadow_refill) of `tree` (default: this repository)
     python scripts/kernel_asm.py diff treeA treeB      -> per source file: identical, or the kernels whose bodies differ (exit status 1)
     python scripts/kernel_asm.py stamp                 -> writes profiles/kernel_asm.sha (the stamp profiles/valu_model.json, traffic.json and
                                                           valu_class_mix.json carry: they describe THIS machine code, not the source text)
@@ -69,11 +70,23 @@ def assemblies(tree):
         return dict(zip(SOURCES, ex.map(lambda s_: normalise(assembly(tree, s_)), SOURCES)))
 
 
+# the kernels the counter files under profiles/ describe: production launch of k_horizon, its follow-up launch, the shadow kernel
+PROFILED = ("_ZN2hz9k_horizonILi2ELb0ELb1ELb0ELb0ELb0EEEvNS_13HorizonParamsE", "_ZN2hz9k_horizonILi2ELb0ELb1ELb0ELb0ELb1EEEvNS_13HorizonParamsE",
+            "_ZN2hz15k_shadow_refillILb0ELb1EEEvNS_12ShadowParamsE")
+
+
 def sha(tree=ROOT):
+    """sha256 over the normalised bodies of the PROFILED kernels (a change of any other kernel of these files does not move it)."""
     h = hashlib.sha256()
     asm = assemblies(tree)
+    found = {}
     for src in SOURCES:
-        for t in asm[src]:
+        found.update(kernels(asm[src]))
+    for name in PROFILED:
+        if name not in found:
+            raise RuntimeError("kernel %s not found in the assembly of %s" % (name, ", ".join(SOURCES)))
+        h.update(name.encode()); h.update(b"\n")
+        for t in found[name]:
             h.update(t.encode()); h.update(b"\n")
     return h.hexdigest()
 

@@ -28,6 +28,7 @@ ap.add_argument("--no-near", action="store_true", help="switch the near-field ce
 ap.add_argument("--verify-near", action="store_true")
 ap.add_argument("--left", type=lambda x: int(x, 0), default=0, help="hz_opts.left_min: byte l = hand-over threshold of level l (0: default, -1: off)")
 ap.add_argument("--pgrid", type=int, default=0, help="hz_opts.persist_grid")
+ap.add_argument("--tune", type=lambda x: int(x, 0), default=0, help="hz_opts.left_tune")
 ap.add_argument("--verify-sample", type=int, default=0, help="production kernel with the sampled certificate check: one of every N shortened rays")
 args = ap.parse_args()
 
@@ -38,6 +39,7 @@ n, w = args.n, args.win
 off = (n - w) // 2
 vec_norm, vec_north = synth.planar_frames(w, w)
 t = time.time()
+hz.horizon.schedule_overrides["left_tune"] = args.tune
 sc = hz.Scene.create(g["vert_grid"], n, n)
 print("scene create %.2fs" % (time.time() - t), json.dumps(sc.stats), flush=True)
 for rep in range(args.reps):

@@ -35,7 +35,7 @@ def test_abi_revision_and_struct_mirrors():
     a, b = C.c_int(0), C.c_int(0)
     assert L.hz_abi_struct_sizes(C.byref(a), C.byref(b)) == 0
     assert a.value == C.sizeof(_lib.hz_opts) and b.value == C.sizeof(_lib.hz_stats)
-    assert _lib.hz_stats._fields_[-1][0] == "left_redo_groups" and _lib.hz_opts._fields_[-1][0] == "left_cap_test"
+    assert _lib.hz_stats._fields_[-1][0] == "left_redo_groups" and _lib.hz_opts._fields_[-1][0] == "left_tune"
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for name, _ in _lib.hz_opts._fields_:
         assert re.search(r"\b%s\b" % name, doc), name
