@@ -823,7 +823,8 @@ static int horizon_run(const Scene *sc, const float *vec_norm, const float *vec_
                     HorizonArgs b = a;
                     b.left_mode = l; b.left_min = l < n_left_launches ? left_t[l] : 0;
                     // a single follow-up launch runs the stack discipline of the production launch (a group whose fast stack overflows is
-                    // computed again, below); with several levels they run one entry per level: nothing can overflow there
+                    // computed again, below, from the sorted order this launch used); with several levels they run one entry per level:
+                    // nothing can overflow there (and the next level's sort reuses the buffers of this one's)
                     if (n_left_launches > 1) b.level_stack = 1;
                     b.tile_list = nullptr; b.n_list = 0;
                     r = horizon_launch(sc, b, st, nullptr);

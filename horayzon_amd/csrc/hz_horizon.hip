@@ -16,7 +16,8 @@
 //                   of a queue is that of the XCD-aware tile map: each of the 8 XCDs walks compact patches
 //                   of 16 x 16 tiles, so that one XCD's L2 sees one region of the BVH.  (Launches with fewer
 //                   tiles than that, redo launches and the counting monitor: workgroup b = tile b, wave = quadrant.)
-//   leftover cells: a block ends when at most 16 of its cells are unfinished; a second launch (LEFT) finishes those.
+//   leftover cells: a block ends when at most 36 of its cells are unfinished (hz_opts.left_min); their records are sorted by
+//                   (azimuths left, position) and a follow-up launch (LEFT) finishes them, 64 per wave.
 //
 // Per lane a small state machine (Search) produces the next elevation sample as
 // soon as the previous occlusion query finishes; lanes never wait for an azimuth

@@ -174,7 +174,19 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
             const float tx = p.vec_north[3 * cell], ty = p.vec_north[3 * cell + 1], tz = p.vec_north[3 * cell + 2];
             const float nn = (nx * nx + ny * ny) + nz * nz, tt = (tx * tx + ty * ty) + tz * tz, nt = (nx * tx + ny * ty) + nz * tz;
             if (!(__builtin_fabsf(nn - 1.0f) <= 1.0e-4f && __builtin_fabsf(tt - 1.0f) <= 1.0e-4f && __builtin_fabsf(nt) <= 1.0e-4f)) bad = 1;
-        }
+            // Round 6 (sweep seed 64003, configurations 734 and 1377): how far the ray of table azimuth k can lie BESIDE the
+            // half-plane H_k this construction cuts the window with.  In the coordinates used here (dot products with east, north,
+            // norm) the direction a e + b t + c n has the components (a |e|^2, b |t|^2 + c n.t, c |n|^2 + b n.t): its azimuth is off
+            // by <= | |n|^2 - 1 | + | |t|^2 - 1 | (|e|^2 / |t|^2 = |n|^2 (1 - (n.t)^2)) and it leaves H_k sideways by |n.t| per unit of
+            // HEIGHT.  At a crossing at horizontal distance r and height z the plane of the ray therefore passes within
+            //     d_lat = |z| k_nt + r k_len
+            // of the crossing computed for H_k.  On ordinary terrain that is nothing; next to a 300 m spike on a 1 m grid (lateral
+            // slope 300) 9 mm sideways are 2.7 m of height -- the certificate of the cell beside the spike let rays start behind a
+            // face they hit (one horizon value per configuration one search step low; found by the full-length re-trace).
+            // The two factors travel in flags[1], flags[2]; phase 1 widens the bins by d_lat / r, phase 2 the crossing interval.
+            flags[1] = __float_as_int(__builtin_fabsf(nt) + 1.0e-7f);
+            flags[2] = __float_as_int(__builtin_fabsf(nn - 1.0f) + __builtin_fabsf(tt - 1.0f) + 1.0e-6f);
+        } else { flags[1] = 0; flags[2] = 0; }
         flags[0] = (bad ? HZ_NR_FRAME : 0) | (bad_mesh ? HZ_NR_BAD_MESH : 0);
     }
     __syncthreads();
@@ -207,7 +219,8 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
                     if (__builtin_fabsf(dl) > 2.9f) atomicOr(&flags[0], HZ_NR_EDGE_OVER_AXIS);    // the edge passes (almost) over the origin
                     else {
                         const float lo = dl >= 0.0f ? pa : pb, span = __builtin_fabsf(dl);
-                        const float m_az = 2.0e-3f + 0.02f / rmin;   // end points within the tolerance count as in the plane
+                        // end points within the tolerance count as in the plane; + how far the ray's own plane can be off (flags[1..2])
+                        const float m_az = 2.0e-3f + 0.02f / rmin + (__builtin_fmaxf(__builtin_fabsf(az), __builtin_fabsf(bz)) * __int_as_float(flags[1])) / rmin + __int_as_float(flags[2]);
                         // (grids with centimetre spacing: the tolerance would span a large part of the circle and the
                         //  bins would leave the (-A, 2 A) range phase 2 wraps once -- no certificate for such a cell)
                         if (m_az > 0.25f) atomicOr(&flags[0], HZ_NR_AZ_TOLERANCE);
@@ -262,6 +275,9 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
             const float er = 6.0e-7f * (ra + rb), ez = 6.0e-7f * ((__builtin_fabsf(az) + __builtin_fabsf(bz)) + (ra + rb));
             const float dz = bz - az;
             const float ninf = -__builtin_inff();
+            // lateral uncertainty of the cutting plane at this edge: rounding of da / db (two rounded products and a difference:
+            // <= 4 * 2^-24 r each) + the ray's own offset from H_k (frame terms of this cell: flags[1..2], see above)
+            const float dl = 4.0e-7f * r_big + __builtin_fmaxf(__builtin_fabsf(az), __builtin_fabsf(bz)) * __int_as_float(flags[1]) + r_big * __int_as_float(flags[2]);
             int k = first;                                           // first lies in (-A, 2 A): wrapped once, then stepped
             if (k < 0) k += A;
             if (k >= A) k -= A;
@@ -273,19 +289,20 @@ __global__ __launch_bounds__(256) void k_near_cert(NearParams p) {
                 const float fa = ae * sp + an * cp, fb = be * sp + bn * cp;     // along the azimuth (r of the end points)
                 // (end points that lie IN the plane -- within the tolerance -- bound themselves: the vertex phase below)
                 float cand = ninf;
-                if ((da < 0.0f) != (db < 0.0f)) {
-                    // The edge crosses the plane at parameter t = da / (da - db).  da and db are differences of two
-                    // rounded products: |error| <= 4 * 2^-24 * r each, so |t - t_exact| <= dt (first order, a factor 1.6 in
-                    // hand).  With x(t) = z(t) / r(t), z and r linear in t:  x(tau) - x(t) = (tau - t) (dz r(t) - z(t) df) /
+                if (__builtin_fminf(da, db) <= dl && __builtin_fmaxf(da, db) >= -dl) {
+                    // The edge crosses the plane -- or ends within dl of it: the plane of the ray may cross it there -- at parameter
+                    // t = da / (da - db), clamped to the edge (an edge that only comes NEAR is evaluated at its near end).  The plane
+                    // is known to within dl sideways, so |t - t_exact| <= dt = dl / |da - db| (a factor 1.6 in hand for the rounding
+                    // part).  With x(t) = z(t) / r(t), z and r linear in t:  x(tau) - x(t) = (tau - t) (dz r(t) - z(t) df) /
                     // (r(tau) r(t))  EXACTLY, hence |x(tau) - x(t)| <= dt (|dz| + |x| |df|) / (0.95 r) for |tau - t| <= dt as
                     // long as dt |df| <= 0.05 r: the candidate is x + that bound (v_rcp_f32: 1 ulp, inside the margins).
                     const float rden = __builtin_amdgcn_rcpf(da - db);
-                    const float dt = 4.0e-7f * r_big * __builtin_fabsf(rden) + 1.0e-6f;
+                    const float dt = dl * __builtin_fabsf(rden) + 1.0e-6f;
                     if (!(dt <= 0.1f)) {
                         // both end points within rounding of the plane: the edge lies IN it; its end-point values bound it
                         if (!(__builtin_fabsf(da) <= tol_a && __builtin_fabsf(db) <= tol_b)) atomicOr(&flags[0], HZ_NR_INPLANE_EDGE);
                     } else {
-                        const float t = da * rden, df = fb - fa;
+                        const float t = __builtin_fminf(__builtin_fmaxf(da * rden, 0.0f), 1.0f), df = fb - fa;
                         const float r = fa + t * df, z = az + t * dz;
                         if (r > 0.0f) {
                             const float rr = __builtin_amdgcn_rcpf(r);

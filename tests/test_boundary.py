@@ -389,3 +389,16 @@ def test_profile_stamp_is_the_hash_of_the_device_assembly(tmp_path):
     for name, key in (("valu_model.json", "valu_model"), ("valu_class_mix.json", "class_mix_note")):
         stamp = json.load(open(os.path.join(ROOT, "profiles", name))).get("kernel_asm_sha")
         assert notes[key].startswith("profiles/" + name) == (stamp == built), (name, notes[key])
+
+
+def test_debug_knobs_are_explicit_calls_not_environment_variables():
+    """Round 6: the shared library reads no environment variable; the two process-wide test knobs are set
+    through hz_debug_set, which rejects unknown keys."""
+    import subprocess
+    L = _lib.lib()
+    assert L.hz_debug_set(b"topo_wide", 1) == 0 and L.hz_debug_set(b"topo_wide", 0) == 0
+    assert L.hz_debug_set(b"shadow_fast_cap", 6) == 0 and L.hz_debug_set(b"shadow_fast_cap", -1) == 0
+    assert L.hz_debug_set(b"no_such_knob", 1) != 0 and b"unknown key" in L.hz_last_error()
+    assert L.hz_debug_set(None, 1) != 0
+    out = subprocess.run(["nm", "-D", "--undefined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in out

@@ -182,3 +182,26 @@ def test_tilted_frame_against_very_steep_terrain(hip, orc):
     assert st["near_used"] == 1 and st["near_violations"] == 0
     assert np.array_equal(out[0], ref, equal_nan=True)
     assert st["num_rays"] == so["rays"] and st["guard_events"] == so["guards"] == 539
+
+
+def test_cell_beside_a_spike_with_a_frame_that_is_not_quite_orthonormal(hip, orc):
+    """Round 6, found by the long adversarial sweep of seed 64003 (configurations 734 and 1377; scripts/r06/diag_64003.py): a 300 m
+    spike on a 1 m grid next to the cell, `vec_norm` 1.5e-5 too long and 3e-5 off the right angle with `vec_north`.  In the
+    coordinates of the certificate pre-pass the ray leaves the half-plane H_k of its table azimuth by |n.t| per unit of height --
+    9 mm beside the spike's face, i.e. 2.7 m of height on a face of slope 300 -- and the certificate let two rays start behind a
+    face they hit: ONE horizon value per configuration came out one search step low (the oracle and the run without certificates
+    agreed with each other).  hz_near.hip now widens the crossing interval by that offset (DESIGN_CERTIFICATES.md).  Replayed from
+    the generator: production path == oracle, and every shortened ray re-traced over its full length takes the same decision."""
+    rng = np.random.default_rng(64003 + 7)
+    for it in range(1378):
+        kw, par, desc = cases.adversarial_near_case(rng)
+        if it not in (734, 1377):
+            continue
+        ho, _, so = orc.horizon_gridded(**kw, **par, return_stats=True)
+        h, _ = hip.horizon.horizon_gridded(**kw, **par)
+        st = dict(hip.horizon.last_stats)
+        assert np.array_equal(h, ho, equal_nan=True), (it, desc, np.argwhere(h != ho)[:4].tolist())
+        assert st["num_rays"] == so["rays"] and st["guard_events"] == so["guards"]
+        hv, _ = hip.horizon.horizon_gridded(**kw, **par, count_work=True, _verify_near=1)
+        sv = dict(hip.horizon.last_stats)
+        assert np.array_equal(hv, ho, equal_nan=True) and sv["near_violations"] == 0 and sv["near_verified"] == sv["rays_shortened"] > 0
