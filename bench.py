@@ -830,6 +830,8 @@ def roofline(args, stats, steps, cw, peaks, A, n, rps):
     r.update({"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s (algorithmic, cache-served)",
               "frac": alg / HBM_PEAK_GBS if alg else None})
     r["frac_8d_hbm_model"] = r["frac"]
+    # (algorithmic bytes are cache-served: the figure CAN exceed 1 -- said explicitly when it does, never capped)
+    r["frac_exceeds_1_cache_served"] = bool(r["frac"] is not None and r["frac"] > 1.0)
     r["binding_resource"] = "valu_issue" if "valu" in r else "unknown (no counter pass)"
     r["frac_is"] = ("SURVEY 8(d): algorithmic bytes / kernel time / HBM peak -- cache-served, not HBM traffic; hbm.hbm_frac is the "
                     "counter-measured HBM utilisation; the kernel is VALU-issue bound: valu.frac_model_raw (class model, mean-priced, "
@@ -1174,6 +1176,7 @@ def c4_roofline(n, S, cells, shadow, k_step, cw, refrac, peaks, cr):
     # contract fields as SURVEY 8(d) writes them (algorithmic bytes, cache-served; see hbm.note); the binding resource is the VALU port
     roof.update({"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s (algorithmic, cache-served, see hbm.note)",
                  "frac": alg / HBM_PEAK_GBS if alg else None, "frac_8d_hbm_model": alg / HBM_PEAK_GBS if alg else None,
+                 "frac_exceeds_1_cache_served": bool(alg and alg / HBM_PEAK_GBS > 1.0),
                  "binding_resource": "valu_issue" if "valu" in roof else "unknown (no counter pass)"})
     return roof
 

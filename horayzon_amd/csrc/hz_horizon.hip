@@ -531,7 +531,7 @@ static int launch_one(const HorizonParams &p_in, int grid, size_t lds, int persi
 }
 
 // The LEFT instantiation: always persistent -- how many records there are is only known on the device (left_in_ctl), so the launch has
-// the resident number of workgroups and every wave pulls groups of 64 records until the sub-regions are empty.
+// the resident number of workgroups and every wave pulls groups of 64 sorted records until none is left.
 // (with a list -- the groups to repeat after a stack overflow -- one group per wave of a plain launch)
 template <int ALG, bool STAGE, bool LS>
 static int launch_left(const HorizonParams &p, size_t lds, int persist_grid, hipStream_t st) {

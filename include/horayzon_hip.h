@@ -88,7 +88,7 @@ typedef struct hz_opts {
     int32_t persist_grid;  /* 0 (default): persistent waves -- a launch has as many workgroups as are resident at once and */
                            /*   every wave pulls 8 x 8 blocks from its XCD's queue; < 0: one 16 x 16 tile per workgroup;   */
                            /*   n > 0 (tests): persistent with n workgroups, so that small grids run the block loop too    */
-    int32_t left_cap_test; /* tests: > 0 caps every sub-region of the leftover records at this many (rounded up to 64), so   */
+    int32_t left_cap_test; /* tests: > 0 caps every region of the leftover records at this many (rounded up to 64), so       */
                            /*   that the out-of-room path runs on small grids                                               */
     int32_t left_tune;     /* tuning of the follow-up launches (0: defaults): byte 0 = their compaction threshold in lanes   */
                            /*   (opts.regroup of those launches), byte 1 = 1 + log2 of the width of the azimuths-left        */
