@@ -205,3 +205,46 @@ def test_cell_beside_a_spike_with_a_frame_that_is_not_quite_orthonormal(hip, orc
         hv, _ = hip.horizon.horizon_gridded(**kw, **par, count_work=True, _verify_near=1)
         sv = dict(hip.horizon.last_stats)
         assert np.array_equal(hv, ho, equal_nan=True) and sv["near_violations"] == 0 and sv["near_verified"] == sv["rays_shortened"] > 0
+
+
+def test_spikes_beside_cells_with_frames_skewed_up_to_the_refusal_threshold(hip, orc):
+    """The worst case of rows F' / C' of DESIGN_CERTIFICATES.md, aimed at directly (the seeded generator only draws skews of 3e-5 and
+    2e-3): 1 m grids with 300 m and 1000 m spikes, frames rotated about the vertical by random angles, `vec_north` up to 9.5e-5 off the
+    right angle with `vec_norm` in either direction and `vec_norm` up to 5e-5 too long or too short (the frame check refuses at
+    1e-4), ray origins 0.01 ... 20 m above the ground.  Production path == oracle; every shortened ray re-traced over its full length
+    takes the same decision; and the certificates are still in use (a useful share of the rays is shortened)."""
+    rng = np.random.default_rng(6401)
+    shortened = 0
+    for it in range(40):
+        n0, n1 = int(rng.integers(11, 17)), int(rng.integers(11, 17))
+        z = np.full((n0, n1), 100.0)
+        for _ in range(int(rng.integers(1, 4))):
+            z[int(rng.integers(2, n0 - 2)), int(rng.integers(2, n1 - 2))] += float(rng.choice([300.0, 1000.0, 30.0]))
+        x = np.arange(n1, dtype=np.float32)
+        y = (n0 - 1 - np.arange(n0)).astype(np.float32)
+        xx, yy = np.meshgrid(x, y)
+        off = 2
+        in0, in1 = n0 - 2 * off, n1 - 2 * off
+        rot = rng.uniform(0.0, 2.0 * np.pi, (in0, in1, 1))
+        nrm = np.zeros((in0, in1, 3)); nrm[..., 2] = 1.0
+        north = np.concatenate([np.sin(rot), np.cos(rot), np.zeros_like(rot)], axis=2)
+        s_nt = rng.uniform(2.0e-5, 9.5e-5, (in0, in1, 1)) * rng.choice([-1.0, 1.0], (in0, in1, 1))
+        s_len = rng.uniform(-5.0e-5, 5.0e-5, (in0, in1, 1))
+        north = north + s_nt * nrm
+        nrm = nrm * (1.0 + s_len)
+        kw = dict(vert_grid=synth.pack_vertices(xx, yy, z.astype(np.float32)), dem_dim_0=n0, dem_dim_1=n1,
+                  vec_norm=np.ascontiguousarray(nrm, np.float32), vec_north=np.ascontiguousarray(north, np.float32),
+                  offset_0=off, offset_1=off)
+        par = dict(dist_search=float(rng.choice([0.004, 0.012])), azim_num=360, hori_acc=float(rng.choice([0.1, 0.25])),
+                   ray_algorithm=str(rng.choice(["guess_constant", "binary_search"])), elev_ang_low_lim=float(rng.choice([-45.0, -89.98])),
+                   ray_org_elev=float(rng.choice([0.01, 2.0, 20.0])))
+        ho, _, so = orc.horizon_gridded(**kw, **par, return_stats=True)
+        h, _ = hip.horizon.horizon_gridded(**kw, **par)
+        st = dict(hip.horizon.last_stats)
+        assert np.array_equal(h, ho, equal_nan=True), (it, par, np.argwhere(h != ho)[:4].tolist())
+        assert st["num_rays"] == so["rays"] and st["guard_events"] == so["guards"], (it, par)
+        hv, _ = hip.horizon.horizon_gridded(**kw, **par, count_work=True, _verify_near=1)
+        sv = dict(hip.horizon.last_stats)
+        assert np.array_equal(hv, ho, equal_nan=True) and sv["near_violations"] == 0, (it, par, sv["near_violations"])
+        shortened += int(sv["rays_shortened"] > 0)
+    assert shortened >= 20
