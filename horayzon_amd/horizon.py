@@ -10,6 +10,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+from . import _validate as V
 from ._lib import Scene, hz_opts, hz_stats, ptr
 
 last_stats = None   # hz_stats of the most recent call as a dict (timers, ray count)
@@ -70,52 +71,28 @@ def horizon_gridded(vert_grid, dem_dim_0, dem_dim_1, vec_norm, vec_north,
     if mask is not None and (not isinstance(mask, np.ndarray) or mask.ndim != 2):
         raise ValueError("Buffer has wrong number of dimensions (expected 2) for mask")
 
-    # Check consistency and validity of input arguments (horizon.pyx:109-146)
-    if len(vert_grid) < (dem_dim_0 * dem_dim_1 * 3):
-        raise ValueError("inconsistency between input arguments vert_grid, "
-                         "dem_dim_0 and dem_dim_1")
-    if ((offset_0 + vec_norm.shape[0] > dem_dim_0)
-            or (offset_1 + vec_norm.shape[1] > dem_dim_1)):
-        raise ValueError("inconsistency between input arguments dem_dim_0, "
-                         "dem_dim_1, offset_0, offset_1 and vec_norm")
-    if ((vec_norm.ndim != 3) or (vec_north.ndim != 3)
-            or (vec_norm.shape[0] != vec_north.shape[0])
-            or (vec_norm.shape[1] != vec_north.shape[1])
-            or (vec_norm.shape[2] != vec_north.shape[2])):
-        raise ValueError("dimension (lengths) of vec_norm and/or vec_north "
-                         "is/are erroneous")
-    if ray_algorithm not in ("discrete_sampling", "binary_search",
-                             "guess_constant"):
-        raise ValueError("invalid input argument for ray_algorithm")
-    if geom_type not in ("triangle", "quad", "grid"):
-        raise ValueError("invalid input argument for geom_type")
-    if len(vert_simp) < (num_vert_simp * 3):
-        raise ValueError("inconsistency between input arguments vert_simp "
-                         "and num_vert_simp")
-    if len(tri_ind_simp) < (num_tri_simp * 3):
-        raise ValueError("inconsistency between input arguments tri_ind_simp "
-                         "and num_tri_simp")
-    if tri_ind_simp.max() > (num_vert_simp - 1):
-        raise ValueError("triangle indices of simplified outer domain exceed "
-                         "number of vertices")
-    if hori_acc > 10.0:
-        raise ValueError("limit of hori_acc (10 degree) is exceeded")
+    # Consistency and validity of the arguments: the reference's checks, classes, messages and order (horizon.pyx:109-153)
     if mask is None:
-        mask = np.ones((vec_norm.shape[0], vec_norm.shape[1]), dtype=np.uint8)
-    if (mask.shape[0] != vec_norm.shape[0]) \
-            or (mask.shape[1] != vec_norm.shape[1]):
-        raise ValueError("shape of mask is inconsistent with other input")
-    if mask.dtype != "uint8":
-        raise TypeError("data type of mask must be 'uint8'")
-    if ray_org_elev < 0.005:
-        raise TypeError("minimal allowed value for 'ray_org_elev' is 0.005 m")
-
-    # Check size of input geometries (horizon.pyx:149-153)
-    if (dem_dim_0 > 32767) or (dem_dim_1 > 32767):
-        raise ValueError("maximal allowed input length for dem_dim_0 and "
-                         "dem_dim_1 is 32'767")
-    if vert_simp.nbytes > (16.0 * 10 ** 9):
-        raise ValueError("vertex buffer vert_simp is larger than 16 GB")
+        mask = np.ones(vec_norm.shape[:2], dtype=np.uint8)
+    V.run((
+        (ValueError, "inconsistency between input arguments vert_grid, dem_dim_0 and dem_dim_1",
+         lambda: not V.fits_grid(len(vert_grid), dem_dim_0, dem_dim_1)),
+        (ValueError, "inconsistency between input arguments dem_dim_0, dem_dim_1, offset_0, offset_1 and vec_norm",
+         lambda: not V.window_inside(offset_0, offset_1, vec_norm.shape, dem_dim_0, dem_dim_1)),
+        (ValueError, V.MSG_NORTH, lambda: not V.same_leading_shape((vec_norm, vec_north), 3, 3)),
+        (ValueError, V.MSG_ALG, lambda: ray_algorithm not in V.ALGORITHMS),
+        (ValueError, V.MSG_GEOM, lambda: geom_type not in V.GEOMETRIES),
+        (ValueError, "inconsistency between input arguments vert_simp and num_vert_simp", lambda: len(vert_simp) < num_vert_simp * 3),
+        (ValueError, "inconsistency between input arguments tri_ind_simp and num_tri_simp", lambda: len(tri_ind_simp) < num_tri_simp * 3),
+        (ValueError, "triangle indices of simplified outer domain exceed number of vertices",
+         lambda: tri_ind_simp.max() > num_vert_simp - 1),
+        (ValueError, V.MSG_ACC, lambda: hori_acc > 10.0),
+        (ValueError, "shape of mask is inconsistent with other input", lambda: mask.shape[:2] != vec_norm.shape[:2]),
+        (TypeError, V.MSG_MASK_TYPE, lambda: mask.dtype != "uint8"),
+        (TypeError, V.MSG_ELEV, lambda: ray_org_elev < 0.005),
+        (ValueError, V.MSG_DIM_LIMIT, lambda: max(dem_dim_0, dem_dim_1) > V.DIM_LIMIT),
+        (ValueError, "vertex buffer vert_simp is larger than 16 GB", lambda: vert_simp.nbytes > 16.0e9),
+    ))
 
     # Ensure that passed arrays are contiguous in memory (horizon.pyx:159-163)
     vert_grid = np.ascontiguousarray(vert_grid)
@@ -263,39 +240,23 @@ def horizon_locations(vert_grid, dem_dim_0, dem_dim_1, coords, vec_norm, vec_nor
     _check_f32(vec_north, 2, "vec_north")
     _check_f32(ray_org_elev, 1, "ray_org_elev")
 
-    # Check consistency and validity of input arguments (horizon.pyx:279-307)
-    if len(vert_grid) < (dem_dim_0 * dem_dim_1 * 3):
-        raise ValueError("inconsistency between input arguments vert_grid, "
-                         "dem_dim_0 and dem_dim_1")
-    if ((coords.ndim != 2) or (coords.shape[0] != vec_norm.shape[0])
-            or (coords.shape[1] != 3)):
-        raise ValueError("'number of dimensions and/or dimension "
-                         + "length(s) of 'coords' incorrect")
-    if ((vec_norm.ndim != 2) or (vec_north.ndim != 2)
-            or (vec_norm.shape[0] != vec_north.shape[0])
-            or (vec_norm.shape[1] != vec_north.shape[1])):
-        raise ValueError("dimension (lengths) of vec_norm and/or vec_north "
-                         "is/are erroneous")
-    if ray_algorithm not in ("discrete_sampling", "binary_search",
-                             "guess_constant"):
-        raise ValueError("invalid input argument for ray_algorithm")
-    if geom_type not in ("triangle", "quad", "grid"):
-        raise ValueError("invalid input argument for geom_type")
-    if hori_acc > 10.0:
-        raise ValueError("limit of hori_acc (10 degree) is exceeded")
-    if (len(ray_org_elev) != 1) and (len(ray_org_elev) != coords.shape[0]):
-        raise ValueError("length of array 'ray_org_elev' must be either "
-                         + "one or correspond to the number of locations")
-    if ray_org_elev.min() < 0.005:
-        raise TypeError("minimal allowed value for 'ray_org_elev' is 0.005 m")
-    if hori_dist_out and (ray_algorithm == "guess_constant"):
-        raise TypeError("horizon detection algorithm 'guess_constant' not "
-                        + "implemented for horizon distance computation")
-
-    # Check size of input geometries (horizon.pyx:310-312)
-    if (dem_dim_0 > 32767) or (dem_dim_1 > 32767):
-        raise ValueError("maximal allowed input length for dem_dim_0 and "
-                         "dem_dim_1 is 32'767")
+    # Consistency and validity of the arguments: the reference's checks, classes, messages and order (horizon.pyx:279-312)
+    V.run((
+        (ValueError, "inconsistency between input arguments vert_grid, dem_dim_0 and dem_dim_1",
+         lambda: not V.fits_grid(len(vert_grid), dem_dim_0, dem_dim_1)),
+        (ValueError, "'number of dimensions and/or dimension length(s) of 'coords' incorrect",
+         lambda: coords.ndim != 2 or coords.shape != (vec_norm.shape[0], 3)),
+        (ValueError, V.MSG_NORTH, lambda: not V.same_leading_shape((vec_norm, vec_north), 2, 2)),
+        (ValueError, V.MSG_ALG, lambda: ray_algorithm not in V.ALGORITHMS),
+        (ValueError, V.MSG_GEOM, lambda: geom_type not in V.GEOMETRIES),
+        (ValueError, V.MSG_ACC, lambda: hori_acc > 10.0),
+        (ValueError, "length of array 'ray_org_elev' must be either one or correspond to the number of locations",
+         lambda: len(ray_org_elev) not in (1, coords.shape[0])),
+        (TypeError, V.MSG_ELEV, lambda: ray_org_elev.min() < 0.005),
+        (TypeError, "horizon detection algorithm 'guess_constant' not implemented for horizon distance computation",
+         lambda: bool(hori_dist_out) and ray_algorithm == "guess_constant"),
+        (ValueError, V.MSG_DIM_LIMIT, lambda: max(dem_dim_0, dem_dim_1) > V.DIM_LIMIT),
+    ))
 
     # Repeat array 'ray_org_elev' if necessary (horizon.pyx:315-316)
     if len(ray_org_elev) != coords.shape[0]:

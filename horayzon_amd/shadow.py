@@ -11,6 +11,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
+from . import _validate as V
 from ._lib import hz_stats, ptr
 
 
@@ -57,54 +58,26 @@ class Terrain:
         _typed(elevation, np.float32, 2, "elevation")
         _typed(mask, np.uint8, 2, "mask")
 
-        # Check consistency and validity of input arguments (shadow.pyx:87-133)
-        if len(vert_grid) < (dem_dim_0 * dem_dim_1 * 3):
-            raise ValueError("inconsistency between input arguments "
-                             + "'vert_grid', 'dem_dim_0' and 'dem_dim_1'")
-        if ((offset_0 + vec_tilt.shape[0] > dem_dim_0)
-                or (offset_1 + vec_tilt.shape[1] > dem_dim_1)):
-            raise ValueError("inconsistency between input arguments "
-                             + "'dem_dim_0', 'dem_dim_1', 'offset_0', "
-                             + "'offset_1' and 'vec_norm'")
-        if ((vec_tilt.ndim != 3) or (vec_norm.ndim != 3)
-                or (vec_tilt.shape[2] != 3)
-                or (vec_tilt.shape[0] != vec_norm.shape[0])
-                or (vec_tilt.shape[1] != vec_norm.shape[1])
-                or (vec_tilt.shape[2] != vec_norm.shape[2])):
-            raise ValueError("Inconsistent/incorrect shape of 'vec_tilt' "
-                             + "and/or 'vec_norm'")
-        if ((surf_enl_fac.ndim != 2) or (elevation.ndim != 2)
-                or (mask.ndim != 2)
-                or (surf_enl_fac.shape[0] != vec_tilt.shape[0])
-                or (surf_enl_fac.shape[1] != vec_tilt.shape[1])
-                or (elevation.shape[0] != vec_tilt.shape[0])
-                or (elevation.shape[1] != vec_tilt.shape[1])
-                or (mask.shape[0] != vec_tilt.shape[0])
-                or (mask.shape[1] != vec_tilt.shape[1])):
-            raise ValueError("Inconsistent/incorrect shape of 'surf_enl_fac', "
-                             + " 'elevation' and/or 'mask'")
-        if ((not vert_grid.flags["C_CONTIGUOUS"])
-                or (not vec_tilt.flags["C_CONTIGUOUS"])
-                or (not vec_norm.flags["C_CONTIGUOUS"])
-                or (not surf_enl_fac.flags["C_CONTIGUOUS"])
-                or (not elevation.flags["C_CONTIGUOUS"])
-                or (not mask.flags["C_CONTIGUOUS"])):
-            raise ValueError("not all input arrays are C-contiguous")
-        if ((np.abs((vec_tilt ** 2).sum(axis=2) - 1.0).max() > 1.0e-5)
-                or (np.abs((vec_norm ** 2).sum(axis=2) - 1.0).max() > 1.0e-5)):
-            raise ValueError("Vectors in 'vec_tilt' and/or 'vec_norm' are "
-                             + "not normalised")
-        if geom_type not in ("triangle", "quad", "grid"):
-            raise ValueError("invalid input argument for geom_type")
-        if mask.dtype != "uint8":
-            raise TypeError("data type of mask must be 'uint8'")
-        if (ang_max < 85.0) or (ang_max > 89.99):
-            raise TypeError("'ang_max' must be in the range [85.0, 89.99]")
-
-        # Check size of input geometries
-        if (dem_dim_0 > 32767) or (dem_dim_1 > 32767):
-            raise ValueError("maximal allowed input length for dem_dim_0 and "
-                             "dem_dim_1 is 32'767")
+        # Consistency and validity of the arguments: the reference's checks, classes, messages and order (shadow.pyx:87-133)
+        cell_arrays = (vec_tilt[..., 0], surf_enl_fac, elevation, mask) if vec_tilt.ndim == 3 else (surf_enl_fac, elevation, mask)
+        V.run((
+            (ValueError, "inconsistency between input arguments 'vert_grid', 'dem_dim_0' and 'dem_dim_1'",
+             lambda: not V.fits_grid(len(vert_grid), dem_dim_0, dem_dim_1)),
+            (ValueError, "inconsistency between input arguments 'dem_dim_0', 'dem_dim_1', 'offset_0', 'offset_1' and 'vec_norm'",
+             lambda: not V.window_inside(offset_0, offset_1, vec_tilt.shape, dem_dim_0, dem_dim_1)),
+            (ValueError, "Inconsistent/incorrect shape of 'vec_tilt' and/or 'vec_norm'",
+             lambda: not V.same_leading_shape((vec_tilt, vec_norm), 3, 3) or vec_tilt.shape[2] != 3),
+            (ValueError, "Inconsistent/incorrect shape of 'surf_enl_fac',  'elevation' and/or 'mask'",
+             lambda: not V.same_leading_shape(cell_arrays, 2, 2)),
+            (ValueError, "not all input arrays are C-contiguous",
+             lambda: not all(a.flags["C_CONTIGUOUS"] for a in (vert_grid, vec_tilt, vec_norm, surf_enl_fac, elevation, mask))),
+            (ValueError, "Vectors in 'vec_tilt' and/or 'vec_norm' are not normalised",
+             lambda: not (V.unit_vectors(vec_tilt) and V.unit_vectors(vec_norm))),
+            (ValueError, V.MSG_GEOM, lambda: geom_type not in V.GEOMETRIES),
+            (TypeError, V.MSG_MASK_TYPE, lambda: mask.dtype != "uint8"),
+            (TypeError, "'ang_max' must be in the range [85.0, 89.99]", lambda: ang_max < 85.0 or ang_max > 89.99),
+            (ValueError, V.MSG_DIM_LIMIT, lambda: max(dem_dim_0, dem_dim_1) > V.DIM_LIMIT),
+        ))
 
         L = _lib.lib()
         st = hz_stats()
